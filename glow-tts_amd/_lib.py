@@ -1,0 +1,74 @@
+"""ctypes binding of libglowtts_hip.so (the C-ABI declared in include/glowtts_hip.h).
+
+The library is the product: there is NO fallback.  `lib()` raises if it is missing or does
+not export a declared symbol.  PyTorch is used by callers only for device memory and streams.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
+
+c_void_p, c_int, c_i64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_size_t, ctypes.c_float)
+
+# name -> (restype, argtypes); mirrors include/glowtts_hip.h one to one
+PROTOTYPES = {
+    "gt_version": (ctypes.c_char_p, []),
+    "gt_mas_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                           c_int, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p]),
+    "gt_mas_lds_bytes": (c_size_t, [c_int, c_int]),
+    "gt_mas_lengths_from_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_i64, c_i64, c_void_p]),
+}
+
+GT_DT_F32, GT_DT_I32, GT_DT_F16, GT_DT_BF16, GT_DT_U8 = 0, 1, 2, 3, 4
+GT_ERRORS = {-1: "GT_E_INVAL", -2: "GT_E_UNSUPPORTED", -3: "GT_E_ALIGN", -4: "GT_E_LAUNCH"}
+
+_LIB = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library; raise loudly if it is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: the HIP extension is not built.  Run "
+                "`python glow-tts_amd/build.py` (or __graft_entry__.build()).  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise HipLibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {GT_ERRORS.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("glow_tts_amd ops run on the MI355X only (got a CPU tensor); "
+                               "there is no CPU fallback — use oracle/ for CPU checking in tests")
