@@ -16,8 +16,9 @@ c_void_p, c_int, c_i64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctyp
 PROTOTYPES = {
     "gt_version": (ctypes.c_char_p, []),
     "gt_mas_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                           c_int, c_int, c_int, c_i64, c_i64, c_void_p, c_void_p]),
+                           c_int, c_int, c_int, c_i64, c_i64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "gt_mas_lds_bytes": (c_size_t, [c_int, c_int]),
+    "gt_mas_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gt_mas_lengths_from_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_i64, c_i64, c_void_p]),
 }

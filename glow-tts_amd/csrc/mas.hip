@@ -3,24 +3,35 @@
 // Replaces reference monotonic_align/core.pyx:9-45 (serial Cython DP) and the
 // copy-heavy wrapper monotonic_align/__init__.py:6-21.  Bit-exact paths.
 //
-// Design (one workgroup per utterance, W = ceil(T_x/64) wavefronts):
+// Two kernels on one stream:
+//
+// (1) gt_mas_dp_kernel — one workgroup per utterance, W = ceil(T_x/64) wavefronts.
 //   * Q[x,y] = max(Q[x,y-1], Q[x-1,y-1]) + v[x,y] only depends on column y-1, so the DP
 //     is column-sequential / row-parallel.  Lane l of wave w owns row x = 64w + l; the
 //     x-1 operand is a one-lane DPP shift (wave_shr:1).
 //   * Rows are split over waves that run skewed by one 32-column chunk ("anti-diagonal
 //     wavefront"): at step s wave w processes chunk s-w; the Q values of its last row
-//     cross to wave w+1 through a 2-slot LDS ring, one __syncthreads() per chunk.
-//   * logp chunks (64 rows x 32 columns per wave) are fetched with coalesced 16-byte
-//     loads one chunk ahead (register prefetch) and staged in an XOR-swizzled LDS tile
-//     so that the per-lane row reads (ds_read_b128) are bank-conflict free.
-//   * max(a,b)+v == max(a+v, b+v) exactly in IEEE arithmetic (rounding is monotone), so
-//     the per-column dependency chain is {add_dpp, max}; the comparison a<b that the
-//     reference's backtrack re-evaluates (core.pyx:34) is emitted as ONE direction bit
-//     per cell and the fp32 lattice is never stored: T_x*T_y bits live in LDS.
-//   * Backtrack: one wave walks rows, not columns — per row a count-leading-zeros on the
+//     cross to wave w+1 through a 2-slot LDS ring, one s_barrier per chunk.
+//   * logp chunks (64 rows x 32 columns per wave) stream HBM -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR staging) into a D-deep per-wave ring, D-1 chunks
+//     ahead, behind counted vmcnt waits.  The XOR swizzle that makes the per-lane row reads
+//     (ds_read_b128) bank-conflict free is applied on the per-lane SOURCE address (the DMA
+//     writes LDS linearly).  Unaligned lattices / the value*mask form use a register-staged
+//     fallback with the same LDS image.
+//   * max(a,b)+v == max(a+v, b+v) exactly in IEEE arithmetic (rounding is monotone), so the
+//     per-column dependency chain is {mov_dpp, add, max}; the comparison a<b that the
+//     reference's backtrack re-evaluates (core.pyx:34) is emitted as ONE direction bit per
+//     cell (v_cmp + v_addc) and the fp32 lattice is never stored: T_x*T_y bits live in LDS.
+//     The steady-state column is 6 VALU + 1 DS instruction, hand-scheduled in inline asm so
+//     that every gfx950 wait-state requirement is met by useful instructions.
+//   * Backtrack: one wave walks rows, not columns — per row a find-first-set on the
 //     32-column direction word gives the run length (<= T_x + T_y/32 serial steps).
-//   * The path is written by all waves with 16-byte stores from the per-row [start,end)
-//     column interval; durations and the frame->token map fall out for free.
+//   * Result: per-row start columns (the path is monotone, so row x owns one column
+//     interval) -> workspace, plus durations and the frame->token map for free.
+//
+// (2) gt_mas_expand_kernel — the whole chip writes the dense 0/1 path from the intervals
+//     with 16-byte stores (a single CU sustains only ~10 B/clk of stores, so leaving this
+//     to the B resident DP workgroups would cost more than the DP itself).
 //
 // Cells outside the reference's band x in [max(0,t_x+y-t_y), min(t_x,y+1)) are computed
 // too (garbage) but never read by in-band cells nor by the backtrack.
@@ -32,19 +43,21 @@
 namespace {
 
 constexpr int   CH       = 32;            // columns per chunk
-constexpr int   TILE_B   = 64 * CH * 4;   // bytes of one wave's logp tile (8 KiB)
+constexpr int   TILE_F   = 64 * CH;       // floats of one wave's logp tile (8 KiB)
 constexpr int   BND_SLOT = 36;            // floats per boundary slot (33 used)
 constexpr int   BND_F    = 2 * BND_SLOT + 104;  // + dummy area for lanes != 63 -> 176 floats
 constexpr float NEG      = -1e9f;         // reference max_neg_val (core.pyx:38)
+constexpr int   MAXD     = 4;             // deepest LDS-DMA ring
 
 struct MasArgs {
   const float* logp; const float* mask;
   const int32_t* t_x; const int32_t* t_y;
-  void* path; int path_dtype;
   float* durations; int32_t* frame2token;
+  int32_t* starts;                         // workspace [B, T_x + 1]
   int T_x, T_y; int64_t stride_b, stride_x;
   int32_t* status;
   int nchp;                                // direction words per row (odd)
+  int depth;                               // ring depth D (2..MAXD)
 };
 
 __host__ __device__ inline int mas_nchp(int T_y) { return ((T_y + CH - 1) / CH) | 1; }
@@ -55,50 +68,110 @@ __device__ __forceinline__ float dpp_wave_shr1(float old, float src) {
                                                     0x138 /*wave_shr:1*/, 0xf, 0xf, false));
 }
 
-// One 32-column chunk of the forward DP for one wave.  DIAG: the chunk may contain the
-// diagonal cell x==y of some lane (only chunks 2w, 2w+1 of wave w).  W0: wave 0 (row 0 has
-// no x-1 neighbour: v_prev = 0 at y==0, else max_neg_val — core.pyx:23-27).
-template <bool DIAG, bool W0>
-__device__ __forceinline__ void mas_chunk(const float* __restrict__ tile, const float* __restrict__ bin,
-                                          float* __restrict__ bout, int lane, int x, int c,
-                                          float& Q, float& carry, unsigned& dir_out)
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)reinterpret_cast<uintptr_t>(p);          // low 32 bits of a shared pointer = LDS byte offset
+}
+
+// ---- steady-state columns, hand-scheduled -------------------------------------------
+// Per column (q = running Q of this lane's row, p = boundary register whose lane 0 holds
+// Q[x-1,y-1] of the row above the wave, v = logp[x,y]):
+//   v_mov_b32_dpp p, q wave_shr:1     p[l] = q[l-1] (lane 0 keeps the boundary)
+//   v_add_f32     ta, q, v            Q[x,y-1]   + v
+//   v_cmp_lt_f32  vcc, q, p           direction bit: Q[x,y-1] < Q[x-1,y-1]   (core.pyx:34)
+//   v_add_f32     tb, p, v            Q[x-1,y-1] + v
+//   v_max_f32     q, ta, tb           == max(.,.) + v   (core.pyx:30)
+//   v_addc_co_u32 d, vcc, d, d, vcc   d = 2*d + bit     (column j ends at bit 31-j)
+//   ds_write_b32  ba, q offset        lane 63 -> boundary slot for wave w+1 (others: dummy)
+// Wait states (gfx950): VALU write -> DPP read of q needs 2 (v_addc + ds_write sit between);
+// VALU write of vcc -> VALU read as carry needs 2 (v_add + v_max sit between).  The leading
+// s_nop 1 covers a compiler-generated VALU write of q directly in front of the statement.
+#ifndef MAS_DPP
+#define MAS_DPP "wave_shr:1"
+#endif
+#ifdef MAS_DIAG_NODSW
+#define MAS_DSW(O) "s_nop 0\n\t"
+#else
+#define MAS_DSW(O) "ds_write_b32 %[ba], %[q] offset:" O "\n\t"
+#endif
+#ifdef MAS_DIAG_NOBIT
+#define MAS_CMP(P) "s_nop 0\n\t"
+#define MAS_ADDC "s_nop 0\n\t"
+#else
+#define MAS_CMP(P) "v_cmp_lt_f32_e32 vcc, %[q], " P "\n\t"
+#define MAS_ADDC "v_addc_co_u32_e32 %[d], vcc, %[d], %[d], vcc\n\t"
+#endif
+#define MAS_COL(P, V, O)                                                        \
+  "v_mov_b32_dpp " P ", %[q] " MAS_DPP " row_mask:0xf bank_mask:0xf\n\t"       \
+  "v_add_f32_e32 %[ta], %[q], " V "\n\t"                                        \
+  MAS_CMP(P)                                                                    \
+  "v_add_f32_e32 %[tb], " P ", " V "\n\t"                                       \
+  "v_max_f32_e32 %[q], %[ta], %[tb]\n\t"                                        \
+  MAS_ADDC                                                                      \
+  MAS_DSW(O)
+
+template <int J0>   // J0 = first column of the group inside the chunk (0,4,...,28)
+__device__ __forceinline__ void mas_cols4(float& Q, unsigned& dir, float4& B, const float4& V, unsigned bout_addr)
+{
+  float ta, tb;
+  asm volatile("s_nop 1\n\t"
+               MAS_COL("%[p0]", "%[v0]", "%[o0]")
+               MAS_COL("%[p1]", "%[v1]", "%[o1]")
+               MAS_COL("%[p2]", "%[v2]", "%[o2]")
+               MAS_COL("%[p3]", "%[v3]", "%[o3]")
+               : [q] "+v"(Q), [d] "+v"(dir), [p0] "+v"(B.x), [p1] "+v"(B.y), [p2] "+v"(B.z), [p3] "+v"(B.w),
+                 [ta] "=&v"(ta), [tb] "=&v"(tb)
+               : [v0] "v"(V.x), [v1] "v"(V.y), [v2] "v"(V.z), [v3] "v"(V.w), [ba] "v"(bout_addr),
+                 [o0] "i"((J0 + 1) * 4), [o1] "i"((J0 + 2) * 4), [o2] "i"((J0 + 3) * 4), [o3] "i"((J0 + 4) * 4)
+               : "vcc", "memory");
+}
+
+// wave 0: the row above does not exist — lane 0 of the single register P stays max_neg_val
+template <int J0>
+__device__ __forceinline__ void mas_cols4_w0(float& Q, unsigned& dir, float& P, const float4& V, unsigned bout_addr)
+{
+  float ta, tb;
+  asm volatile("s_nop 1\n\t"
+               MAS_COL("%[p]", "%[v0]", "%[o0]")
+               MAS_COL("%[p]", "%[v1]", "%[o1]")
+               MAS_COL("%[p]", "%[v2]", "%[o2]")
+               MAS_COL("%[p]", "%[v3]", "%[o3]")
+               : [q] "+v"(Q), [d] "+v"(dir), [p] "+v"(P), [ta] "=&v"(ta), [tb] "=&v"(tb)
+               : [v0] "v"(V.x), [v1] "v"(V.y), [v2] "v"(V.z), [v3] "v"(V.w), [ba] "v"(bout_addr),
+                 [o0] "i"((J0 + 1) * 4), [o1] "i"((J0 + 2) * 4), [o2] "i"((J0 + 3) * 4), [o3] "i"((J0 + 4) * 4)
+               : "vcc", "memory");
+}
+
+// A chunk that may contain the diagonal cell x==y of some lane (only chunks 2w, 2w+1 of wave
+// w): plain HIP, core.pyx:19-20 handled with an explicit select.  V/B already in registers.
+template <bool W0>
+__device__ __forceinline__ void mas_chunk_diag(const float4 (&V)[8], const float4 (&B)[8], float* __restrict__ bout,
+                                               int x, int c, float& Q, unsigned& dir_out)
 {
   unsigned dir = 0;
-  const int sw = (lane >> 1) & 7;
 #pragma unroll
-  for (int q = 0; q < CH / 4; ++q) {
-    const float4 v4 = *reinterpret_cast<const float4*>(tile + lane * CH + ((q ^ sw) << 2));
-    float4 b4;
-    if (W0) {
-      b4 = make_float4(NEG, NEG, NEG, NEG);
-      if (q == 0 && c == 0) b4.x = 0.0f;                       // core.pyx:24-25
-    } else {
-      b4 = *reinterpret_cast<const float4*>(bin + q * 4);      // broadcast read
-      if (q == 0) b4.x = carry;
-    }
-    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+  for (int q = 0; q < 8; ++q) {
+    const float vv[4] = {V[q].x, V[q].y, V[q].z, V[q].w};
+    float bb[4] = {B[q].x, B[q].y, B[q].z, B[q].w};
+    if (W0) { bb[0] = bb[1] = bb[2] = bb[3] = NEG; if (q == 0 && c == 0) bb[0] = 0.0f; }   // core.pyx:23-27
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = q * 4 + i;
       const float P = dpp_wave_shr1(bb[i], Q);                 // Q[x-1, y-1]
-      float A = Q;                                             // Q[x,   y-1]
-      bool d = false;
-      if (DIAG) { d = (x == c * CH + j); A = d ? NEG : A; }    // core.pyx:19-20
-      const bool lt = (A < P);                                 // core.pyx:34 predicate / :30 select
+      const bool d = (x == c * CH + j);
+      const float A = d ? NEG : Q;                             // core.pyx:19-20
+      const bool lt = (A < P);                                 // core.pyx:34 predicate
       const float qa = A + vv[i];
       const float qp = P + vv[i];
       Q = (qp > qa) ? qp : qa;                                 // == max(A,P)+v bit-exactly
-      dir |= ((lt || d) ? 1u : 0u) << j;
-      bout[j + 1] = Q;                                         // lane 63: boundary row; others: dummy
+      dir = (dir << 1) | ((lt || d) ? 1u : 0u);
+      bout[j + 1] = Q;
     }
   }
-  if (!W0) carry = bin[CH];                                    // Q[64w-1, last column of chunk]
   dir_out = dir;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
+template <bool DMA, bool MASK>
+__global__ __launch_bounds__(512) void gt_mas_dp_kernel(MasArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b    = blockIdx.x;
@@ -108,6 +181,7 @@ __global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
   const int W    = blockDim.x >> 6;
   const int NT   = blockDim.x;
   const int T_x = a.T_x, T_y = a.T_y, NCHP = a.nchp;
+  const int D   = DMA ? a.depth : 1;
 
   int t_x = a.t_x[b], t_y = a.t_y[b];
   {
@@ -118,8 +192,9 @@ __global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
     if (t_x == 0 || t_y == 0) { t_x = 0; t_y = 0; }            // empty utterance -> all-zero path
   }
 
-  float*    tile   = reinterpret_cast<float*>(smem) + w * (64 * CH);
-  float*    bndall = reinterpret_cast<float*>(smem + (size_t)W * TILE_B);
+  // LDS carve: [W][D] tiles | [W] boundary rings | direction words | starts
+  float*    ring   = reinterpret_cast<float*>(smem) + (size_t)w * D * TILE_F;
+  float*    bndall = reinterpret_cast<float*>(smem) + (size_t)W * D * TILE_F;
   unsigned* dirs   = reinterpret_cast<unsigned*>(bndall + W * BND_F);
   int*      starts = reinterpret_cast<int*>(dirs + (size_t)W * 64 * NCHP);   // [W*64 + 1]
 
@@ -129,79 +204,158 @@ __global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
   const int x = w * 64 + lane;
 
   const float* lp = a.logp + (int64_t)b * a.stride_b;
-  const float* mp = a.mask ? a.mask + (int64_t)b * a.stride_b : nullptr;
+  const float* mp = MASK ? a.mask + (int64_t)b * a.stride_b : nullptr;
 
-  float4 r[8];
-  auto load_chunk = [&](int c) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = w * 64 + i * 8 + (lane >> 3);
-      const int col = c * CH + (lane & 7) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < T_x) {
-        const float* p = lp + (int64_t)row * a.stride_x + col;
-        if (VEC) {
-          if (col < T_y) {                                     // T_y % 4 == 0 in VEC mode
-            v = *reinterpret_cast<const float4*>(p);
-            if (mp) {
-              const float4 m = *reinterpret_cast<const float4*>(mp + (int64_t)row * a.stride_x + col);
-              v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;   // __init__.py:11
-            }
-          }
-        } else {
-          const float* pm = mp ? mp + (int64_t)row * a.stride_x + col : nullptr;
-          if (col + 0 < T_y) { v.x = p[0]; if (pm) v.x *= pm[0]; }
-          if (col + 1 < T_y) { v.y = p[1]; if (pm) v.y *= pm[1]; }
-          if (col + 2 < T_y) { v.z = p[2]; if (pm) v.z *= pm[2]; }
-          if (col + 3 < T_y) { v.w = p[3]; if (pm) v.w *= pm[3]; }
-        }
-      }
-      r[i] = v;
-    }
-  };
-  auto store_tile = [&]() {
+  // ---- tile fill: chunk c -> ring slot c % D.  Always-in-bounds addresses: rows >= T_x and
+  // columns >= T_y are clamped onto valid cells; what they return is never used by a valid cell
+  // (t_x <= T_x, t_y <= T_y) and a guarded load would serialise the stream.
+  auto fill_dma = [&](int c) {                                  // 8 x global_load_lds_dwordx4
+    float* slot = ring + (c % D) * TILE_F;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rr = i * 8 + (lane >> 3);
-      const int q  = lane & 7;
-      *reinterpret_cast<float4*>(tile + rr * CH + ((q ^ ((rr >> 1) & 7)) << 2)) = r[i];
+      const int q  = (lane & 7) ^ ((rr >> 1) & 7);              // swizzle on the SOURCE side
+      int row = w * 64 + rr;  row = row < T_x ? row : T_x - 1;
+      int col = c * CH + q * 4; col = col < T_y ? col : T_y - 4;
+      const float* g = lp + (int64_t)row * a.stride_x + col;
+      // LDS-DMA in inline asm: with the builtin hipcc drains vmcnt(0) in front of every
+      // ds_read of the ring (it cannot tell the slots apart), which kills the prefetch.
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_off(slot + i * 256));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+    }
+  };
+  auto fill_regs = [&](int c) {                                 // generic: any alignment, optional mask
+    float* slot = ring + (c % D) * TILE_F;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = i * 8 + (lane >> 3);
+      int row = w * 64 + rr;  row = row < T_x ? row : T_x - 1;
+      const int col = c * CH + (lane & 7) * 4;
+      const int c0 = col     < T_y ? col     : T_y - 1;
+      const int c1 = col + 1 < T_y ? col + 1 : T_y - 1;
+      const int c2 = col + 2 < T_y ? col + 2 : T_y - 1;
+      const int c3 = col + 3 < T_y ? col + 3 : T_y - 1;
+      const float* p = lp + (int64_t)row * a.stride_x;
+      float4 v = make_float4(p[c0], p[c1], p[c2], p[c3]);
+      if (MASK) {                                               // value*mask, __init__.py:11
+        const float* pm = mp + (int64_t)row * a.stride_x;
+        v.x *= pm[c0]; v.y *= pm[c1]; v.z *= pm[c2]; v.w *= pm[c3];
+      }
+      *reinterpret_cast<float4*>(slot + rr * CH + (((lane & 7) ^ ((rr >> 1) & 7)) << 2)) = v;
     }
   };
 
-  // ---------------- forward DP: direction bits into LDS ----------------
-  if (wave_active && 2 * w < nch) { load_chunk(2 * w); store_tile(); }
-  __syncthreads();
+  int issued = 2 * w;                                           // next chunk this wave fetches
+  auto issue_upto = [&](int target) {
+    if (DMA) { while (issued <= target && issued < nch) { fill_dma(issued); ++issued; } }
+  };
+  // wait until at most `n` DMA groups (8 loads each) are still in flight
+  auto wait_groups = [&](int n) {
+    if (!DMA) return;
+    if      (n >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(8)"  ::: "memory");
+    else             asm volatile("s_waitcnt vmcnt(0)"  ::: "memory");
+  };
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // asm ds_writes are invisible to hipcc
+    __builtin_amdgcn_s_barrier();
+  };
 
-  float Q = 0.0f, carry = NEG;
+#ifdef MAS_STAMPS
+  unsigned long long st0 = __builtin_readcyclecounter();
+#endif
+  // ---------------- forward DP: direction bits into LDS ----------------
+  if (wave_active) {
+    if (DMA) { issue_upto(2 * w + D - 2); wait_groups(issued - (2 * w + 1)); }
+    else if (2 * w < nch) fill_regs(2 * w);
+  }
+  step_barrier();
+
+  float Q = 0.0f, carry = NEG, Pneg = NEG;
   const float* bin_base  = bndall + (w > 0 ? (w - 1) : 0) * BND_F;       // producer = wave w-1
   float*       bout_base = bndall + w * BND_F;
   const int nsteps = (nch > 0) ? nch + Wact - 1 : 0;
+#ifdef MAS_STAMPS
+  unsigned long long acc_issue = 0, acc_lds = 0, acc_comp = 0, acc_wait = 0, acc_bar = 0;
+#endif
   for (int s = 0; s < nsteps; ++s) {
     const int c = s - w;
+#ifdef MAS_STAMPS
+    bool inb = false;
+#endif
     if (wave_active && c >= 2 * w && c < nch) {
-      if (c + 1 < nch) load_chunk(c + 1);
-      const float* bin = bin_base + (c & 1) * BND_SLOT;
-      float* bout = (lane == 63) ? (bout_base + (c & 1) * BND_SLOT)
-                                 : (bout_base + 2 * BND_SLOT + lane);
-      unsigned dir;
-      const bool diag = (c >> 1) == w;
-      if (w == 0) {
-        if (diag) mas_chunk<true,  true >(tile, bin, bout, lane, x, c, Q, carry, dir);
-        else      mas_chunk<false, true >(tile, bin, bout, lane, x, c, Q, carry, dir);
-      } else {
-        if (diag) mas_chunk<true,  false>(tile, bin, bout, lane, x, c, Q, carry, dir);
-        else      mas_chunk<false, false>(tile, bin, bout, lane, x, c, Q, carry, dir);
+#ifdef MAS_STAMPS
+      const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+      issue_upto(c + D - 1);
+#ifdef MAS_STAMPS
+      const unsigned long long ts1 = __builtin_readcyclecounter(); acc_issue += ts1 - ts0;
+#endif
+      const float* slot = ring + (c % D) * TILE_F;
+      const float* bin  = bin_base + (c & 1) * BND_SLOT;
+      float* bout = (lane == 63) ? (bout_base + (c & 1) * BND_SLOT) : (bout_base + 2 * BND_SLOT + lane);
+      const int sw = (lane >> 1) & 7;
+      float4 V[8], B[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) V[q] = *reinterpret_cast<const float4*>(slot + lane * CH + ((q ^ sw) << 2));
+      if (w > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) B[q] = *reinterpret_cast<const float4*>(bin + q * 4);   // broadcast reads
+        B[0].x = carry;
+        carry = bin[CH];                                        // Q[64w-1, last column of this chunk]
       }
+      unsigned dir = 0;
+#ifdef MAS_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" :: "v"(V[0].x), "v"(V[7].w) : "memory"); const unsigned long long ts2 = __builtin_readcyclecounter(); acc_lds += ts2 - ts1;
+#endif
+      if ((c >> 1) == w) {                                      // chunk holds x == y cells
+        if (w == 0) mas_chunk_diag<true >(V, B, bout, x, c, Q, dir);
+        else        mas_chunk_diag<false>(V, B, bout, x, c, Q, dir);
+      } else {
+        const unsigned ba = lds_off(bout);
+        if (w == 0) {
+          mas_cols4_w0< 0>(Q, dir, Pneg, V[0], ba); mas_cols4_w0< 4>(Q, dir, Pneg, V[1], ba);
+          mas_cols4_w0< 8>(Q, dir, Pneg, V[2], ba); mas_cols4_w0<12>(Q, dir, Pneg, V[3], ba);
+          mas_cols4_w0<16>(Q, dir, Pneg, V[4], ba); mas_cols4_w0<20>(Q, dir, Pneg, V[5], ba);
+          mas_cols4_w0<24>(Q, dir, Pneg, V[6], ba); mas_cols4_w0<28>(Q, dir, Pneg, V[7], ba);
+        } else {
+          mas_cols4< 0>(Q, dir, B[0], V[0], ba); mas_cols4< 4>(Q, dir, B[1], V[1], ba);
+          mas_cols4< 8>(Q, dir, B[2], V[2], ba); mas_cols4<12>(Q, dir, B[3], V[3], ba);
+          mas_cols4<16>(Q, dir, B[4], V[4], ba); mas_cols4<20>(Q, dir, B[5], V[5], ba);
+          mas_cols4<24>(Q, dir, B[6], V[6], ba); mas_cols4<28>(Q, dir, B[7], V[7], ba);
+        }
+      }
+#ifdef MAS_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long ts3 = __builtin_readcyclecounter(); acc_comp += ts3 - ts2;
+#endif
       dirs[(size_t)x * NCHP + c] = dir;
-      if (c + 1 < nch) store_tile();
+      if (DMA) wait_groups(issued - (c + 2));                   // chunk c+1 has landed
+      else if (c + 1 < nch) fill_regs(c + 1);                   // D == 1: refill the only slot
+#ifdef MAS_STAMPS
+      { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t4 = __builtin_readcyclecounter(); acc_wait += t4 - ts3; inb = true; }
+#endif
     } else if (wave_active && w > 0 && c == 2 * w - 1) {
       // the chunk before this wave's first: pick up Q[64w-1, 64w-1] as carry-in
       carry = bin_base[(c & 1) * BND_SLOT + CH];
     }
-    __syncthreads();
+#ifdef MAS_STAMPS
+    const unsigned long long tsb = __builtin_readcyclecounter();
+#endif
+    step_barrier();
+#ifdef MAS_STAMPS
+    if (inb) { acc_bar += __builtin_readcyclecounter() - tsb; }
+#endif
   }
 
+#ifdef MAS_STAMPS
+  unsigned long long st1 = __builtin_readcyclecounter();
+#endif
   // ---------------- backtrack (wave 0): rows, not columns ----------------
+  // direction word of (row, chunk): column 32c+j at bit 31-j
   if (w == 0) {
     int idx = t_x - 1;
     int y   = t_y - 1;
@@ -211,25 +365,30 @@ __global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
       const unsigned wv = (r >= 0) ? dirs[(size_t)r * NCHP + c] : 0u;
       const int base = idx;
       const int ylo  = c << 5;
-      while (true) {
-        const unsigned word = __builtin_amdgcn_readlane(wv, base - idx);
-        const unsigned m = word << (31 - (y & 31));   // bit of column y -> bit 31
+      do {
+        const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)wv, base - idx);
+        const unsigned m = word >> (31 - (y & 31));   // column y at bit 0, y-1 at bit 1, ...
         if (m == 0u) { y = ylo - 1; break; }          // stays on this row down to the chunk start
-        const int yp = y - __builtin_clz(m);          // first column (going down) with a diagonal move
-        if (lane == 0) starts[idx] = yp;              // row idx occupies columns [yp, ...]
+        const int yp = y - __builtin_ctz(m);          // first column (going down) with a diagonal move
+        starts[idx] = yp;                             // row idx occupies columns [yp, ...); uniform store
         idx -= 1;
         y = yp - 1;
-        if (idx == 0 || y < ylo) break;
-      }
+      } while (idx > 0 && y >= ylo);
     }
-    if (lane == 0) { if (t_x > 0) starts[0] = 0; starts[t_x] = t_y; }
+    if (t_x > 0) starts[0] = 0;
   }
   __syncthreads();
+  for (int xx = t_x + tid; xx <= W * 64; xx += NT) starts[xx] = t_y;   // rows >= t_x: empty interval
+  __syncthreads();
 
-  // ---------------- outputs ----------------
+#ifdef MAS_STAMPS
+  unsigned long long st2 = __builtin_readcyclecounter();
+#endif
+  // ---------------- outputs: intervals, durations, frame -> token ----------------
+  for (int xx = tid; xx <= T_x; xx += NT) a.starts[(int64_t)b * (T_x + 1) + xx] = starts[xx];
   if (a.durations) {
     for (int xx = tid; xx < T_x; xx += NT)
-      a.durations[(int64_t)b * T_x + xx] = (xx < t_x) ? (float)(starts[xx + 1] - starts[xx]) : 0.0f;
+      a.durations[(int64_t)b * T_x + xx] = (float)(starts[xx + 1] - starts[xx]);
   }
   if (a.frame2token) {
     for (int yy = tid; yy < T_y; yy += NT) {
@@ -242,51 +401,58 @@ __global__ __launch_bounds__(1024) void gt_mas_kernel(MasArgs a)
       a.frame2token[(int64_t)b * T_y + yy] = tok;
     }
   }
+#ifdef MAS_STAMPS
+  if (b == 0 && tid == 0 && a.status) {
+    unsigned long long st3 = __builtin_readcyclecounter();
+    a.status[1] = (int)(st1 - st0); a.status[2] = (int)(st2 - st1); a.status[3] = (int)(st3 - st2);
+    a.status[4] = (int)acc_issue; a.status[5] = (int)acc_lds; a.status[6] = (int)acc_comp; a.status[7] = (int)acc_wait; a.status[8] = (int)acc_bar;
+  }
+#endif
+}
 
-  const int64_t obase = (int64_t)b * T_x * T_y;
-  const int dt = a.path_dtype;
+// Dense path from the per-row column intervals: grid (ceil(T_y/4/256), T_x, B).
+template <bool VEC>
+__global__ __launch_bounds__(256) void gt_mas_expand_kernel(const int32_t* __restrict__ starts, void* __restrict__ path,
+                                                            int dt, int T_x, int T_y)
+{
+  const int row = blockIdx.y, b = blockIdx.z;
+  const int s0 = starts[(int64_t)b * (T_x + 1) + row];
+  const int e0 = starts[(int64_t)b * (T_x + 1) + row + 1];
+  const int64_t obase = ((int64_t)b * T_x + row) * T_y;
   if (VEC) {
-    const int T4 = T_y >> 2;
-    for (int row = w; row < T_x; row += W) {
-      int s0 = 0, e0 = 0;
-      if (row < t_x) { s0 = starts[row]; e0 = starts[row + 1]; }
-      for (int q = lane; q < T4; q += 64) {
-        const int y0 = q << 2;
-        const unsigned b0 = (y0     >= s0 && y0     < e0);
-        const unsigned b1 = (y0 + 1 >= s0 && y0 + 1 < e0);
-        const unsigned b2 = (y0 + 2 >= s0 && y0 + 2 < e0);
-        const unsigned b3 = (y0 + 3 >= s0 && y0 + 3 < e0);
-        const int64_t o = obase + (int64_t)row * T_y + y0;
-        if (dt == GT_DT_F32) {
-          *reinterpret_cast<float4*>(static_cast<float*>(a.path) + o) =
-              make_float4((float)b0, (float)b1, (float)b2, (float)b3);
-        } else if (dt == GT_DT_I32) {
-          *reinterpret_cast<int4*>(static_cast<int32_t*>(a.path) + o) = make_int4(b0, b1, b2, b3);
-        } else if (dt == GT_DT_F16) {                 // 1.0h = 0x3C00
-          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(a.path) + o) =
-              make_uint2((b0 * 0x3C00u) | ((b1 * 0x3C00u) << 16), (b2 * 0x3C00u) | ((b3 * 0x3C00u) << 16));
-        } else if (dt == GT_DT_BF16) {                // 1.0bf16 = 0x3F80
-          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(a.path) + o) =
-              make_uint2((b0 * 0x3F80u) | ((b1 * 0x3F80u) << 16), (b2 * 0x3F80u) | ((b3 * 0x3F80u) << 16));
-        } else {                                      // GT_DT_U8
-          *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a.path) + o) =
-              b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        }
-      }
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int y0 = q << 2;
+    if (y0 >= T_y) return;
+    const unsigned b0 = (y0     >= s0 && y0     < e0);
+    const unsigned b1 = (y0 + 1 >= s0 && y0 + 1 < e0);
+    const unsigned b2 = (y0 + 2 >= s0 && y0 + 2 < e0);
+    const unsigned b3 = (y0 + 3 >= s0 && y0 + 3 < e0);
+    const int64_t o = obase + y0;
+    if (dt == GT_DT_F32) {
+      *reinterpret_cast<float4*>(static_cast<float*>(path) + o) = make_float4((float)b0, (float)b1, (float)b2, (float)b3);
+    } else if (dt == GT_DT_I32) {
+      *reinterpret_cast<int4*>(static_cast<int32_t*>(path) + o) = make_int4(b0, b1, b2, b3);
+    } else if (dt == GT_DT_F16) {                 // 1.0h = 0x3C00
+      *reinterpret_cast<uint2*>(static_cast<uint16_t*>(path) + o) =
+          make_uint2((b0 * 0x3C00u) | ((b1 * 0x3C00u) << 16), (b2 * 0x3C00u) | ((b3 * 0x3C00u) << 16));
+    } else if (dt == GT_DT_BF16) {                // 1.0bf16 = 0x3F80
+      *reinterpret_cast<uint2*>(static_cast<uint16_t*>(path) + o) =
+          make_uint2((b0 * 0x3F80u) | ((b1 * 0x3F80u) << 16), (b2 * 0x3F80u) | ((b3 * 0x3F80u) << 16));
+    } else {                                      // GT_DT_U8
+      *reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(path) + o) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
   } else {
-    for (int row = w; row < T_x; row += W) {
-      int s0 = 0, e0 = 0;
-      if (row < t_x) { s0 = starts[row]; e0 = starts[row + 1]; }
-      for (int yy = lane; yy < T_y; yy += 64) {
-        const unsigned bit = (yy >= s0 && yy < e0);
-        const int64_t o = obase + (int64_t)row * T_y + yy;
-        if      (dt == GT_DT_F32)  static_cast<float*>(a.path)[o]    = (float)bit;
-        else if (dt == GT_DT_I32)  static_cast<int32_t*>(a.path)[o]  = (int32_t)bit;
-        else if (dt == GT_DT_F16)  static_cast<uint16_t*>(a.path)[o] = (uint16_t)(bit * 0x3C00u);
-        else if (dt == GT_DT_BF16) static_cast<uint16_t*>(a.path)[o] = (uint16_t)(bit * 0x3F80u);
-        else                       static_cast<uint8_t*>(a.path)[o]  = (uint8_t)bit;
-      }
+    const int y0 = (blockIdx.x * 256 + threadIdx.x) << 2;
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + k;
+      if (yy >= T_y) return;
+      const unsigned bit = (yy >= s0 && yy < e0);
+      const int64_t o = obase + yy;
+      if      (dt == GT_DT_F32)  static_cast<float*>(path)[o]    = (float)bit;
+      else if (dt == GT_DT_I32)  static_cast<int32_t*>(path)[o]  = (int32_t)bit;
+      else if (dt == GT_DT_F16)  static_cast<uint16_t*>(path)[o] = (uint16_t)(bit * 0x3C00u);
+      else if (dt == GT_DT_BF16) static_cast<uint16_t*>(path)[o] = (uint16_t)(bit * 0x3F80u);
+      else                       static_cast<uint8_t*>(path)[o]  = (uint8_t)bit;
     }
   }
 }
@@ -310,13 +476,26 @@ __global__ void gt_mas_lengths_kernel(const float* mask, int32_t* t_x, int32_t* 
   }
 }
 
+size_t mas_lds_fixed(int T_x, int T_y) {        // everything but the tile ring
+  const size_t W = (size_t)(T_x + 63) / 64;
+  return W * BND_F * 4 + W * 64 * (size_t)mas_nchp(T_y) * 4 + (W * 64 + 1) * 4 + 12;
+}
+constexpr size_t LDS_CAP = 160 * 1024;
+
 }  // namespace
 
 extern "C" size_t gt_mas_lds_bytes(int T_x, int T_y)
 {
   if (T_x <= 0 || T_y <= 0) return 0;
   const size_t W = (size_t)(T_x + 63) / 64;
-  return W * TILE_B + W * BND_F * 4 + W * 64 * (size_t)mas_nchp(T_y) * 4 + (W * 64 + 1) * 4 + 12;
+  return mas_lds_fixed(T_x, T_y) + W * 2 * TILE_F * 4;         // minimum: ring depth 2
+}
+
+extern "C" size_t gt_mas_workspace_bytes(int B, int T_x, int T_y)
+{
+  (void)T_y;
+  if (B <= 0 || T_x <= 0) return 0;
+  return ((size_t)B * (size_t)(T_x + 1) * 4 + 255) & ~(size_t)255;
 }
 
 extern "C" int gt_mas_f32(const float* logp, const float* mask,
@@ -324,40 +503,60 @@ extern "C" int gt_mas_f32(const float* logp, const float* mask,
                           void* path, int path_dtype,
                           float* durations, int32_t* frame2token,
                           int B, int T_x, int T_y, int64_t stride_b, int64_t stride_x,
+                          void* workspace, size_t workspace_bytes,
                           int32_t* status, void* stream)
 {
   if (B < 0 || T_x < 0 || T_y < 0) return GT_E_INVAL;
   if (B == 0 || T_x == 0 || T_y == 0) return GT_OK;            // nothing to write
-  if (!logp || !t_x || !t_y || !path) return GT_E_INVAL;
-  if (path_dtype < GT_DT_F32 || path_dtype > GT_DT_U8) return GT_E_INVAL;
+  if (!logp || !t_x || !t_y) return GT_E_INVAL;
+  if (path && (path_dtype < GT_DT_F32 || path_dtype > GT_DT_U8)) return GT_E_INVAL;
   if (stride_x < T_y || stride_b < (int64_t)T_x * stride_x) return GT_E_INVAL;
-  if (T_x > 1024) return GT_E_UNSUPPORTED;
-  const size_t lds = gt_mas_lds_bytes(T_x, T_y);
-  if (lds > 160 * 1024) return GT_E_UNSUPPORTED;
-
-  MasArgs a;
-  a.logp = logp; a.mask = mask; a.t_x = t_x; a.t_y = t_y; a.path = path; a.path_dtype = path_dtype;
-  a.durations = durations; a.frame2token = frame2token; a.T_x = T_x; a.T_y = T_y;
-  a.stride_b = stride_b; a.stride_x = stride_x; a.status = status; a.nchp = mas_nchp(T_y);
+  if (!workspace || workspace_bytes < gt_mas_workspace_bytes(B, T_x, T_y)) return GT_E_INVAL;
+  if ((uintptr_t)workspace % 4) return GT_E_ALIGN;
+  if (T_x > 512) return GT_E_UNSUPPORTED;                      // 8 waves x 64 rows
+  if (gt_mas_lds_bytes(T_x, T_y) > LDS_CAP) return GT_E_UNSUPPORTED;
 
   const int W = (T_x + 63) / 64;
-  const bool vec = (T_y % 4 == 0) && (stride_x % 4 == 0) && (stride_b % 4 == 0) &&
-                   ((uintptr_t)logp % 16 == 0) && (!mask || (uintptr_t)mask % 16 == 0) &&
-                   ((uintptr_t)path % 16 == 0);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e;
-  if (vec) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_mas_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return GT_E_LAUNCH;
-    hipLaunchKernelGGL(gt_mas_kernel<true>, dim3(B), dim3(W * 64), lds, st, a);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_mas_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return GT_E_LAUNCH;
-    hipLaunchKernelGGL(gt_mas_kernel<false>, dim3(B), dim3(W * 64), lds, st, a);
+  const bool dma = !mask && T_y >= 4 && (T_y % 4 == 0) && (stride_x % 4 == 0) && (stride_b % 4 == 0) &&
+                   ((uintptr_t)logp % 16 == 0);
+  // deepest ring that fits next to the direction words
+  int depth = 1;
+  if (dma) {
+    const size_t room = LDS_CAP - mas_lds_fixed(T_x, T_y);
+    depth = (int)(room / ((size_t)W * TILE_F * 4));
+    if (depth > MAXD) depth = MAXD;
   }
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  const size_t lds = mas_lds_fixed(T_x, T_y) + (size_t)W * depth * TILE_F * 4;
+
+  MasArgs a;
+  a.logp = logp; a.mask = mask; a.t_x = t_x; a.t_y = t_y;
+  a.durations = durations; a.frame2token = frame2token; a.starts = static_cast<int32_t*>(workspace);
+  a.T_x = T_x; a.T_y = T_y; a.stride_b = stride_b; a.stride_x = stride_x; a.status = status;
+  a.nchp = mas_nchp(T_y); a.depth = depth;
+
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  using KernT = void (*)(MasArgs);
+  static const KernT kerns[3] = {gt_mas_dp_kernel<true, false>, gt_mas_dp_kernel<false, false>,
+                                 gt_mas_dp_kernel<false, true>};
+  static bool attr_set[3] = {false, false, false};             // benign one-time cache
+  const int k = dma ? 0 : (mask ? 2 : 1);
+  if (!attr_set[k]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[k]),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP) != hipSuccess)
+      return GT_E_LAUNCH;
+    attr_set[k] = true;
+  }
+  hipLaunchKernelGGL(kerns[k], dim3(B), dim3(W * 64), lds, st, a);
+  if (hipGetLastError() != hipSuccess) return GT_E_LAUNCH;
+
+  if (path) {
+    const bool vec = (T_y % 4 == 0) && ((uintptr_t)path % 16 == 0);
+    const dim3 grid((unsigned)(((T_y + 3) / 4 + 255) / 256), (unsigned)T_x, (unsigned)B);
+    if (vec) hipLaunchKernelGGL(gt_mas_expand_kernel<true>,  grid, dim3(256), 0, st, a.starts, path, path_dtype, T_x, T_y);
+    else     hipLaunchKernelGGL(gt_mas_expand_kernel<false>, grid, dim3(256), 0, st, a.starts, path, path_dtype, T_x, T_y);
+    if (hipGetLastError() != hipSuccess) return GT_E_LAUNCH;
+  }
+  return GT_OK;
 }
 
 extern "C" int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,

@@ -57,12 +57,15 @@ def maximum_path_lengths(value, t_x, t_y, mask=None, out_dtype=None, want_durati
     f2t = torch.empty((B, T_y), dtype=torch.int32, device=v.device) if want_frame2token else None
     status = torch.zeros((1,), dtype=torch.int32, device=v.device) if validate else None
     if B and T_x and T_y:
+        ws_bytes = L.gt_mas_workspace_bytes(B, T_x, T_y)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=v.device)
         rc = L.gt_mas_f32(_lib.ptr(v), _lib.ptr(m), _lib.ptr(t_x), _lib.ptr(t_y), _lib.ptr(path),
                           _DT[out_dtype], _lib.ptr(dur), _lib.ptr(f2t), B, T_x, T_y,
-                          v.stride(0), v.stride(1), _lib.ptr(status), _lib.current_stream(v.device))
+                          v.stride(0), v.stride(1), _lib.ptr(ws), ws_bytes, _lib.ptr(status),
+                          _lib.current_stream(v.device))
         if rc == -2:
             raise RuntimeError(f"gt_mas_f32: lattice [{T_x},{T_y}] exceeds the kernel's limits "
-                               f"(T_x<=1024, LDS {L.gt_mas_lds_bytes(T_x, T_y)} B > 160 KiB)")
+                               f"(T_x<=512, LDS {L.gt_mas_lds_bytes(T_x, T_y)} B > 160 KiB)")
         _lib.check(rc, "gt_mas_f32")
     if validate:
         st = int(status.item())

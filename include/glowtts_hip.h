@@ -54,16 +54,20 @@ const char* gt_version(void);
  *   mask        optional (may be NULL) fp32 tensor with the same strides; when given the
  *               kernel uses logp*mask exactly like __init__.py:11.
  *   t_x, t_y    [B] int32 valid lengths per utterance (__init__.py:18-19).
- *   path        [B, T_x, T_y] contiguous output of element type path_dtype (GT_DT_*):
- *               1 on the alignment path, 0 elsewhere — every element is written.
+ *   path        optional (may be NULL) [B, T_x, T_y] contiguous output of element type
+ *               path_dtype (GT_DT_*): 1 on the alignment path, 0 elsewhere — every element
+ *               is written (by a second, chip-wide kernel on the same stream).
  *   durations   optional [B, T_x] fp32: row sums of path (models.py:1085 `w`).
  *   frame2token optional [B, T_y] int32: for each frame y < t_y the row x with
  *               path[b,x,y]==1, else -1 (lets the prior expansion models.py:1118-1119
  *               be a gather instead of a matmul with a one-hot matrix).
+ *   workspace   device scratch of at least gt_mas_workspace_bytes(B,T_x,T_y) bytes, 4-byte
+ *               aligned; after the call it holds int32 [B, T_x+1] row start columns (row x of
+ *               utterance b is aligned to frames [ws[b][x], ws[b][x+1]) ).
  *   status      optional device int32, OR-ed with GT_MAS_ST_* bits.  Utterances with
  *               invalid lengths get an all-zero path.
  *
- * Limits: T_x <= 1024, and gt_mas_lds_bytes(T_x,T_y) <= 160 KiB, else GT_E_UNSUPPORTED.
+ * Limits: T_x <= 512, and gt_mas_lds_bytes(T_x,T_y) <= 160 KiB, else GT_E_UNSUPPORTED.
  * Bit-exact with the reference for every t_x <= t_y (IEEE fp32, same tie-breaks).
  */
 int gt_mas_f32(const float* logp, const float* mask,
@@ -71,7 +75,11 @@ int gt_mas_f32(const float* logp, const float* mask,
                void* path, int path_dtype,
                float* durations, int32_t* frame2token,
                int B, int T_x, int T_y, int64_t stride_b, int64_t stride_x,
+               void* workspace, size_t workspace_bytes,
                int32_t* status, void* stream);
+
+/* Scratch bytes gt_mas_f32 needs for a batch (host helper). */
+size_t gt_mas_workspace_bytes(int B, int T_x, int T_y);
 
 /* LDS bytes one workgroup of gt_mas_f32 needs for a [T_x, T_y] lattice (host helper). */
 size_t gt_mas_lds_bytes(int T_x, int T_y);

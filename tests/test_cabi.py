@@ -45,10 +45,11 @@ def test_host_helpers_no_gpu(built):
     assert L.gt_mas_lds_bytes(150, 800) < 160 * 1024
     assert L.gt_mas_lds_bytes(375, 870) < 160 * 1024
     assert L.gt_mas_lds_bytes(0, 10) == 0
+    assert L.gt_mas_workspace_bytes(32, 150, 800) >= 32 * 151 * 4
     # argument validation happens before any launch
-    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, 2, 8, 8, 64, 8, None, None) == -1
-    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, 0, 8, 8, 64, 8, None, None) == 0
-    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, -1, 8, 8, 64, 8, None, None) == -1
+    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, 2, 8, 8, 64, 8, None, 0, None, None) == -1
+    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, 0, 8, 8, 64, 8, None, 0, None, None) == 0
+    assert L.gt_mas_f32(None, None, None, None, None, 0, None, None, -1, 8, 8, 64, 8, None, 0, None, None) == -1
 
 
 def test_ops_fail_loudly_without_gpu(built):
