@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
 
-c_void_p, c_int, c_i64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
-                                             ctypes.c_size_t, ctypes.c_float)
+c_void_p, c_int, c_i64, c_size_t, c_float, c_u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                    ctypes.c_size_t, ctypes.c_float, ctypes.c_uint32)
 
 # name -> (restype, argtypes); mirrors include/glowtts_hip.h one to one
 PROTOTYPES = {
@@ -21,6 +21,12 @@ PROTOTYPES = {
     "gt_mas_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gt_mas_lengths_from_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_i64, c_i64, c_void_p]),
+    "gt_conv_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 GT_DT_F32, GT_DT_I32, GT_DT_F16, GT_DT_BF16, GT_DT_U8 = 0, 1, 2, 3, 4

@@ -1,0 +1,34 @@
+// Shared device helpers for the gfx950 kernels (bf16 storage, MFMA fragment types, RNG).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef uint16_t bf16_t;   // raw bf16 bits in memory
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {       // round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {      // 1 - 2/(e^{2x}+1): exact limits at +-inf
+  return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+}
+
+// Counter-based RNG for dropout: one 32-bit hash per element index, replayable in backward.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
+  // keep with probability 1-p, thresh = p * 2^32
+  return hash_u32(seed ^ hash_u32(row * 0x9E3779B1U + col)) >= thresh;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

@@ -1,0 +1,295 @@
+// Implicit-GEMM 1-D convolution on bf16 MFMA (v_mfma_f32_32x32x16_bf16) for gfx950.
+//
+// Replaces the ATen/cuDNN conv1d calls of the reference hot path:
+//   modules.py:152 (WN in_layer k=5), :165 (res/skip 1x1), attentions.py:144,172 (start / end 1x1),
+//   attentions.py:232-238 (q/k/v/o 1x1), :365-371 (FFN k=3), modules.py:97 (prenet k=5),
+//   models.py:710 (proj_m), and — with transposed/flipped packed weights — their data gradients.
+//
+// Data layout ("rows"): activations are [R, C] channels-last, R = B * Tp rows where every
+// utterance owns Tp = T + 2*HALO consecutive rows and its first/last HALO rows (and every row
+// past its length) are zero.  A k-tap convolution is then k shifted row-block GEMMs with no
+// boundary logic:  Y[m, n] = sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci].
+//
+// Mapping: MFMA A = weight tile (rows = output channels n), MFMA B = activation tile
+// (columns = rows m), so a lane's 16 accumulators are 4 groups of 4 CONSECUTIVE channels of ONE
+// row m -> 8/16-byte channels-last stores, per-channel bias as float4, and the WaveNet gate
+// tanh(.)*sigmoid(.) (commons.py:61-68) pairs two accumulator blocks of the same lane when the
+// packed weight rows are interleaved [32 tanh | 32 sigmoid] (see gt_pack_conv_weights).
+//
+// Tile: 128 rows x {128|64} channels per 256-thread workgroup, K slice 64, LDS pitch 144 B
+// (conflict-free ds_read_b128 for 16 distinct rows), weights and activations double-buffered
+// in LDS with register prefetch (global loads of step i+1 fly under the MFMAs of step i), one
+// barrier per (K-slice, tap) step, 2 workgroups per CU.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LDP = 72;                       // halfs per LDS row (64 + 8 pad)
+constexpr int MAXTAPS = 5;
+constexpr int XROWS = BM + MAXTAPS - 1;
+
+struct ConvArgs {
+  const bf16_t* X; int ldx;                   // [R, >=Cin]
+  const bf16_t* W;                            // packed [taps][Np][Kp]
+  const float* bias;                          // [N] (gate: [2*half]) or null
+  const float* cond; int ldc;                 // [B, ldc] or null
+  const float* rowmask;                       // [R] or null
+  void* Y; int ldy;
+  const void* addend; int ldadd;              // same dtype as Y, or null
+  bf16_t* Tout; bf16_t* Sout; int ldts;       // gate: saved tanh / sigmoid halves
+  int R, N, Cin, taps, Tp, Np, Kp;
+  int out_f32, relu;
+  uint32_t drop_thresh, drop_seed; float drop_scale;   // gate dropout (modules.py:153)
+};
+
+template <int BN, bool GATE>
+__global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
+{
+  constexpr int WN = BN / 64;                 // waves along channels
+  constexpr int WM = 4 / WN;                  // waves along rows
+  constexpr int MB = BM / (32 * WM);          // 32-row MFMA blocks per wave
+  constexpr int WCH = BN / 32;                // weight 16-B chunks per thread per tile
+
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][XROWS * LDP];
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * LDP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wm = wave / WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int taps = a.taps, padl = taps >> 1;
+  const int NS = a.Kp / BK, NIT = NS * taps;
+  const int xrows = BM + taps - 1;
+
+  // staging registers as named scalars (arrays that live across the conditional prefetch end up
+  // in scratch memory)
+  uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, x0 = {}, x1 = {}, x2 = {}, x3 = {}, x4 = {};
+  auto ldw1 = [&](int it, int i) -> uint4 {
+    const int slice = it / taps, tap = it - slice * taps;
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    return *reinterpret_cast<const uint4*>(a.W + ((size_t)(tap * a.Np + n0 + row) * a.Kp + slice * BK + c8 * 8));
+  };
+  auto ldx1 = [&](int slice, int i) -> uint4 {
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    int gm = m0 - padl + (row < xrows ? row : xrows - 1);
+    gm = gm < 0 ? 0 : (gm >= a.R ? a.R - 1 : gm);
+    const int ch = slice * BK + c8 * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ch < a.Cin) v = *reinterpret_cast<const uint4*>(a.X + (size_t)gm * a.ldx + ch);
+    return v;
+  };
+  auto stw1 = [&](int buf, int i, const uint4& v) {
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    *reinterpret_cast<uint4*>(&Ws[buf][row * LDP + c8 * 8]) = v;
+  };
+  auto stx1 = [&](int buf, int i, const uint4& v) {
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    if (row < xrows) *reinterpret_cast<uint4*>(&Xs[buf][row * LDP + c8 * 8]) = v;
+  };
+#define load_W(it)  do { w0 = ldw1(it, 0); w1 = ldw1(it, 1); if (WCH > 2) { w2 = ldw1(it, 2); w3 = ldw1(it, 3); } } while (0)
+#define store_W(bf) do { stw1(bf, 0, w0); stw1(bf, 1, w1); if (WCH > 2) { stw1(bf, 2, w2); stw1(bf, 3, w3); } } while (0)
+#define load_X(sl)  do { x0 = ldx1(sl, 0); x1 = ldx1(sl, 1); x2 = ldx1(sl, 2); x3 = ldx1(sl, 3); x4 = ldx1(sl, 4); } while (0)
+#define store_X(bf) do { stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); stx1(bf, 3, x3); stx1(bf, 4, x4); } while (0)
+
+  f32x16_t acc[2][MB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  load_W(0); load_X(0); store_W(0); store_X(0);
+  __syncthreads();
+
+  const int mrow0 = wm * (32 * MB);
+  for (int it = 0; it < NIT; ++it) {
+    const int slice = it / taps, tap = it - slice * taps;
+    const int nxt = it + 1;
+    const bool has = nxt < NIT;
+    const bool newslice = has && (tap == taps - 1);
+    if (has) { load_W(nxt); if (newslice) load_X(slice + 1); }
+
+    const bf16_t* wsb = &Ws[it & 1][(64 * wn + r) * LDP + 8 * h];
+    const bf16_t* xsb = &Xs[slice & 1][(mrow0 + r + tap) * LDP + 8 * h];
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8_t af[2], bfm[MB];
+#pragma unroll
+      for (int bn = 0; bn < 2; ++bn) af[bn] = *reinterpret_cast<const bf16x8_t*>(wsb + bn * 32 * LDP + ks * 16);
+#pragma unroll
+      for (int bm = 0; bm < MB; ++bm) bfm[bm] = *reinterpret_cast<const bf16x8_t*>(xsb + bm * 32 * LDP + ks * 16);
+#pragma unroll
+      for (int bn = 0; bn < 2; ++bn)
+#pragma unroll
+        for (int bm = 0; bm < MB; ++bm)
+          acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[bn], bfm[bm], acc[bn][bm], 0, 0, 0);
+    }
+
+    if (has) { store_W(nxt & 1); if (newslice) store_X((slice + 1) & 1); }
+    __syncthreads();
+  }
+
+#undef load_W
+#undef store_W
+#undef load_X
+#undef store_X
+  // ------------------------------------------------------------------ epilogue
+#pragma unroll
+  for (int bm = 0; bm < MB; ++bm) {
+    const int m = m0 + mrow0 + 32 * bm + r;
+    if (m >= a.R) continue;
+    const float rm = a.rowmask ? a.rowmask[m] : 1.0f;
+    const int b = a.cond ? (m / a.Tp) : 0;
+    if (GATE) {
+      const int half = a.N >> 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = (n0 >> 1) + 32 * wn + 8 * g + 4 * h;          // gate channel of element 0
+        float tt[4], ss[4], aa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float pt = acc[0][bm][4 * g + i], ps = acc[1][bm][4 * g + i];
+          if (a.bias) { pt += a.bias[c + i]; ps += a.bias[half + c + i]; }
+          if (a.drop_thresh) {                                       // x_in = drop(conv(x))
+            pt = drop_keep(a.drop_seed, m, c + i, a.drop_thresh) ? pt * a.drop_scale : 0.0f;
+            ps = drop_keep(a.drop_seed, m, half + c + i, a.drop_thresh) ? ps * a.drop_scale : 0.0f;
+          }
+          if (a.cond) { pt += a.cond[(size_t)b * a.ldc + c + i]; ps += a.cond[(size_t)b * a.ldc + half + c + i]; }
+          tt[i] = tanhf_(pt); ss[i] = sigmoidf_(ps); aa[i] = tt[i] * ss[i];
+        }
+        *reinterpret_cast<uint2*>(a.Tout + (size_t)m * a.ldts + c) = make_uint2(pack2bf(tt[0], tt[1]), pack2bf(tt[2], tt[3]));
+        *reinterpret_cast<uint2*>(a.Sout + (size_t)m * a.ldts + c) = make_uint2(pack2bf(ss[0], ss[1]), pack2bf(ss[2], ss[3]));
+        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + c) =
+            make_uint2(pack2bf(aa[0], aa[1]), pack2bf(aa[2], aa[3]));
+      }
+    } else {
+#pragma unroll
+      for (int bn = 0; bn < 2; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + 64 * wn + 32 * bn + 8 * g + 4 * h;
+          if (n >= a.N) continue;                                    // N % 4 == 0
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[bn][bm][4 * g + i];
+          if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+          if (a.cond) { const float* cp = a.cond + (size_t)b * a.ldc + n; v[0] += cp[0]; v[1] += cp[1]; v[2] += cp[2]; v[3] += cp[3]; }
+          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          if (a.out_f32) {
+            if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n);
+                            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w; }
+            *reinterpret_cast<float4*>(static_cast<float*>(a.Y) + (size_t)m * a.ldy + n) =
+                make_float4(v[0] * rm, v[1] * rm, v[2] * rm, v[3] * rm);
+          } else {
+            if (a.addend) { const uint2 ad = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(a.addend) + (size_t)m * a.ldadd + n);
+                            v[0] += bf2f(ad.x & 0xffff); v[1] += bf2f(ad.x >> 16); v[2] += bf2f(ad.y & 0xffff); v[3] += bf2f(ad.y >> 16); }
+            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) =
+                make_uint2(pack2bf(v[0] * rm, v[1] * rm), pack2bf(v[2] * rm, v[3] * rm));
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight preparation: (optional) weight-norm w = g * v / ||v|| (torch weight_norm dim=0, the
+// reference's modules.py:127,132,141 / attentions.py:103), then bf16 packing into
+//   fwd   Pf[tap][pn(co)][ci]              (pn = gate interleave or identity)
+//   dgrad Pd[taps-1-tap][ci][co]           (data-gradient conv: roles swapped, taps flipped)
+// One workgroup per output channel.  Padding entries of Pf/Pd are never written (callers zero
+// the buffers once).
+__global__ __launch_bounds__(256) void gt_pack_conv_weights_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
+    float* __restrict__ inv_norm, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate)
+{
+  __shared__ float red[4];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  const int n = Cin * taps;
+  const float* vr = v + (size_t)co * n;
+  float scale = 1.0f;
+  if (g) {
+    float ss = 0.f;
+    for (int i = tid; i < n; i += 256) { const float x = vr[i]; ss += x * x; }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float inv = 1.0f / sqrtf(tot);
+    if (tid == 0 && inv_norm) inv_norm[co] = inv;
+    scale = g[co] * inv;
+  }
+  int pn = co;
+  if (gate) {                                   // [32 tanh | 32 sigmoid] interleave per 64 packed rows
+    const int half = Cout >> 1;
+    const int c = co < half ? co : co - half;
+    pn = (c >> 5) * 64 + (co < half ? 0 : 32) + (c & 31);
+  }
+  for (int i = tid; i < n; i += 256) {
+    const int ci = i / taps, tap = i - ci * taps;
+    const bf16_t w = f2bf(vr[i] * scale);
+    if (Pf) Pf[((size_t)tap * Npf + pn) * Kpf + ci] = w;
+    if (Pd) Pd[((size_t)(taps - 1 - tap) * Npd + ci) * Kpd + co] = w;
+  }
+}
+
+}  // namespace
+
+extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
+                                 const float* cond, int ldc, const float* rowmask,
+                                 void* Y, int ldy, int out_f32, const void* addend, int ldadd,
+                                 void* gate_t, void* gate_s, int ldts,
+                                 int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
+                                 int relu, int gate, float drop_p, uint32_t drop_seed, void* stream)
+{
+  if (R < 0 || N <= 0 || Cin <= 0) return GT_E_INVAL;
+  if (R == 0) return GT_OK;
+  if (!X || !Wp || !Y) return GT_E_INVAL;
+  if (taps < 1 || taps > MAXTAPS || !(taps & 1)) return GT_E_UNSUPPORTED;
+  if ((N & 3) || (Cin & 7) || (ldx & 7) || (ldy & 3) || (Kp % BK) || Kp < Cin) return GT_E_ALIGN;
+  if (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15) return GT_E_ALIGN;
+  if (addend && (ldadd & 3)) return GT_E_ALIGN;
+  if (cond && Tp <= 0) return GT_E_INVAL;
+  ConvArgs a;
+  a.X = static_cast<const bf16_t*>(X); a.ldx = ldx; a.W = static_cast<const bf16_t*>(Wp); a.bias = bias;
+  a.cond = cond; a.ldc = ldc; a.rowmask = rowmask; a.Y = Y; a.ldy = ldy; a.addend = addend; a.ldadd = ldadd;
+  a.Tout = static_cast<bf16_t*>(gate_t); a.Sout = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
+  a.R = R; a.N = N; a.Cin = Cin; a.taps = taps; a.Tp = Tp > 0 ? Tp : 1; a.Np = Np; a.Kp = Kp;
+  a.out_f32 = out_f32; a.relu = relu;
+  a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f;
+  if (drop_p > 0.0f) {
+    if (!gate || drop_p >= 1.0f) return GT_E_UNSUPPORTED;
+    a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 block(256);
+  if (gate) {
+    if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32 || (ldts & 3)) return GT_E_INVAL;
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);
+  } else if (Np % 128 == 0) {
+    if (Np < N) return GT_E_INVAL;
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, false>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);
+  } else {
+    if (Np % 64 || Np < N) return GT_E_INVAL;
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<64, false>), dim3(Np / 64, (R + BM - 1) / BM), block, 0, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
+extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
+                                    float* inv_norm, int Cout, int Cin, int taps,
+                                    int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream)
+{
+  if (Cout <= 0 || Cin <= 0 || taps < 1 || taps > MAXTAPS) return GT_E_INVAL;
+  if (!v || (!pack_fwd && !pack_dgrad)) return GT_E_INVAL;
+  if (pack_fwd && (Np_fwd < Cout || Kp_fwd < Cin)) return GT_E_INVAL;
+  if (pack_dgrad && (Np_dgrad < Cin || Kp_dgrad < Cout)) return GT_E_INVAL;
+  if (gate && (Cout % 128)) return GT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gt_pack_conv_weights_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     v, g, static_cast<bf16_t*>(pack_fwd), static_cast<bf16_t*>(pack_dgrad), inv_norm,
+                     Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}

@@ -1,0 +1,102 @@
+"""Thin host-side wrappers over the C-ABI kernels (rows layout helpers, packed conv weights).
+
+PyTorch is used here only for device memory, streams and trivial index plumbing (building the
+row mask); all arithmetic of the hot path happens in libglowtts_hip.so.
+"""
+import torch
+
+from . import _lib
+
+HALO = 2  # GT_HALO in include/glowtts_hip.h
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class RowsCtx:
+    """Geometry of one batch in the rows layout: utterance b owns rows [b*Tp, (b+1)*Tp),
+    frame t is row b*Tp + HALO + t; rowmask is 1 on valid frames."""
+
+    def __init__(self, lengths, T):
+        _lib.require_cuda(lengths)
+        self.device = lengths.device
+        self.B = int(lengths.shape[0])
+        self.T = int(T)
+        self.Tp = self.T + 2 * HALO
+        self.R = self.B * self.Tp
+        self.lengths = lengths.to(torch.int32)
+        t = torch.arange(self.Tp, device=self.device) - HALO
+        self.rowmask2d = ((t[None, :] >= 0) & (t[None, :] < self.lengths[:, None])).to(torch.float32)
+        self.rowmask = self.rowmask2d.reshape(-1).contiguous()
+
+    def to_rows(self, x, dtype=None):
+        """[B, C, T] -> [R, C] (test/boundary helper; zero halos)."""
+        B, C, T = x.shape
+        assert B == self.B and T == self.T
+        out = torch.zeros(self.B, self.Tp, C, device=x.device, dtype=dtype or x.dtype)
+        out[:, HALO:HALO + T] = x.transpose(1, 2).to(out.dtype)
+        return out.reshape(self.R, C)
+
+    def from_rows(self, xr, dtype=None):
+        """[R, C] -> [B, C, T]."""
+        C = xr.shape[1]
+        x = xr.reshape(self.B, self.Tp, C)[:, HALO:HALO + self.T].transpose(1, 2)
+        return x.to(dtype or xr.dtype).contiguous()
+
+
+class PackedConv:
+    """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing."""
+
+    def __init__(self, Cout, Cin, taps, gate=False, device="cuda"):
+        self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, taps, gate
+        self.Kp_f = _round_up(Cin, 64)
+        self.Np_f = Cout if gate else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
+        self.Kp_d = _round_up(Cout, 64)
+        self.Np_d = _round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64)
+        self.fwd = torch.zeros(taps * self.Np_f * self.Kp_f, dtype=torch.int16, device=device)
+        self.dgrad = torch.zeros(taps * self.Np_d * self.Kp_d, dtype=torch.int16, device=device)
+        self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
+
+    def pack(self, v, g=None):
+        """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""
+        L = _lib.lib()
+        v = v.detach().contiguous().float()
+        assert tuple(v.shape) == (self.Cout, self.Cin, self.taps), (v.shape, self.Cout, self.Cin, self.taps)
+        gg = None if g is None else g.detach().reshape(-1).contiguous().float()
+        _lib.check(L.gt_pack_conv_weights(_lib.ptr(v), _lib.ptr(gg), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
+                                          _lib.ptr(self.inv_norm), self.Cout, self.Cin, self.taps,
+                                          self.Np_f, self.Kp_f, self.Np_d, self.Kp_d, int(self.gate),
+                                          _lib.current_stream(v.device)), "gt_pack_conv_weights")
+        return self
+
+
+def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=None, out_f32=False,
+              addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None):
+    """Y = epilogue(conv(x)) in the rows layout via gt_conv_gemm_bf16.  x: [R, >=Cin] bf16.
+    `out`/`addend` may be column-slices of wider row buffers (row stride taken from .stride(0))."""
+    L = _lib.lib()
+    assert x.dtype == torch.bfloat16 and x.stride(1) == 1
+    R = x.shape[0] if R is None else R
+    if dgrad:
+        N, Cin, Np, Kp, W = pc.Cin, pc.Cout, pc.Np_d, pc.Kp_d, pc.dgrad
+    else:
+        N, Cin, Np, Kp, W = pc.Cout, pc.Cin, pc.Np_f, pc.Kp_f, pc.fwd
+    n_out = N // 2 if gate else N
+    if out is None:
+        out = torch.empty(R, n_out, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    out_f32 = out.dtype == torch.float32
+    if gate:
+        if gate_t is None:
+            gate_t = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
+            gate_s = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
+    rc = L.gt_conv_gemm_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
+                             _lib.ptr(cond), 0 if cond is None else cond.stride(0),
+                             _lib.ptr(ctx.rowmask) if mask else None,
+                             _lib.ptr(out), out.stride(0), int(out_f32),
+                             _lib.ptr(addend), 0 if addend is None else addend.stride(0),
+                             _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
+                             R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
+                             _lib.current_stream(x.device))
+    _lib.check(rc, "gt_conv_gemm_bf16")
+    return (out, gate_t, gate_s) if gate else out

@@ -90,6 +90,40 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
                                  int B, int T_x, int T_y, int64_t stride_b, int64_t stride_x,
                                  void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * "Rows" activation layout used by every kernel below: [R, C] channels-last (C contiguous),
+ * R = B * Tp, utterance b owns rows [b*Tp, (b+1)*Tp), Tp = T + 2*HALO (HALO = 2), frame t of
+ * utterance b is row b*Tp + HALO + t; halo rows and rows past the utterance length are zero
+ * (rowmask[R] is 1 on valid frames, 0 elsewhere).  bf16 tensors are raw uint16 bit patterns.
+ */
+#define GT_HALO 2
+
+/* 1-D convolution (odd k <= 5, dilation 1) as implicit GEMM on bf16 MFMA, fp32 accumulate.
+ * Replaces the conv1d calls of modules.py:152,165 / attentions.py:144,172,232-238,365-371 /
+ * modules.py:97 / models.py:710 and, with dgrad-packed weights, their data gradients.
+ *   Y[m,n] = epi( sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci] + bias[n] + cond[m/Tp][n] )
+ *   epi: optional relu, optional + addend[m,n], optional * rowmask[m]; output bf16 or fp32.
+ *   gate != 0 (WaveNet gate, commons.py:61-68; N = 2*half, packed with the gate interleave):
+ *     pre = drop(acc + bias) + cond;  T = tanh(pre[:half]), S = sigmoid(pre[half:]),
+ *     Y[m, :half] = T*S (bf16), T and S are saved to gate_t / gate_s ([R, ldts] bf16).
+ *   Wp: weights packed by gt_pack_conv_weights ([taps][Np][Kp] bf16, zero padded).
+ * Alignment: all pointers 16 B; N%4, Cin%8, ldx%8, ldy%4, Kp%64 == 0. */
+int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
+                      const float* cond, int ldc, const float* rowmask,
+                      void* Y, int ldy, int out_f32, const void* addend, int ldadd,
+                      void* gate_t, void* gate_s, int ldts,
+                      int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
+                      int relu, int gate, float drop_p, uint32_t drop_seed, void* stream);
+
+/* Weight preparation for gt_conv_gemm_bf16: w = g*v/||v|| when g != NULL (torch weight_norm,
+ * dim 0: modules.py:127,132,141, attentions.py:103) else w = v; v is [Cout, Cin, taps] fp32.
+ * Writes bf16 pack_fwd [taps][Np_fwd][Kp_fwd] and/or pack_dgrad [taps][Np_dgrad][Kp_dgrad]
+ * (roles swapped, taps flipped) and inv_norm[Cout] = 1/||v|| (optional).  Padding entries are
+ * not touched: zero the buffers once. */
+int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
+                         float* inv_norm, int Cout, int Cin, int taps,
+                         int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

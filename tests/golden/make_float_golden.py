@@ -1,0 +1,167 @@
+"""Generate tests/golden/float_golden.npz by IMPORTING the reference's Python modules
+(/root/reference: modules.py, attentions.py, models.py, commons.py) in the build container.
+
+    make -C oracle && python tests/golden/make_float_golden.py
+
+Nothing of the reference is copied: this script imports it where it lies, fills the reference
+nn.Modules with closed-form weights (tests/golden/fill.py), runs them in eval mode on small
+seeded inputs at the true channel counts and stores inputs / outputs / input-gradients.
+
+Import notes (recorded in DESIGN.md): commons.py / stft.py import `librosa`, which is not in this
+image and is not on the hot path, and models.py imports the in-place-compiled `monotonic_align`
+package; both names are registered in sys.modules before the import (librosa as an empty
+placeholder whose functions are never called; monotonic_align backed by oracle/_ref, the
+reference's own core.pyx compiled by oracle/Makefile).  `text/` is not imported.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("GLOWTTS_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from fill import fill_module  # noqa: E402
+from oracle import mas as omas  # noqa: E402
+
+
+def import_reference():
+    def _never(*a, **k):
+        raise RuntimeError("librosa placeholder: not available in this image, not on the hot path")
+    lib = types.ModuleType("librosa")
+    lib.filters = types.ModuleType("librosa.filters"); lib.filters.mel = _never
+    lib.util = types.ModuleType("librosa.util"); lib.util.pad_center = _never; lib.util.tiny = _never
+    lib.util.normalize = _never
+    lib.stft = _never; lib.istft = _never
+    sys.modules.setdefault("librosa", lib)
+    sys.modules.setdefault("librosa.filters", lib.filters)
+    sys.modules.setdefault("librosa.util", lib.util)
+
+    ma = types.ModuleType("monotonic_align")
+
+    def maximum_path(value, mask):      # call pattern of reference monotonic_align/__init__.py:6-21
+        p = omas.oracle_maximum_path(value.detach().cpu().numpy(), mask.detach().cpu().numpy(),
+                                     core=omas.ref_maximum_path_c)
+        return torch.from_numpy(p).to(device=value.device, dtype=value.dtype)
+    ma.maximum_path = maximum_path
+    sys.modules.setdefault("monotonic_align", ma)
+
+    sys.path.insert(0, REF)
+    import attentions, commons, models, modules  # noqa: E401
+    return commons, modules, attentions, models
+
+
+def lens_mask(lengths, T):
+    l = torch.tensor(lengths)
+    return (torch.arange(T)[None, :] < l[:, None]).unsqueeze(1).float()
+
+
+def grads_of(outs_weights, inputs):
+    """d(sum_k <out_k, r_k>)/d(inputs) for fixed pseudo-random r_k: pins the backward pass."""
+    tot = 0
+    for o, seed in outs_weights:
+        g = torch.Generator().manual_seed(seed)
+        tot = tot + (o * torch.randn(o.shape, generator=g)).sum()
+    return torch.autograd.grad(tot, inputs, allow_unused=True)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(True)
+    commons, modules, attentions, models = import_reference()
+    out = {}
+    g = torch.Generator().manual_seed(1234)
+
+    def rnd(*shape, scale=1.0):
+        return torch.randn(*shape, generator=g) * scale
+
+    # ---- ActNorm / InvConvNear on the squeezed flow state [b,160,t]
+    x = rnd(2, 160, 12); m = lens_mask([12, 7], 12); x = x * m
+    an = fill_module(modules.ActNorm(160), "an.")
+    z, ld = an(x, m)
+    out.update(an_x=x, an_mask=m, an_z=z, an_logdet=ld)
+    ic = fill_module(modules.InvConvNear(160, n_split=4), "ic.")
+    z, ld = ic(x, m)
+    out.update(ic_z=z, ic_logdet=ld)
+
+    # ---- WN (no conditioning) and WN with g
+    xh = rnd(2, 192, 12) * m
+    wn = fill_module(modules.WN(160, 192, 5, 1, 4, 0, 0.05), "wn.").eval()
+    out.update(wn_x=xh, wn_out=wn(xh, m))
+    wng = fill_module(modules.WN(160, 192, 5, 1, 4, 8, 0.05), "wng.").eval()
+    gc = rnd(2, 8, 1)
+    out.update(wng_g=gc, wng_out=wng(xh, m, gc))
+
+    # ---- CouplingBlock fwd + input grad
+    xc = (rnd(2, 160, 12) * m).requires_grad_(True)
+    cb = fill_module(attentions.CouplingBlock(160, 192, 5, 1, 4, gin_channels=0, p_dropout=0.05, n_sqz=2), "cb.").eval()
+    z, ld = cb(xc, m)
+    (gx,) = grads_of([(z, 1), (ld, 2)], [xc])
+    out.update(cb_x=xc, cb_z=z, cb_logdet=ld, cb_gx=gx)
+
+    # ---- FlowSpecDecoder (2 blocks), odd T_y to exercise the trim, fwd + input grad
+    y = rnd(2, 80, 25); ym = lens_mask([24, 14], 25)
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, n_split=4, n_sqz=2), "decoder.").eval()
+    yy = (y[:, :, :24] * ym[:, :, :24]).requires_grad_(True)
+    z, ld = dec(yy, ym[:, :, :24])
+    (gy,) = grads_of([(z, 3), (ld, 4)], [yy])
+    out.update(dec_y=yy, dec_mask=ym[:, :, :24], dec_z=z, dec_logdet=ld, dec_gy=gy)
+
+    # ---- relative-position MHA at T in {3,5,37}: both branches of attentions.py:292-305
+    for T in (3, 5, 37):
+        xm = lens_mask([T, max(1, T - 2)], T)
+        xa = (rnd(2, 192, T) * xm).requires_grad_(True)
+        mha = fill_module(attentions.MultiHeadAttention(192, 192, 2, window_size=4, p_dropout=0.1), f"mha{T}.").eval()
+        am = xm.unsqueeze(2) * xm.unsqueeze(-1)
+        o = mha(xa, xa, am)
+        (ga,) = grads_of([(o, 5)], [xa])
+        out.update({f"mha{T}_x": xa, f"mha{T}_mask": xm, f"mha{T}_out": o, f"mha{T}_p": mha.attn, f"mha{T}_gx": ga})
+
+    # ---- FFN, LayerNorm, ConvReluNorm, Encoder(2 layers), TextEncoder(2 layers), DurationPredictor
+    T = 11; xm = lens_mask([11, 6], T); xe = rnd(2, 192, T) * xm
+    ffn = fill_module(attentions.FFN(192, 192, 768, 3, p_dropout=0.1), "ffn.").eval()
+    out.update(enc_x=xe, enc_mask=xm, ffn_out=ffn(xe, xm))
+    ln = fill_module(modules.LayerNorm(192), "ln.")
+    out.update(ln_out=ln(xe))
+    crn = fill_module(modules.ConvReluNorm(192, 192, 192, 5, 3, 0.5), "pre.").eval()
+    out.update(crn_out=crn(xe, xm))
+    enc = fill_module(attentions.Encoder(192, 768, 2, 2, 3, 0.1, window_size=4), "enc.").eval()
+    out.update(encoder_out=enc(xe, xm))
+    ids = torch.randint(1, 148, (2, T), generator=g); xl = torch.tensor([11, 6])
+    te = fill_module(models.TextEncoder(148, 80, 192, 768, 256, 2, 2, 3, 0.1, window_size=4, mean_only=True,
+                                        prenet=True, use_sdp=False), "encoder.").eval()
+    tx, tm, tlogs, tmask = te(ids, xl)
+    out.update(te_ids=ids, te_len=xl, te_x=tx, te_m=tm, te_logs=tlogs, te_mask=tmask)
+    dp = fill_module(models.DurationPredictor(192, 256, 3, 0.1), "dp.").eval()
+    out.update(dp_out=dp(xe, xm))
+
+    # ---- glue: logp (models.py:1076-1082), MAS through the reference call pattern, mle_loss
+    x_m = rnd(2, 80, T) * xm; x_logs = torch.zeros_like(x_m)
+    zz = rnd(2, 80, 24) * ym[:, :, :24]
+    with torch.no_grad():
+        x_s_sq_r = torch.exp(-2 * x_logs)
+        import math
+        logp1 = torch.sum(-0.5 * math.log(2 * math.pi) - x_logs, [1]).unsqueeze(-1)
+        logp2 = torch.matmul(x_s_sq_r.transpose(1, 2), -0.5 * (zz ** 2))
+        logp3 = torch.matmul((x_m * x_s_sq_r).transpose(1, 2), zz)
+        logp4 = torch.sum(-0.5 * (x_m ** 2) * x_s_sq_r, [1]).unsqueeze(-1)
+        logp = logp1 + logp2 + logp3 + logp4
+    import monotonic_align
+    amask = (xm.unsqueeze(-1) * ym[:, :, :24].unsqueeze(2)).squeeze(1)
+    attn = monotonic_align.maximum_path(logp, amask)
+    z_m = torch.matmul(attn.transpose(1, 2), x_m.transpose(1, 2)).transpose(1, 2)
+    mle = commons.mle_loss(zz, z_m, torch.zeros_like(z_m), torch.tensor([1.5, -0.5]), ym[:, :, :24])
+    out.update(glue_xm=x_m, glue_z=zz, glue_logp=logp, glue_attn=attn, glue_zm=z_m, glue_mle=mle)
+
+    path = os.path.join(HERE, "float_golden.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
+    print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""GPU tests: bf16 MFMA implicit-GEMM conv (gt_conv_gemm_bf16) vs plain PyTorch fp32 conv1d on the
+same bf16-rounded operands.  Tolerance: fp32 accumulation of bf16 products -> 2e-3 relative to the
+output scale (bf16 output rounding adds 2^-8)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def ref_conv(x_bct, w, b, pad):
+    return F.conv1d(x_bct.float(), w.float(), None if b is None else b.float(), padding=pad)
+
+
+def make(B, T, Cin, Cout, k, seed, lens=None):
+    from glow_tts_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    lens = lens or [T] * B
+    ctx = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev()), T)
+    x = torch.randn(B, Cin, T, generator=g).to(dev())
+    x = x * ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)
+    w = (torch.randn(Cout, Cin, k, generator=g) / (Cin * k) ** 0.5).to(dev())
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev())
+    return ctx, x, w, b
+
+
+@pytest.mark.parametrize("Cin,Cout,k", [(192, 384, 5), (80, 192, 1), (192, 160, 1), (192, 768, 3), (768, 192, 3),
+                                        (192, 192, 1), (192, 80, 1), (384, 192, 1)])
+def test_conv_fwd_matches_torch(built, Cin, Cout, k):
+    from glow_tts_amd import ops
+    B, T = 3, 150
+    ctx, x, w, b = make(B, T, Cin, Cout, k, seed=Cin + Cout + k, lens=[150, 97, 1])
+    xb = x.to(torch.bfloat16)
+    wb = w.to(torch.bfloat16)
+    pc = ops.PackedConv(Cout, Cin, k).pack(wb.float())
+    xr = ctx.to_rows(xb)
+    y = ops.conv_rows(xr, pc, ctx, bias=b, out_f32=True)
+    got = ctx.from_rows(y)
+    want = ref_conv(xb, wb, b, k // 2)
+    scale = want.abs().max().item()
+    assert torch.allclose(got, want, atol=2e-3 * scale, rtol=0), (got - want).abs().max().item() / scale
+    # masked + relu + bf16 out
+    y2 = ops.conv_rows(xr, pc, ctx, bias=b, relu=True, mask=True)
+    got2 = ctx.from_rows(y2).float()
+    want2 = torch.relu(want) * ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)
+    assert torch.allclose(got2, want2, atol=1e-2 * scale, rtol=0)
+    # halo rows of a masked output are exactly zero
+    assert y2.reshape(B, ctx.Tp, Cout)[:, :ops.HALO].abs().max().item() == 0
+    assert y2.reshape(B, ctx.Tp, Cout)[:, ops.HALO + T:].abs().max().item() == 0
+
+
+def test_conv_dgrad_and_addend(built):
+    """Data gradient of a k=5 conv = conv of dY with the dgrad-packed weights; epilogue addend."""
+    from glow_tts_amd import ops
+    B, T, Cin, Cout, k = 2, 96, 192, 384, 5
+    ctx, x, w, b = make(B, T, Cin, Cout, k, seed=7)
+    wb = w.to(torch.bfloat16)
+    pc = ops.PackedConv(Cout, Cin, k).pack(wb.float())
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(B, Cout, T, generator=g).to(dev()).to(torch.bfloat16)
+    xx = x.clone().float().requires_grad_(True)
+    F.conv1d(xx, wb.float(), None, padding=2).backward(dy.float())
+    add = torch.randn(B, Cin, T, generator=g).to(dev()).to(torch.bfloat16)
+    dx = ops.conv_rows(ctx.to_rows(dy), pc, ctx, dgrad=True, addend=ctx.to_rows(add), mask=True)
+    got = ctx.from_rows(dx).float()
+    want = xx.grad + add.float()
+    scale = want.abs().max().item()
+    assert torch.allclose(got, want, atol=1e-2 * scale, rtol=0), (got - want).abs().max().item() / scale
+
+
+def test_conv_weight_norm_pack(built):
+    """w = g * v / ||v|| (torch weight_norm dim 0) folded into the packing."""
+    from glow_tts_amd import ops
+    B, T, Cin, Cout, k = 2, 64, 192, 192, 1
+    ctx, x, v, b = make(B, T, Cin, Cout, k, seed=11)
+    gw = (torch.rand(Cout, 1, 1, generator=torch.Generator().manual_seed(5)) + 0.5).to(dev())
+    w = gw * v / v.reshape(Cout, -1).norm(dim=1).reshape(Cout, 1, 1)
+    pc = ops.PackedConv(Cout, Cin, k).pack(v, gw)
+    assert torch.allclose(pc.inv_norm, 1.0 / v.reshape(Cout, -1).norm(dim=1), rtol=1e-5)
+    xb = x.to(torch.bfloat16)
+    y = ops.conv_rows(ctx.to_rows(xb), pc, ctx, bias=b, out_f32=True)
+    want = ref_conv(xb, w.to(torch.bfloat16), b, 0)
+    scale = want.abs().max().item()
+    assert torch.allclose(ctx.from_rows(y), want, atol=3e-3 * scale, rtol=0)
+
+
+def test_conv_gate_epilogue(built):
+    """in_layer + cond + tanh*sigmoid gate (modules.py:152-163, commons.py:61-68), no dropout."""
+    from glow_tts_amd import ops
+    B, T, H, k = 2, 80, 192, 5
+    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=21, lens=[80, 33])
+    wb = w.to(torch.bfloat16)
+    pc = ops.PackedConv(2 * H, H, k, gate=True).pack(wb.float())
+    cond = torch.randn(B, 2 * H, generator=torch.Generator().manual_seed(9)).to(dev())
+    xb = x.to(torch.bfloat16)
+    acts, t, s = ops.conv_rows(ctx.to_rows(xb), pc, ctx, bias=b, cond=cond, gate=True)
+    pre = ref_conv(xb, wb, b, 2) + cond.unsqueeze(-1)
+    want_t, want_s = torch.tanh(pre[:, :H]), torch.sigmoid(pre[:, H:])
+    assert torch.allclose(ctx.from_rows(t).float(), want_t, atol=1.5e-2)
+    assert torch.allclose(ctx.from_rows(s).float(), want_s, atol=1.5e-2)
+    assert torch.allclose(ctx.from_rows(acts).float(), want_t * want_s, atol=1.5e-2)
+
+
+def test_conv_gate_dropout_statistics(built):
+    from glow_tts_amd import ops
+    B, T, H, k = 2, 128, 192, 5
+    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=22)
+    pc = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
+    xr = ctx.to_rows(x.to(torch.bfloat16))
+    a0, t0, _ = ops.conv_rows(xr, pc, ctx, bias=None, gate=True)
+    a1, t1, _ = ops.conv_rows(xr, pc, ctx, bias=None, gate=True, drop_p=0.25, seed=1234)
+    a2, t2, _ = ops.conv_rows(xr, pc, ctx, bias=None, gate=True, drop_p=0.25, seed=1234)
+    assert torch.equal(a1, a2)                                   # replayable
+    dropped = (t1.float() == 0) & (t0.float().abs() > 1e-3)      # tanh(0) = 0 where the pre-activation was dropped
+    frac = dropped.float().mean().item()
+    assert 0.2 < frac < 0.3, frac
