@@ -25,6 +25,25 @@ PROTOTYPES = {
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_flow_scalars": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gt_actnorm_invconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gt_actnorm_invconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gt_coupling_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_coupling_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_gate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                            c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_rows_add_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gt_rows_f32_to_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

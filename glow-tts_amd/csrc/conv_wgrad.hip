@@ -1,0 +1,240 @@
+// Weight gradient of the rows-layout 1-D convolution on bf16 MFMA for gfx950, plus the
+// weight-norm backward that consumes it.  (The reference gets these from autograd through
+// ATen conv backward + torch weight_norm: modules.py:127-141,152,165; attentions.py:103.)
+//
+//   dW[tap][co][ci] = sum_m dY[m, co] * X[m + tap - k/2, ci]          (reduction over ALL rows)
+//
+// MFMA A = dY^T (rows = co, k = row m), MFMA B = X (k = row m + tap shift, cols = ci).  Both
+// operands have the reduction index strided in memory (channels-last), so tiles are staged
+// row-major in LDS by coalesced 16-byte loads and consumed through ds_read_b64_tr_b16 (the
+// hardware transposing read), pitch = row bytes + 64 so that the four rows of a read block hit
+// disjoint bank windows.  One workgroup = 128 co x 64 ci x all taps over one slab of rows; slab
+// partials go to a workspace [S][taps][Cout][Cin] with plain 128-byte-coalesced stores (float
+// atomics would cap at ~1.3 TB/s) and are summed by the weight-norm backward kernel, which then
+// maps dW to (dv, dg) or to a plain dw in the parameter's own [Cout, Cin, taps] layout.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int KB = 64;                        // rows per staging step
+constexpr int MAXTAPS = 5;
+constexpr int YP = 128 + 32;                  // dY tile pitch in halfs (320 B)
+constexpr int XP = 64 + 32;                   // X tile pitch in halfs (192 B)
+constexpr int XROWS = KB + MAXTAPS - 1;
+
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p0, const bf16_t* p1) {
+  // two transposing reads: rows kb..kb+3 and kb+4..kb+7 of this lane's column
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)p1);
+  typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
+    const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy,
+    float* __restrict__ part, int R, int Cin, int Cout, int slab_rows)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[KB * YP];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[XROWS * XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64, slab = blockIdx.z;
+  const int padl = TAPS >> 1;
+  const int mbeg = slab * slab_rows;
+  const int mend = min(R, mbeg + slab_rows);
+
+  f32x16_t acc[TAPS][2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][j][e] = 0.0f;
+
+  // lane geometry of the transposing read (see cdna guide T10): within a 16-lane group lane
+  // 4q+p supplies the address of block row q, columns 4p..4p+3 and receives column (lane&15).
+  const int li = lane & 15, q = li >> 2, p = li & 3;
+  const int colhalf = ((lane >> 4) & 1) * 16;          // which 16 columns of the 32-wide MFMA block
+  const int h = lane >> 5;                             // k half (rows 8h..8h+7 of a 16-row step)
+
+  for (int mb = mbeg; mb < mend; mb += KB) {
+    // ---- stage dY[mb .. mb+64) x [co0 .. co0+128) and X[mb-padl .. mb+64+padl) x [ci0 .. ci0+64)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
+      const int m = mb + row, co = co0 + c8 * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < mend && co < Cout) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
+      *reinterpret_cast<uint4*>(&Ys[row * YP + c8 * 8]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+      if (row < KB + TAPS - 1) {
+        const int m = mb - padl + row, ci = ci0 + c8 * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m >= 0 && m < R && ci < Cin) v = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + ci);
+        *reinterpret_cast<uint4*>(&Xs[row * XP + c8 * 8]) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks) {
+      const int kb = ks * 16 + 8 * h;
+      // A: dY^T block (32 co of this wave) — rows kb..kb+7
+      const bf16_t* ya = &Ys[(kb + q) * YP + wave * 32 + colhalf + 4 * p];
+      const bf16x8_t af = tr_frag(ya, ya + 4 * YP);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16_t* xa = &Xs[(kb + t + q) * XP + j * 32 + colhalf + 4 * p];
+          const bf16x8_t bfg = tr_frag(xa, xa + 4 * XP);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfg, acc[t][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- slab partial: part[slab][tap][co][ci], lane = ci (128-byte rows per register)
+  const int r = lane & 31;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + j * 32 + r;
+      if (ci >= Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (co < Cout) part[(((size_t)slab * TAPS + t) * Cout + co) * Cin + ci] = acc[t][j][e];
+      }
+    }
+}
+
+// Sum the S slab partials and map to the parameter gradient(s).  One workgroup per co.
+//   plain conv:   dw[co][ci][tap] (+)= dW
+//   weight-norm:  w = g v / ||v||  =>  dg = <dW, v>/||v|| ;  dv = g/||v|| (dW - v <dW,v>/||v||^2)
+__global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
+    const float* __restrict__ part, int S, const float* __restrict__ v, const float* __restrict__ g,
+    const float* __restrict__ inv_norm, float* __restrict__ dv, float* __restrict__ dg,
+    int Cout, int Cin, int taps, int accumulate)
+{
+  extern __shared__ float dws[];               // [Cin*taps] summed dW of this co, natural order
+  __shared__ float red[4];
+  const int co = blockIdx.x, tid = threadIdx.x, n = Cin * taps;
+  float dot = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const int ci = i / taps, tap = i - ci * taps;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(((size_t)k * taps + tap) * Cout + co) * Cin + ci];
+    dws[i] = s;
+    if (g) dot += s * v[(size_t)co * n + i];
+  }
+  if (!g) {
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const size_t o = (size_t)co * n + i;
+      dv[o] = accumulate ? dv[o] + dws[i] : dws[i];
+    }
+    return;
+  }
+  dot = wave_sum(dot);
+  if ((tid & 63) == 0) red[tid >> 6] = dot;
+  __syncthreads();
+  const float d = red[0] + red[1] + red[2] + red[3];
+  const float inv = inv_norm[co], gg = g[co];
+  if (tid == 0) dg[co] = accumulate ? dg[co] + d * inv : d * inv;
+  const float a = gg * inv, bcoef = gg * d * inv * inv * inv;
+  for (int i = tid; i < n; i += 256) {
+    const size_t o = (size_t)co * n + i;
+    const float val = a * dws[i] - bcoef * v[o];
+    dv[o] = accumulate ? dv[o] + val : val;
+  }
+}
+
+// Column sums over rows: out[n] (+)= sum_m Y[m, n] (bias gradients).  bf16 or fp32 input.
+template <bool F32>
+__global__ __launch_bounds__(256) void gt_colsum_kernel(const void* __restrict__ Y, int ldy, float* __restrict__ out,
+                                                        int R, int N, int rows_per_block)
+{
+  // block (x: 64-column group, y: row slab); thread = (column c = tid&63, row phase tid>>6)
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * rows_per_block, m1 = min(R, m0 + rows_per_block);
+  float s = 0.f;
+  if (c < N) {
+    for (int m = m0 + ph; m < m1; m += 4)
+      s += F32 ? static_cast<const float*>(Y)[(size_t)m * ldy + c] : bf2f(static_cast<const bf16_t*>(Y)[(size_t)m * ldy + c]);
+  }
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int taps, int* slabs_out)
+{
+  if (R <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0) { if (slabs_out) *slabs_out = 0; return 0; }
+  const int tiles = ((Cout + 127) / 128) * ((Cin + 63) / 64);
+  int S = (256 + tiles - 1) / tiles;            // ~one workgroup per CU
+  if (S > 32) S = 32;
+  const int max_s = (R + KB - 1) / KB;
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  if (slabs_out) *slabs_out = S;
+  return (size_t)S * taps * Cout * Cin * sizeof(float);
+}
+
+extern "C" int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, int Cin, int Cout,
+                                  int taps, void* workspace, size_t workspace_bytes, void* stream)
+{
+  if (R <= 0 || Cin <= 0 || Cout <= 0) return GT_E_INVAL;
+  if (!X || !dY || !workspace) return GT_E_INVAL;
+  if (taps != 1 && taps != 3 && taps != 5) return GT_E_UNSUPPORTED;
+  if ((Cin & 7) || (Cout & 7) || (ldx & 7) || (ldy & 7)) return GT_E_ALIGN;
+  if (((uintptr_t)X | (uintptr_t)dY) & 15) return GT_E_ALIGN;
+  int S = 0;
+  if (workspace_bytes < gt_conv_wgrad_workspace_bytes(R, Cin, Cout, taps, &S)) return GT_E_INVAL;
+  const int slab_rows = (((R + S - 1) / S) + KB - 1) / KB * KB;
+  const dim3 grid((Cout + 127) / 128, (Cin + 63) / 64, S);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bf16_t* x = static_cast<const bf16_t*>(X); const bf16_t* dy = static_cast<const bf16_t*>(dY);
+  float* part = static_cast<float*>(workspace);
+  if (taps == 5)      hipLaunchKernelGGL(gt_conv_wgrad_kernel<5>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
+  else if (taps == 3) hipLaunchKernelGGL(gt_conv_wgrad_kernel<3>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
+  else                hipLaunchKernelGGL(gt_conv_wgrad_kernel<1>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
+extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
+                                 float* dv, float* dg, int Cout, int Cin, int taps, int accumulate, void* stream)
+{
+  if (!workspace || !v || !dv || Cout <= 0 || Cin <= 0 || taps <= 0) return GT_E_INVAL;
+  if (g && (!inv_norm || !dg)) return GT_E_INVAL;
+  int S = 0;
+  gt_conv_wgrad_workspace_bytes(R, Cin, Cout, taps, &S);
+  const size_t lds = (size_t)Cin * taps * sizeof(float);
+  if (lds > 60 * 1024) return GT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gt_weightnorm_bwd_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(workspace), S, v, g, inv_norm, dv, dg, Cout, Cin, taps, accumulate);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
+extern "C" int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void* stream)
+{
+  if (!Y || !out || R < 0 || N <= 0) return GT_E_INVAL;
+  if (R == 0) return GT_OK;
+  const int rows_per_block = 512;
+  const dim3 grid((N + 63) / 64, (R + rows_per_block - 1) / rows_per_block);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (is_f32) hipLaunchKernelGGL(gt_colsum_kernel<true>,  grid, dim3(256), 0, st, Y, ldy, out, R, N, rows_per_block);
+  else        hipLaunchKernelGGL(gt_colsum_kernel<false>, grid, dim3(256), 0, st, Y, ldy, out, R, N, rows_per_block);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}

@@ -1,0 +1,380 @@
+// HBM-bound pieces of the flow decoder for gfx950, in the rows layout (see glowtts_hip.h):
+//   squeeze / unsqueeze          commons.py:339-364  (+ layout change [B,C,T] <-> rows)
+//   ActNorm + InvConvNear fused  modules.py:584-599, 635-665 (forward, backward, log-dets)
+//   affine coupling              attentions.py:174-186      (forward, backward)
+//   WaveNet gate backward        commons.py:61-68 (autograd of tanh*sigmoid, dropout replay)
+// All fp32 math; bf16 only where a tensor feeds an MFMA GEMM.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int HALO = GT_HALO;
+
+// ------------------------------------------------------------------ squeeze: [B,C,Ty] -> rows [R,2C]
+// rows[b*Tp + HALO + t', p*C + c] = y[b, c, 2t'+p] * (t' < len[b]);  halo / padded rows = 0.
+__global__ __launch_bounds__(256) void gt_squeeze_rows_kernel(const float* __restrict__ y, float* __restrict__ rows,
+                                                              const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp)
+{
+  __shared__ float tile[32][2 * 80 + 1];          // [t'][p*C+c], C <= 80
+  const int b = blockIdx.y, tp0 = blockIdx.x * 32;                 // tp0 indexes rows of the utterance (incl. halo)
+  const int len = len_sq[b], T2 = Tp - 2 * HALO;
+  // load: for each channel, 64 consecutive frames (= 32 squeezed frames x 2 phases)
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int c = i >> 6, f = i & 63;
+    const int tq = tp0 - HALO + (f >> 1), p = f & 1;               // squeezed frame, phase
+    float v = 0.f;
+    if (tq >= 0 && tq < len && tq < T2 && 2 * tq + p < Ty) v = y[((size_t)b * C + c) * Ty + 2 * tq + p];
+    tile[f >> 1][p * C + c] = v;
+  }
+  __syncthreads();
+  const int C2 = 2 * C;
+  for (int i = threadIdx.x; i < 32 * C2; i += 256) {
+    const int rr = i / C2, ch = i - rr * C2;
+    if (tp0 + rr < Tp) rows[((size_t)b * Tp + tp0 + rr) * C2 + ch] = tile[rr][ch];
+  }
+}
+
+// unsqueeze: rows [R,2C] -> [B,C,Ty] with y[b,c,2t'+p] = rows[...]*mask; frames >= 2*len (and a
+// trailing odd frame) are written as 0.  Also the backward of squeeze (and vice versa).
+__global__ __launch_bounds__(256) void gt_unsqueeze_rows_kernel(const float* __restrict__ rows, float* __restrict__ y,
+                                                                const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp)
+{
+  __shared__ float tile[32][2 * 80 + 1];
+  const int b = blockIdx.y, t0 = blockIdx.x * 32;                  // squeezed frame base (no halo offset)
+  const int len = len_sq[b], C2 = 2 * C, T2 = Tp - 2 * HALO;
+  for (int i = threadIdx.x; i < 32 * C2; i += 256) {
+    const int rr = i / C2, ch = i - rr * C2;
+    const int tq = t0 + rr;
+    tile[rr][ch] = (tq < len && tq < T2) ? rows[((size_t)b * Tp + HALO + tq) * C2 + ch] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int c = i >> 6, f = i & 63;
+    const int t = 2 * t0 + f;
+    if (t < Ty) y[((size_t)b * C + c) * Ty + t] = tile[f >> 1][(f & 1) * C + c];
+  }
+}
+
+// ------------------------------------------------------------------ ActNorm + InvConvNear
+// scal[0] = sum(logs), scal[1] = log det W (4x4), scal[2..17] = W^{-T} (row major).
+__global__ void gt_flow_scalars_kernel(const float* __restrict__ logs, int C, const float* __restrict__ W, float* __restrict__ scal)
+{
+  float s = 0.f;
+  for (int i = threadIdx.x; i < C; i += 64) s += logs[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    scal[0] = s;
+    double m[4][4], inv[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { m[i][j] = W[i * 4 + j]; inv[i][j] = (i == j); }
+    double det = 1.0;
+    for (int c = 0; c < 4; ++c) {                                  // Gauss-Jordan with partial pivoting
+      int piv = c; double best = fabs(m[c][c]);
+      for (int r = c + 1; r < 4; ++r) if (fabs(m[r][c]) > best) { best = fabs(m[r][c]); piv = r; }
+      if (piv != c) { for (int j = 0; j < 4; ++j) { double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t;
+                                                     t = inv[c][j]; inv[c][j] = inv[piv][j]; inv[piv][j] = t; } det = -det; }
+      const double d = m[c][c]; det *= d;
+      for (int j = 0; j < 4; ++j) { m[c][j] /= d; inv[c][j] /= d; }
+      for (int r = 0; r < 4; ++r) if (r != c) { const double f = m[r][c];
+        for (int j = 0; j < 4; ++j) { m[r][j] -= f * m[c][j]; inv[r][j] -= f * inv[c][j]; } }
+    }
+    scal[1] = (float)log(det);                                      // torch.logdet: nan if det < 0
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) scal[2 + i * 4 + j] = (float)inv[j][i];   // W^{-T}
+  }
+}
+
+// thread = (row, group g): members {2g, 2g+1, C/2+2g, C/2+2g+1}.
+__global__ __launch_bounds__(256) void gt_actnorm_invconv_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ y0_bf16, int ld0,
+    const float* __restrict__ logs, const float* __restrict__ bias, const float* __restrict__ W,
+    const float* __restrict__ rowmask, int R, int C)
+{
+  const int G = C >> 2, half = C >> 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * G) return;
+  const int m = idx / G, g = idx - m * G;
+  const float rm = rowmask[m];
+  const float2 xa = *reinterpret_cast<const float2*>(x + (size_t)m * C + 2 * g);
+  const float2 xb = *reinterpret_cast<const float2*>(x + (size_t)m * C + half + 2 * g);
+  const float a0 = bias[2 * g] + __expf(logs[2 * g]) * xa.x, a1 = bias[2 * g + 1] + __expf(logs[2 * g + 1]) * xa.y;
+  const float a2 = bias[half + 2 * g] + __expf(logs[half + 2 * g]) * xb.x, a3 = bias[half + 2 * g + 1] + __expf(logs[half + 2 * g + 1]) * xb.y;
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (W[k * 4] * a0 + W[k * 4 + 1] * a1 + W[k * 4 + 2] * a2 + W[k * 4 + 3] * a3) * rm;
+  *reinterpret_cast<float2*>(y + (size_t)m * C + 2 * g) = make_float2(o[0], o[1]);
+  *reinterpret_cast<float2*>(y + (size_t)m * C + half + 2 * g) = make_float2(o[2], o[3]);
+  if (y0_bf16) *reinterpret_cast<uint32_t*>(y0_bf16 + (size_t)m * ld0 + 2 * g) = pack2bf(o[0], o[1]);
+}
+
+// backward: dx = exp(logs) * W^T (dy*mask);  reductions into dlogs[C], dbias[C], dW[16] by atomics.
+__global__ __launch_bounds__(256) void gt_actnorm_invconv_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+    const float* __restrict__ logs, const float* __restrict__ bias, const float* __restrict__ W,
+    const float* __restrict__ rowmask, float* __restrict__ dlogs, float* __restrict__ dbias, float* __restrict__ dW,
+    int R, int C, int rows_per_block)
+{
+  // block: 256 threads = 4 row phases x 64 "group lanes" (G = C/4 <= 64); loops over its row slab
+  __shared__ float sW[4][16];
+  const int G = C >> 2, half = C >> 1;
+  const int g = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(R, m0 + rows_per_block);
+  float accW[16], accL[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accW[i] = 0.f;
+  if (g < G) {
+    const int ch[4] = {2 * g, 2 * g + 1, half + 2 * g, half + 2 * g + 1};
+    float el[4], bs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { el[k] = __expf(logs[ch[k]]); bs[k] = bias[ch[k]]; }
+    for (int m = m0 + ph; m < m1; m += 4) {
+      const float rm = rowmask[m];
+      const float2 xa = *reinterpret_cast<const float2*>(x + (size_t)m * C + 2 * g);
+      const float2 xb = *reinterpret_cast<const float2*>(x + (size_t)m * C + half + 2 * g);
+      const float2 da = *reinterpret_cast<const float2*>(dy + (size_t)m * C + 2 * g);
+      const float2 db = *reinterpret_cast<const float2*>(dy + (size_t)m * C + half + 2 * g);
+      const float xv[4] = {xa.x, xa.y, xb.x, xb.y};
+      const float dym[4] = {da.x * rm, da.y * rm, db.x * rm, db.y * rm};
+      float a[4], d_a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = bs[k] + el[k] * xv[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d_a[i] = W[i] * dym[0] + W[4 + i] * dym[1] + W[8 + i] * dym[2] + W[12 + i] * dym[3];
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accW[o * 4 + i] += dym[o] * a[i];
+      float dxv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { accB[k] += d_a[k]; accL[k] += d_a[k] * xv[k] * el[k]; dxv[k] = d_a[k] * el[k]; }
+      *reinterpret_cast<float2*>(dx + (size_t)m * C + 2 * g) = make_float2(dxv[0], dxv[1]);
+      *reinterpret_cast<float2*>(dx + (size_t)m * C + half + 2 * g) = make_float2(dxv[2], dxv[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(dlogs + ch[k], accL[k]); atomicAdd(dbias + ch[k], accB[k]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accW[i] = wave_sum(accW[i]);
+  if (g == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sW[ph][i] = accW[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(dW + threadIdx.x, sW[0][threadIdx.x] + sW[1][threadIdx.x] + sW[2][threadIdx.x] + sW[3][threadIdx.x]);
+}
+
+// log-det bookkeeping: logdet[b] += (sum logs + G*logdet W) * len_b ; backward adds the matching
+// terms: dlogs[c] += s, dW += G * s * W^{-T} with s = sum_b dlogdet[b]*len_b.
+__global__ void gt_flow_logdet_kernel(const float* __restrict__ scal, const int32_t* __restrict__ len, float* __restrict__ logdet,
+                                      int B, int G)
+{
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b < B) logdet[b] += (scal[0] + (float)G * scal[1]) * (float)len[b];
+}
+__global__ void gt_flow_logdet_bwd_kernel(const float* __restrict__ scal, const int32_t* __restrict__ len,
+                                          const float* __restrict__ dlogdet, float* __restrict__ dlogs, float* __restrict__ dW,
+                                          int B, int C)
+{
+  float s = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) s += dlogdet[b] * (float)len[b];
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  for (int c = threadIdx.x; c < C; c += 256) dlogs[c] += s;
+  if (threadIdx.x < 16) dW[threadIdx.x] += (float)(C >> 2) * s * scal[2 + threadIdx.x];
+}
+
+// ------------------------------------------------------------------ affine coupling
+// out = [m | logs] ([R, C] fp32 from the `end` conv), x = [x0 | x1]:
+//   z = [x0 | (m + exp(logs) * x1) * mask],  logdet[b] += sum logs*mask.   One wave per row.
+__global__ __launch_bounds__(256) void gt_coupling_fwd_kernel(const float* __restrict__ out, const float* __restrict__ x,
+                                                              float* __restrict__ z, const float* __restrict__ rowmask,
+                                                              float* __restrict__ logdet, int R, int C, int Tp, int sigmoid_scale)
+{
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, half = C >> 1;
+  if (m >= R) return;
+  const float rm = rowmask[m];
+  float s = 0.f;
+  for (int c = lane; c < half; c += 64) {
+    const float mm = out[(size_t)m * C + c];
+    float lg = out[(size_t)m * C + half + c];
+    if (sigmoid_scale) lg = __logf(1e-6f + sigmoidf_(lg + 2.0f));
+    const float x1 = x[(size_t)m * C + half + c];
+    z[(size_t)m * C + c] = x[(size_t)m * C + c];
+    z[(size_t)m * C + half + c] = (mm + __expf(lg) * x1) * rm;
+    s += lg * rm;
+  }
+  s = wave_sum(s);
+  if (lane == 0 && rm != 0.f) atomicAdd(logdet + m / Tp, s);
+}
+
+// backward: dz -> dx (x0 part passed through, the start-conv contribution is added later),
+// d_out = [d_m | d_logs] in bf16 for the dgrad/wgrad GEMMs.
+__global__ __launch_bounds__(256) void gt_coupling_bwd_kernel(const float* __restrict__ out, const float* __restrict__ x,
+                                                              const float* __restrict__ dz, const float* __restrict__ dlogdet,
+                                                              const float* __restrict__ rowmask, float* __restrict__ dx,
+                                                              bf16_t* __restrict__ dout_bf16, int R, int C, int Tp, int sigmoid_scale)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x, half = C >> 1;
+  if (idx >= R * half) return;
+  const int m = idx / half, c = idx - m * half;
+  const float rm = rowmask[m];
+  const float lraw = out[(size_t)m * C + half + c];
+  float lg = lraw, dl_draw = 1.0f;
+  if (sigmoid_scale) { const float sg = sigmoidf_(lraw + 2.0f); lg = __logf(1e-6f + sg); dl_draw = sg * (1.0f - sg) / (1e-6f + sg); }
+  const float e = __expf(lg), x1 = x[(size_t)m * C + half + c];
+  const float dz1 = dz[(size_t)m * C + half + c] * rm;
+  const float d_m = dz1;
+  const float d_lg = (dz1 * e * x1 + dlogdet[m / Tp] * rm) * dl_draw;
+  dx[(size_t)m * C + c] = dz[(size_t)m * C + c];
+  dx[(size_t)m * C + half + c] = dz1 * e;
+  dout_bf16[(size_t)m * C + c] = f2bf(d_m);
+  dout_bf16[(size_t)m * C + half + c] = f2bf(d_lg);
+}
+
+// dx[:, :n] += add (bf16 rows, e.g. the start-conv data gradient) * mask
+__global__ __launch_bounds__(256) void gt_rows_add_bf16_kernel(float* __restrict__ dx, int ldx, const bf16_t* __restrict__ add, int lda,
+                                                               int R, int n)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * n) return;
+  const int m = idx / n, c = idx - m * n;
+  dx[(size_t)m * ldx + c] += bf2f(add[(size_t)m * lda + c]);
+}
+
+// ------------------------------------------------------------------ WaveNet gate backward
+// acts = T*S, T = tanh(pre_t), S = sigmoid(pre_s), pre = drop(conv) + cond:
+//   d_pre_t = d_acts * S * (1 - T^2),  d_pre_s = d_acts * T * S * (1 - S);  the conv-side gradient
+//   additionally carries the replayed dropout mask.  Output [R, 2*half] bf16, natural order.
+__global__ __launch_bounds__(256) void gt_gate_bwd_kernel(const bf16_t* __restrict__ dacts, int ldd, const bf16_t* __restrict__ T,
+                                                          const bf16_t* __restrict__ S, int ldts, bf16_t* __restrict__ dpre, int ldp,
+                                                          bf16_t* __restrict__ dpre_cond, int R, int half,
+                                                          uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x, q4 = half >> 2;
+  if (idx >= R * q4) return;
+  const int m = idx / q4, c = (idx - m * q4) * 4;
+  const uint2 dv = *reinterpret_cast<const uint2*>(dacts + (size_t)m * ldd + c);
+  const uint2 tv = *reinterpret_cast<const uint2*>(T + (size_t)m * ldts + c);
+  const uint2 sv = *reinterpret_cast<const uint2*>(S + (size_t)m * ldts + c);
+  const float d[4] = {bf2f(dv.x & 0xffff), bf2f(dv.x >> 16), bf2f(dv.y & 0xffff), bf2f(dv.y >> 16)};
+  const float t[4] = {bf2f(tv.x & 0xffff), bf2f(tv.x >> 16), bf2f(tv.y & 0xffff), bf2f(tv.y >> 16)};
+  const float s[4] = {bf2f(sv.x & 0xffff), bf2f(sv.x >> 16), bf2f(sv.y & 0xffff), bf2f(sv.y >> 16)};
+  float gt[4], gs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { gt[i] = d[i] * s[i] * (1.0f - t[i] * t[i]); gs[i] = d[i] * t[i] * s[i] * (1.0f - s[i]); }
+  if (dpre_cond) {
+    *reinterpret_cast<uint2*>(dpre_cond + (size_t)m * ldp + c) = make_uint2(pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3]));
+    *reinterpret_cast<uint2*>(dpre_cond + (size_t)m * ldp + half + c) = make_uint2(pack2bf(gs[0], gs[1]), pack2bf(gs[2], gs[3]));
+  }
+  if (drop_thresh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      gt[i] = drop_keep(drop_seed, m, c + i, drop_thresh) ? gt[i] * drop_scale : 0.0f;
+      gs[i] = drop_keep(drop_seed, m, half + c + i, drop_thresh) ? gs[i] * drop_scale : 0.0f;
+    }
+  }
+  *reinterpret_cast<uint2*>(dpre + (size_t)m * ldp + c) = make_uint2(pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3]));
+  *reinterpret_cast<uint2*>(dpre + (size_t)m * ldp + half + c) = make_uint2(pack2bf(gs[0], gs[1]), pack2bf(gs[2], gs[3]));
+}
+
+// generic: out_bf16[m, :n] = in_f32[m, :n] * (rowmask ? rowmask[m] : 1)
+__global__ __launch_bounds__(256) void gt_rows_f32_to_bf16_kernel(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo,
+                                                                  const float* __restrict__ rowmask, int R, int n)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * n) return;
+  const int m = idx / n, c = idx - m * n;
+  out[(size_t)m * ldo + c] = f2bf(in[(size_t)m * ldi + c] * (rowmask ? rowmask[m] : 1.0f));
+}
+
+}  // namespace
+
+#define GT_ST(s) static_cast<hipStream_t>(s)
+#define GT_RET() return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH
+
+extern "C" int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream)
+{
+  if (!y || !rows || !len_sq || B <= 0 || C <= 0 || C > 80 || Ty <= 0 || Tp <= 2 * HALO) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_squeeze_rows_kernel, dim3((Tp + 31) / 32, B), dim3(256), 0, GT_ST(stream), y, rows, len_sq, B, C, Ty, Tp);
+  GT_RET();
+}
+extern "C" int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream)
+{
+  if (!y || !rows || !len_sq || B <= 0 || C <= 0 || C > 80 || Ty <= 0 || Tp <= 2 * HALO) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_unsqueeze_rows_kernel, dim3((Ty / 2 + 1 + 31) / 32, B), dim3(256), 0, GT_ST(stream), rows, y, len_sq, B, C, Ty, Tp);
+  GT_RET();
+}
+extern "C" int gt_flow_scalars(const float* logs, int C, const float* W, float* scal, void* stream)
+{
+  if (!logs || !W || !scal || C <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_flow_scalars_kernel, dim3(1), dim3(64), 0, GT_ST(stream), logs, C, W, scal);
+  GT_RET();
+}
+extern "C" int gt_actnorm_invconv_fwd(const float* x, float* y, void* y0_bf16, int ld0, const float* logs, const float* bias,
+                                      const float* W, const float* scal, const float* rowmask, const int32_t* len,
+                                      float* logdet, int B, int R, int C, void* stream)
+{
+  if (!x || !y || !logs || !bias || !W || !rowmask || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
+  const int G = C >> 2;
+  hipLaunchKernelGGL(gt_actnorm_invconv_fwd_kernel, dim3((R * G + 255) / 256), dim3(256), 0, GT_ST(stream),
+                     x, y, static_cast<bf16_t*>(y0_bf16), ld0, logs, bias, W, rowmask, R, C);
+  if (logdet) {
+    if (!scal || !len) return GT_E_INVAL;
+    hipLaunchKernelGGL(gt_flow_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, GT_ST(stream), scal, len, logdet, B, G);
+  }
+  GT_RET();
+}
+extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx, const float* logs, const float* bias,
+                                      const float* W, const float* scal, const float* rowmask, const int32_t* len,
+                                      const float* dlogdet, float* dlogs, float* dbias, float* dW, int B, int R, int C, void* stream)
+{
+  if (!x || !dy || !dx || !logs || !bias || !W || !rowmask || !dlogs || !dbias || !dW || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
+  const int rows_per_block = 64;
+  hipLaunchKernelGGL(gt_actnorm_invconv_bwd_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(256), 0, GT_ST(stream),
+                     x, dy, dx, logs, bias, W, rowmask, dlogs, dbias, dW, R, C, rows_per_block);
+  if (dlogdet) {
+    if (!scal || !len) return GT_E_INVAL;
+    hipLaunchKernelGGL(gt_flow_logdet_bwd_kernel, dim3(1), dim3(256), 0, GT_ST(stream), scal, len, dlogdet, dlogs, dW, B, C);
+  }
+  GT_RET();
+}
+extern "C" int gt_coupling_fwd(const float* out, const float* x, float* z, const float* rowmask, float* logdet,
+                               int R, int C, int Tp, int sigmoid_scale, void* stream)
+{
+  if (!out || !x || !z || !rowmask || !logdet || R <= 0 || (C & 1)) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_coupling_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), out, x, z, rowmask, logdet, R, C, Tp, sigmoid_scale);
+  GT_RET();
+}
+extern "C" int gt_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const float* rowmask,
+                               float* dx, void* dout_bf16, int R, int C, int Tp, int sigmoid_scale, void* stream)
+{
+  if (!out || !x || !dz || !dlogdet || !rowmask || !dx || !dout_bf16 || R <= 0 || (C & 1)) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_coupling_bwd_kernel, dim3((R * (C / 2) + 255) / 256), dim3(256), 0, GT_ST(stream),
+                     out, x, dz, dlogdet, rowmask, dx, static_cast<bf16_t*>(dout_bf16), R, C, Tp, sigmoid_scale);
+  GT_RET();
+}
+extern "C" int gt_rows_add_bf16(float* dx, int ldx, const void* add, int lda, int R, int n, void* stream)
+{
+  if (!dx || !add || R <= 0 || n <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_add_bf16_kernel, dim3((R * n + 255) / 256), dim3(256), 0, GT_ST(stream), dx, ldx, static_cast<const bf16_t*>(add), lda, R, n);
+  GT_RET();
+}
+extern "C" int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void* S, int ldts, void* dpre, int ldp, void* dpre_cond,
+                           int R, int half, float drop_p, uint32_t drop_seed, void* stream)
+{
+  if (!dacts || !T || !S || !dpre || R <= 0 || (half & 3) || (ldd & 3) || (ldts & 3) || (ldp & 3)) return GT_E_INVAL;
+  uint32_t th = 0; float sc = 1.0f;
+  if (drop_p > 0.f) { th = (uint32_t)((double)drop_p * 4294967296.0); sc = 1.0f / (1.0f - drop_p); }
+  hipLaunchKernelGGL(gt_gate_bwd_kernel, dim3((R * (half / 4) + 255) / 256), dim3(256), 0, GT_ST(stream),
+                     static_cast<const bf16_t*>(dacts), ldd, static_cast<const bf16_t*>(T), static_cast<const bf16_t*>(S), ldts,
+                     static_cast<bf16_t*>(dpre), ldp, static_cast<bf16_t*>(dpre_cond), R, half, th, drop_seed, sc);
+  GT_RET();
+}
+extern "C" int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const float* rowmask, int R, int n, void* stream)
+{
+  if (!in || !out || R <= 0 || n <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_f32_to_bf16_kernel, dim3((R * n + 255) / 256), dim3(256), 0, GT_ST(stream), in, ldi, static_cast<bf16_t*>(out), ldo, rowmask, R, n);
+  GT_RET();
+}

@@ -1,0 +1,205 @@
+"""Forward/backward launch sequences of the flow decoder on the rows layout (host side of the
+HIP kernels).  Every function here only allocates buffers and calls the C-ABI; the hand-written
+backward mirrors what autograd derives for the reference modules:
+
+  actnorm_invconv_*   modules.ActNorm + modules.InvConvNear   (modules.py:584-599, 635-665)
+  wn_*                modules.WN                               (modules.py:144-171)
+  coupling_*          attentions.CouplingBlock                 (attentions.py:132-186)
+"""
+import torch
+
+from . import _lib
+from .ops import RowsCtx, conv_rows  # noqa: F401
+
+_SCRATCH = {}
+
+
+def _scratch(name, nbytes, device):
+    """Grow-only device scratch (wgrad partial slabs etc.), one per purpose and device."""
+    key = (name, str(device))
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    return buf
+
+
+def _st(dev):
+    return _lib.current_stream(dev)
+
+
+# ----------------------------------------------------------------------------- conv parameter grads
+def conv_param_grads(conv, x, dy, R, want_bias=True):
+    """Gradients of a ConvP/WNConvP module's parameters from its input rows x (bf16) and output
+    gradient rows dy (bf16): wgrad MFMA kernel -> slab partials -> weight-norm backward; bias by
+    column sums.  Returns {param: grad}."""
+    L = _lib.lib()
+    pc = conv.pc
+    dev = x.device
+    import ctypes
+    S = ctypes.c_int(0)
+    nbytes = L.gt_conv_wgrad_workspace_bytes(R, pc.Cin, pc.Cout, pc.taps, ctypes.byref(S))
+    ws = _scratch("wgrad", nbytes, dev)
+    _lib.check(L.gt_conv_wgrad_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(dy), dy.stride(0), R, pc.Cin, pc.Cout, pc.taps,
+                                    _lib.ptr(ws), nbytes, _st(dev)), "gt_conv_wgrad_bf16")
+    out = {}
+    v = conv.weight_v if conv.weight_norm else conv.weight
+    dv = torch.empty_like(v)
+    if conv.weight_norm:
+        dg = torch.empty_like(conv.weight_g)
+        _lib.check(L.gt_weightnorm_bwd(_lib.ptr(ws), R, _lib.ptr(v), _lib.ptr(conv.weight_g), _lib.ptr(pc.inv_norm),
+                                       _lib.ptr(dv), _lib.ptr(dg), pc.Cout, pc.Cin, pc.taps, 0, _st(dev)), "gt_weightnorm_bwd")
+        out[conv.weight_v] = dv
+        out[conv.weight_g] = dg
+    else:
+        _lib.check(L.gt_weightnorm_bwd(_lib.ptr(ws), R, _lib.ptr(v), None, None, _lib.ptr(dv), None,
+                                       pc.Cout, pc.Cin, pc.taps, 0, _st(dev)), "gt_weightnorm_bwd")
+        out[conv.weight] = dv
+    if want_bias and conv.bias is not None:
+        db = torch.zeros_like(conv.bias)
+        _lib.check(L.gt_colsum(_lib.ptr(dy), dy.stride(0), int(dy.dtype == torch.float32), _lib.ptr(db), R, pc.Cout, _st(dev)),
+                   "gt_colsum")
+        out[conv.bias] = db
+    return out
+
+
+# ----------------------------------------------------------------------------- ActNorm + InvConvNear
+def actnorm_invconv_fwd(rc, x, logs, bias, W, logdet, want_x0=True):
+    """x: [R,C] fp32 rows.  Returns y [R,C] fp32, x0 bf16 [R,C/2] (coupling start input), saved."""
+    L = _lib.lib()
+    dev = x.device
+    R, C = x.shape
+    y = torch.empty_like(x)
+    x0 = torch.empty(R, C // 2, dtype=torch.bfloat16, device=dev) if want_x0 else None
+    scal = torch.empty(18, dtype=torch.float32, device=dev)
+    lg = logs.detach().reshape(-1).contiguous()
+    bs = bias.detach().reshape(-1).contiguous()
+    Wc = W.detach().contiguous()
+    _lib.check(L.gt_flow_scalars(_lib.ptr(lg), C, _lib.ptr(Wc), _lib.ptr(scal), _st(dev)), "gt_flow_scalars")
+    _lib.check(L.gt_actnorm_invconv_fwd(_lib.ptr(x), _lib.ptr(y), _lib.ptr(x0), C // 2, _lib.ptr(lg), _lib.ptr(bs), _lib.ptr(Wc),
+                                        _lib.ptr(scal), _lib.ptr(rc.rowmask), _lib.ptr(rc.lengths), _lib.ptr(logdet),
+                                        rc.B, R, C, _st(dev)), "gt_actnorm_invconv_fwd")
+    return y, x0, (x, lg, bs, Wc, scal)
+
+
+def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
+    L = _lib.lib()
+    x, lg, bs, Wc, scal = saved
+    dev = x.device
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    dlogs = torch.zeros(C, dtype=torch.float32, device=dev)
+    dbias = torch.zeros(C, dtype=torch.float32, device=dev)
+    dW = torch.zeros(16, dtype=torch.float32, device=dev)
+    _lib.check(L.gt_actnorm_invconv_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(lg), _lib.ptr(bs), _lib.ptr(Wc),
+                                        _lib.ptr(scal), _lib.ptr(rc.rowmask), _lib.ptr(rc.lengths), _lib.ptr(dlogdet),
+                                        _lib.ptr(dlogs), _lib.ptr(dbias), _lib.ptr(dW), rc.B, R, C, _st(dev)),
+               "gt_actnorm_invconv_bwd")
+    return dx, {logs: dlogs.view_as(logs), bias: dbias.view_as(bias), W: dW.view_as(W)}
+
+
+# ----------------------------------------------------------------------------- WN
+def wn_fwd(rc, wn, h0, cond, train, seed):
+    """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None.
+    Returns out [R,H] bf16 (= skip sum * mask) and saved activations."""
+    R, H = h0.shape
+    dev = h0.device
+    n = wn.n_layers
+    p = wn.p_dropout if train else 0.0
+    xs, ts, ss, acts_l = [h0], [], [], []
+    skip = torch.zeros(R, H, dtype=torch.float32, device=dev)
+    x = h0
+    for i in range(n):
+        ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
+        acts, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True,
+                               drop_p=p, seed=seed + i)
+        ts.append(t); ss.append(s); acts_l.append(acts)
+        rs = wn.res_skip_layers[i]
+        if i < n - 1:
+            # rows [0,H) of the weight -> residual, rows [H,2H) -> skip (modules.py:166-168)
+            xn = conv_rows(acts, rs.pc_res, rc, bias=rs.bias[:H], addend=x, mask=True)
+            conv_rows(acts, rs.pc_skip, rc, bias=rs.bias[H:], addend=skip, out=skip)
+            x = xn
+            xs.append(x)
+        else:
+            conv_rows(acts, rs.pc, rc, bias=rs.bias, addend=skip, out=skip)
+    out = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+    L = _lib.lib()
+    _lib.check(L.gt_rows_f32_to_bf16(_lib.ptr(skip), H, _lib.ptr(out), H, _lib.ptr(rc.rowmask), R, H, _st(dev)),
+               "gt_rows_f32_to_bf16")
+    return out, (xs, ts, ss, acts_l, p, seed)
+
+
+def wn_bwd(rc, wn, saved, drs, want_dcond=False):
+    """drs: [R,2H] bf16 work buffer whose columns [H,2H) hold the MASKED gradient of the wn output
+    (= d skip of every layer, since out = skip*mask); columns [0,H) are scratch.
+    Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond)."""
+    L = _lib.lib()
+    xs, ts, ss, acts_l, p, seed = saved
+    R, H = drs.shape[0], drs.shape[1] // 2
+    dev = drs.device
+    n = wn.n_layers
+    grads = {}
+    dskip = drs[:, H:]
+    dx_next = None          # gradient wrt x_{i+1} pre-mask (= drs[:, :H]) once available
+    dcond = None if not want_dcond else torch.zeros(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    for i in reversed(range(n)):
+        rs = wn.res_skip_layers[i]
+        acts = acts_l[i]
+        if i < n - 1:
+            dacts = conv_rows(drs, rs.pc, rc, dgrad=True)                      # [R,H] = d_rs @ W_rs
+            grads.update(conv_param_grads(rs, acts, drs, R))
+        else:
+            dacts = conv_rows(dskip, rs.pc, rc, dgrad=True)
+            grads.update(conv_param_grads(rs, acts, dskip, R))
+        dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
+        dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if (want_dcond and p > 0) else None
+        _lib.check(L.gt_gate_bwd(_lib.ptr(dacts), dacts.stride(0), _lib.ptr(ts[i]), _lib.ptr(ss[i]), ts[i].stride(0),
+                                 _lib.ptr(dpre), 2 * H, _lib.ptr(dpre_c), R, H, float(p), int(seed + i), _st(dev)), "gt_gate_bwd")
+        grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
+        if want_dcond:
+            src = dpre_c if dpre_c is not None else dpre
+            dcond[:, 2 * H * i:2 * H * (i + 1)] = src.float().reshape(rc.B, rc.Tp, 2 * H).sum(1)
+        # d x_i = dgrad(in_layer) + (residual path) ;  then through the mask of x_i's producer
+        if i > 0:
+            conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=(drs[:, :H] if i < n - 1 else None), mask=True,
+                      out=drs[:, :H])
+        else:
+            dh0 = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=(drs[:, :H] if n > 1 else None), mask=True)
+    return dh0, grads, dcond
+
+
+# ----------------------------------------------------------------------------- coupling block
+def coupling_fwd(rc, cb, x, x0_bf16, cond, logdet, train, seed):
+    """attentions.CouplingBlock.forward on rows.  x [R,C] fp32, x0_bf16 = bf16(x[:, :C/2])."""
+    L = _lib.lib()
+    dev = x.device
+    R, C = x.shape
+    h0 = conv_rows(x0_bf16, cb.start.pc, rc, bias=cb.start.bias, mask=True)
+    wn_out, wn_saved = wn_fwd(rc, cb.wn, h0, cond, train, seed)
+    out = conv_rows(wn_out, cb.end.pc, rc, bias=cb.end.bias, out_f32=True)      # [R,C] = [m | logs]
+    z = torch.empty_like(x)
+    _lib.check(L.gt_coupling_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(z), _lib.ptr(rc.rowmask), _lib.ptr(logdet),
+                                 R, C, rc.Tp, int(cb.sigmoid_scale), _st(dev)), "gt_coupling_fwd")
+    return z, (x, x0_bf16, h0, wn_out, wn_saved, out)
+
+
+def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
+    L = _lib.lib()
+    x, x0_bf16, h0, wn_out, wn_saved, out = saved
+    dev = x.device
+    R, C = x.shape
+    dx = torch.empty_like(x)
+    dout = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.gt_coupling_bwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dlogdet), _lib.ptr(rc.rowmask),
+                                 _lib.ptr(dx), _lib.ptr(dout), R, C, rc.Tp, int(cb.sigmoid_scale), _st(dev)), "gt_coupling_bwd")
+    grads = conv_param_grads(cb.end, wn_out, dout, R)
+    H = cb.hidden_channels
+    drs = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
+    conv_rows(dout, cb.end.pc, rc, dgrad=True, mask=True, out=drs[:, H:])         # d(wn out) * mask = d skip
+    dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, drs, want_dcond)
+    grads.update(g2)
+    grads.update(conv_param_grads(cb.start, x0_bf16, dh0, R))                    # dh0 is already masked
+    dx0 = conv_rows(dh0, cb.start.pc, rc, dgrad=True)
+    _lib.check(L.gt_rows_add_bf16(_lib.ptr(dx), C, _lib.ptr(dx0), dx0.stride(0), R, C // 2, _st(dev)), "gt_rows_add_bf16")
+    return dx, grads, dcond

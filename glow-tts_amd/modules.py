@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's modules.py for the hot path (same class names, constructor
+arguments and state_dict keys), with the arithmetic in HIP kernels behind the C-ABI.
+
+  ActNorm        reference modules.py:575-619
+  InvConvNear    reference modules.py:622-668
+  WN             reference modules.py:105-179
+  LayerNorm      reference modules.py:26-44
+Parameters are ordinary nn.Parameters (fp32 masters) owned by PyTorch; kernels borrow pointers.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, flow_impl
+from .ops import PackedConv, RowsCtx
+
+
+class ConvP(nn.Module):
+    """Parameters of a plain nn.Conv1d (state_dict keys `weight`, `bias`) + packed bf16 images."""
+    weight_norm = False
+
+    def __init__(self, in_channels, out_channels, kernel_size, gate=False, zero_init=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.gate = in_channels, out_channels, kernel_size, gate
+        w = torch.empty(out_channels, in_channels, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))                 # nn.Conv1d default init
+        bound = 1 / math.sqrt(in_channels * kernel_size)
+        b = torch.empty(out_channels).uniform_(-bound, bound)
+        if zero_init:
+            w.zero_(); b.zero_()
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(b)
+        self._pc = None
+
+    @property
+    def pc(self):
+        if self._pc is None:
+            raise RuntimeError("conv weights not packed: call prepare() first")
+        return self._pc
+
+    def _new_pc(self, Cout=None):
+        return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device)
+
+    def prepare(self):
+        """(Re)pack the current weights for the MFMA kernels — once per optimizer step."""
+        if self._pc is None or self._pc.fwd.device != self.weight.device:
+            self._pc = self._new_pc()
+        self._pc.pack(self.weight, None)
+        return self
+
+
+class WNConvP(ConvP):
+    """Parameters of torch.nn.utils.weight_norm(nn.Conv1d): `weight_g` [Cout,1,1], `weight_v`, `bias`."""
+    weight_norm = True
+
+    def __init__(self, in_channels, out_channels, kernel_size, gate=False, split_res_skip=False):
+        super().__init__(in_channels, out_channels, kernel_size, gate)
+        v = self.weight.data
+        del self.weight
+        self.weight_g = nn.Parameter(v.reshape(out_channels, -1).norm(dim=1).reshape(out_channels, 1, 1).clone())
+        self.weight_v = nn.Parameter(v.clone())
+        self.split_res_skip = split_res_skip
+        self.pc_res = self.pc_skip = None
+
+    def prepare(self):
+        dev = self.weight_v.device
+        if self._pc is None or self._pc.fwd.device != dev:
+            self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev)
+            if self.split_res_skip:
+                h = self.out_channels // 2
+                self.pc_res = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
+                self.pc_skip = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
+        self._pc.pack(self.weight_v, self.weight_g)
+        if self.split_res_skip:
+            h = self.out_channels // 2
+            self.pc_res.pack(self.weight_v[:h], self.weight_g[:h])
+            self.pc_skip.pack(self.weight_v[h:], self.weight_g[h:])
+        return self
+
+
+def prepare_all(module):
+    for m in module.modules():
+        if isinstance(m, ConvP):
+            m.prepare()
+
+
+class _RowsFn(torch.autograd.Function):
+    """Generic bridge: runner.forward(*tensors) -> (outputs, saved); runner.backward(saved, *grads)
+    -> grads aligned with the tensor inputs."""
+
+    @staticmethod
+    def forward(ctx, runner, n_out, *tensors):
+        outs, saved = runner.forward(*tensors)
+        ctx.runner, ctx.saved, ctx.n_in = runner, saved, len(tensors)
+        ctx.mark_non_differentiable(*[o for o in outs[n_out:]])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gin = ctx.runner.backward(ctx.saved, *grads)
+        assert len(gin) == ctx.n_in
+        return (None, None) + tuple(gin)
+
+
+def _mask_lengths(x_mask):
+    return x_mask.sum([1, 2]).to(torch.int32)
+
+
+class LayerNorm(nn.Module):
+    """reference modules.LayerNorm (modules.py:26-44): over the channel dim, eps 1e-4."""
+
+    def __init__(self, channels, eps=1e-4):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self.gamma = nn.Parameter(torch.ones(channels))
+        self.beta = nn.Parameter(torch.zeros(channels))
+
+
+class ActNorm(nn.Module):
+    """reference modules.ActNorm (modules.py:575-619)."""
+
+    def __init__(self, channels, ddi=False, **kwargs):
+        super().__init__()
+        self.channels = channels
+        self.initialized = not ddi
+        self.logs = nn.Parameter(torch.zeros(1, channels, 1))
+        self.bias = nn.Parameter(torch.zeros(1, channels, 1))
+
+    def store_inverse(self):
+        pass
+
+    def set_ddi(self, ddi):
+        self.initialized = not ddi
+
+
+class InvConvNear(nn.Module):
+    """reference modules.InvConvNear (modules.py:622-668): QR-orthogonal init with det > 0."""
+
+    def __init__(self, channels, n_split=4, no_jacobian=False, **kwargs):
+        super().__init__()
+        assert n_split == 4, "the fused kernel implements n_split=4 (every reference config)"
+        self.channels, self.n_split, self.no_jacobian = channels, n_split, no_jacobian
+        w_init = torch.linalg.qr(torch.FloatTensor(n_split, n_split).normal_())[0]
+        if torch.det(w_init) < 0:
+            w_init[:, 0] = -1 * w_init[:, 0]
+        self.weight = nn.Parameter(w_init)
+
+    def store_inverse(self):
+        self.weight_inv = torch.inverse(self.weight.float()).to(dtype=self.weight.dtype)
+
+
+class WN(nn.Module):
+    """reference modules.WN (modules.py:105-179): gated conv stack, all convs weight-normed."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0):
+        super().__init__()
+        assert kernel_size % 2 == 1 and hidden_channels % 2 == 0
+        assert dilation_rate == 1, "dilation_rate is 1 in every reference config (configs/*.json); kernels assume it"
+        self.in_channels, self.hidden_channels = in_channels, hidden_channels
+        self.kernel_size, self.dilation_rate, self.n_layers = kernel_size, dilation_rate, n_layers
+        self.gin_channels, self.p_dropout = gin_channels, p_dropout
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        if gin_channels != 0:
+            self.cond_layer = WNConvP(gin_channels, 2 * hidden_channels * n_layers, 1)
+        for i in range(n_layers):
+            self.in_layers.append(WNConvP(hidden_channels, 2 * hidden_channels, kernel_size, gate=True))
+            last = i == n_layers - 1
+            self.res_skip_layers.append(WNConvP(hidden_channels, hidden_channels if last else 2 * hidden_channels, 1,
+                                                split_res_skip=not last))

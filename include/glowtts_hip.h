@@ -124,6 +124,58 @@ int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* p
                          float* inv_norm, int Cout, int Cin, int taps,
                          int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
 
+/* Weight gradient of the rows-layout convolution: partial sums over S row slabs into
+ * workspace [S][taps][Cout][Cin] fp32 (S from gt_conv_wgrad_workspace_bytes), bf16 MFMA with
+ * transposing LDS reads.  dW[tap][co][ci] = sum_m dY[m,co] * X[m + tap - k/2, ci].
+ * (ATen conv backward-weight in the reference, reached through autograd.) */
+size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int taps, int* slabs_out);
+int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, int Cin, int Cout,
+                       int taps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Reduce the wgrad workspace and map it onto the parameter gradient(s) in the parameter's own
+ * [Cout, Cin, taps] layout: plain conv (g == NULL): dv (+)= dW; weight-normed conv
+ * (torch weight_norm dim 0): dg = <dW,v>/||v||, dv = g/||v|| (dW - v <dW,v>/||v||^2). */
+int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
+                      float* dv, float* dg, int Cout, int Cin, int taps, int accumulate, void* stream);
+
+/* out[n] += sum_m Y[m,n]  (bias gradients); Y bf16 (is_f32 == 0) or fp32 rows. */
+int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void* stream);
+
+/* commons.squeeze / unsqueeze (commons.py:339-364) fused with the [B,C,T] <-> rows layout change.
+ * len_sq[b] = valid squeezed frames; Tp = Ty/2 + 2*GT_HALO; C <= 80.  Each is the other's backward. */
+int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream);
+int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream);
+
+/* ActNorm (modules.py:584-599) + InvConvNear (modules.py:635-665) fused, rows layout fp32 [R,C]:
+ *   y = (W_4x4 applied per group {2g,2g+1,C/2+2g,C/2+2g+1} to (bias + exp(logs)*x)) * mask
+ *   logdet[b] += (sum(logs) + (C/4)*logdet(W)) * len[b]          (when logdet != NULL)
+ * gt_flow_scalars precomputes scal[18] = {sum logs, logdet W, W^-T}.  y0_bf16 (optional) receives
+ * a bf16 copy of the first C/2 channels (the coupling's start-conv input). */
+int gt_flow_scalars(const float* logs, int C, const float* W, float* scal, void* stream);
+int gt_actnorm_invconv_fwd(const float* x, float* y, void* y0_bf16, int ld0, const float* logs, const float* bias,
+                           const float* W, const float* scal, const float* rowmask, const int32_t* len,
+                           float* logdet, int B, int R, int C, void* stream);
+/* dlogs/dbias/dW are ACCUMULATED into (zero them first). */
+int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx, const float* logs, const float* bias,
+                           const float* W, const float* scal, const float* rowmask, const int32_t* len,
+                           const float* dlogdet, float* dlogs, float* dbias, float* dW, int B, int R, int C, void* stream);
+
+/* Affine coupling (attentions.py:174-186): out = [m|logs] fp32 rows from the `end` conv.
+ *   z = [x0 | (m + exp(logs)*x1)*mask],  logdet[b] += sum(logs*mask). */
+int gt_coupling_fwd(const float* out, const float* x, float* z, const float* rowmask, float* logdet,
+                    int R, int C, int Tp, int sigmoid_scale, void* stream);
+int gt_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const float* rowmask,
+                    float* dx, void* dout_bf16, int R, int C, int Tp, int sigmoid_scale, void* stream);
+
+/* WaveNet gate backward (commons.py:61-68): dpre [R,2*half] bf16 from d(acts), saved T and S;
+ * dpre carries the replayed dropout mask, dpre_cond (optional) does not. */
+int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void* S, int ldts, void* dpre, int ldp, void* dpre_cond,
+                int R, int half, float drop_p, uint32_t drop_seed, void* stream);
+
+/* small row helpers */
+int gt_rows_add_bf16(float* dx, int ldx, const void* add, int lda, int R, int n, void* stream);
+int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const float* rowmask, int R, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,168 @@
+"""GPU parity tests: flow-decoder HIP path (through the C-ABI, glow_tts_amd modules) vs the float
+oracle (oracle/glowtts_ref.py, CPU fp32, pinned to the reference by tests/golden/float_golden.npz).
+
+Tolerances (stated, north_star "stated fp tolerance"): GEMMs run in bf16 with fp32 accumulation and
+bf16 hidden activations, so z / gradients are compared at 3e-2 of the tensor's max-abs (observed
+~5e-3); log-dets at 2e-3 * valid frames; the fp32-only kernels (ActNorm/InvConvNear) at 1e-4."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from fill import fill_module  # noqa: E402
+from oracle import glowtts_ref as R  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
+
+
+def lens_mask(lengths, T):
+    l = torch.tensor(lengths)
+    return (torch.arange(T)[None, :] < l[:, None]).unsqueeze(1).float()
+
+
+def cpu_state(mod, prefix=""):
+    return {prefix + k: v.detach().cpu().float() for k, v in mod.state_dict().items()}
+
+
+def test_wgrad_kernel_vs_torch(built):
+    from glow_tts_amd import _lib, ops, flow_impl
+    from glow_tts_amd.modules import ConvP, WNConvP
+    for (Cin, Cout, k, wn) in [(192, 384, 5, True), (192, 160, 1, False), (80, 192, 1, True), (192, 768, 3, False)]:
+        B, T = 3, 90
+        g = torch.Generator().manual_seed(Cin + k)
+        ctx = ops.RowsCtx(torch.tensor([90, 41, 7], dtype=torch.int32, device=dev()), T)
+        m = ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)
+        x = (torch.randn(B, Cin, T, generator=g).to(dev()) * m).to(torch.bfloat16)
+        dy = (torch.randn(B, Cout, T, generator=g).to(dev()) * m).to(torch.bfloat16)
+        conv = (WNConvP if wn else ConvP)(Cin, Cout, k).to(dev())
+        conv.prepare()
+        grads = flow_impl.conv_param_grads(conv, ctx.to_rows(x), ctx.to_rows(dy), ctx.R)
+        # torch reference on the same bf16-rounded operands
+        if wn:
+            v = conv.weight_v.detach().clone().requires_grad_(True); gg = conv.weight_g.detach().clone().requires_grad_(True)
+            w = gg * v / v.reshape(Cout, -1).norm(dim=1).reshape(Cout, 1, 1)
+        else:
+            v = conv.weight.detach().clone().requires_grad_(True); w = v
+        b = conv.bias.detach().clone().requires_grad_(True)
+        F.conv1d(x.float(), w, b, padding=k // 2).backward(dy.float())
+        if wn:
+            assert relerr(grads[conv.weight_v], v.grad) < 1e-2 and relerr(grads[conv.weight_g], gg.grad) < 1e-2
+        else:
+            assert relerr(grads[conv.weight], v.grad) < 1e-2
+        assert relerr(grads[conv.bias], b.grad) < 1e-3
+
+
+def test_actnorm_invconv_fwd_bwd(built):
+    from glow_tts_amd import ops, flow_impl
+    B, T, C = 2, 40, 160
+    g = torch.Generator().manual_seed(5)
+    lens = [40, 23]
+    rc = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev()), T)
+    m = lens_mask(lens, T)
+    x = torch.randn(B, C, T, generator=g) * m
+    logs = (torch.randn(1, C, 1, generator=g) * 0.2).requires_grad_(True)
+    bias = (torch.randn(1, C, 1, generator=g) * 0.2).requires_grad_(True)
+    W = (torch.eye(4) + 0.3 * torch.randn(4, 4, generator=g)).requires_grad_(True)
+    xx = x.clone().requires_grad_(True)
+    P = {"a.logs": logs, "a.bias": bias, "i.weight": W}
+    z1, ld1 = R.actnorm_fwd(P, "a.", xx, m)
+    z, ld2 = R.invconv_fwd(P, "i.", z1, m)
+    rz = torch.randn(z.shape, generator=g); rl = torch.randn(B, generator=g)
+    ((z * rz).sum() + ((ld1 + ld2) * rl).sum()).backward()
+    # HIP
+    d = dev()
+    logdet = torch.zeros(B, device=d)
+    xr = rc.to_rows(x.to(d))
+    y, x0, saved = flow_impl.actnorm_invconv_fwd(rc, xr, logs.detach().to(d), bias.detach().to(d), W.detach().to(d), logdet)
+    assert relerr(rc.from_rows(y).cpu(), z.detach()) < 1e-5
+    assert relerr(logdet.cpu(), (ld1 + ld2).detach()) < 1e-5
+    assert relerr(rc.from_rows(x0.float()).cpu(), z.detach()[:, :C // 2]) < 1e-2
+    lg, bs, Wd = logs.detach().to(d), bias.detach().to(d), W.detach().to(d)
+    dx, grads = flow_impl.actnorm_invconv_bwd(rc, saved, rc.to_rows(rz.to(d)), rl.to(d), lg, bs, Wd)
+    assert relerr(rc.from_rows(dx).cpu(), xx.grad) < 1e-4
+    assert relerr(grads[lg].cpu(), logs.grad) < 1e-4
+    assert relerr(grads[bs].cpu(), bias.grad) < 1e-4
+    assert relerr(grads[Wd].cpu(), W.grad) < 1e-4
+
+
+def _run_decoder_case(n_blocks, B, T, lens, seed, check_params):
+    from glow_tts_amd import models
+    torch.manual_seed(seed)
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, n_blocks, 4, p_dropout=0.05), "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    for v in P.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(seed)
+    m = lens_mask(lens, T)
+    y = torch.randn(B, 80, T, generator=g) * m
+    yy = y.clone().requires_grad_(True)
+    z, ld = R.decoder_fwd(P, "decoder.", yy, m, n_blocks=n_blocks)
+    rz = torch.randn(z.shape, generator=g) * m[:, :, :z.shape[2]]; rl = torch.randn(B, generator=g) * 0.1
+    ((z * rz).sum() + (ld * rl).sum()).backward()
+
+    dec = dec.to(dev())
+    yd = y.to(dev()).requires_grad_(True)
+    zd, ldd = dec(yd, m.to(dev()))
+    assert zd.shape == z.shape and ldd.shape == ld.shape
+    assert relerr(zd.detach().cpu(), z.detach()) < 3e-2, relerr(zd.detach().cpu(), z.detach())
+    nvalid = torch.tensor(lens, dtype=torch.float32) // 2 * 160
+    assert ((ldd.detach().cpu() - ld.detach()).abs() < 2e-3 * nvalid + 1e-2).all(), (ldd.cpu(), ld)
+    ((zd * rz.to(dev())).sum() + (ldd * rl.to(dev())).sum()).backward()
+    assert relerr(yd.grad.cpu(), yy.grad) < 3e-2, relerr(yd.grad.cpu(), yy.grad)
+    if check_params:
+        worst = {}
+        for name, p in dec.named_parameters():
+            ref = P["decoder." + name].grad
+            assert p.grad is not None, name
+            e = relerr(p.grad.cpu(), ref)
+            worst[name] = e
+            assert e < 6e-2, (name, e)
+    return True
+
+
+def test_decoder_two_blocks_fwd_bwd(built):
+    _run_decoder_case(2, 2, 48, [48, 26], seed=3, check_params=True)
+
+
+def test_decoder_odd_length_and_ragged(built):
+    _run_decoder_case(1, 3, 51, [51, 20, 2], seed=4, check_params=False)
+
+
+def test_decoder_full_depth(built):
+    """12 blocks (configs/base.json n_blocks_dec) on a short batch: error does not blow up with depth."""
+    _run_decoder_case(12, 2, 64, [64, 30], seed=5, check_params=False)
+
+
+def test_coupling_block_dropin(built):
+    from glow_tts_amd import attentions
+    cb = fill_module(attentions.CouplingBlock(160, 192, 5, 1, 4, p_dropout=0.05), "cb.").eval()
+    P = cpu_state(cb, "cb.")
+    B, T = 2, 30
+    m = lens_mask([30, 11], T)
+    x = torch.randn(B, 160, T, generator=torch.Generator().manual_seed(8)) * m
+    z, ld = R.coupling_fwd(P, "cb.", x, m)
+    zd, ldd = cb.to(dev())(x.to(dev()), m.to(dev()))
+    assert relerr(zd.cpu(), z) < 3e-2 and (ldd.cpu() - ld).abs().max() < 0.5
+
+
+def test_decoder_train_mode_dropout_runs(built):
+    from glow_tts_amd import models
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05), "decoder.").to(dev()).train()
+    m = lens_mask([40, 40], 40).to(dev())
+    y = (torch.randn(2, 80, 40, device=dev()) * m).requires_grad_(True)
+    z1, ld1 = dec(y, m)
+    z2, ld2 = dec(y, m)
+    assert torch.isfinite(z1).all() and not torch.equal(z1, z2)        # different dropout masks per call
+    (z1.sum() + ld1.sum()).backward()
+    assert torch.isfinite(y.grad).all()

@@ -1,0 +1,141 @@
+"""CPU tests: the float oracle (oracle/glowtts_ref.py) against goldens produced by IMPORTING the
+reference modules (tests/golden/make_float_golden.py).  Weights are the closed-form fill of
+tests/golden/fill.py applied by parameter NAME, so these tests also pin the state_dict key/shape
+contract of the product's host modules (glow_tts_amd.models / attentions / modules)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from fill import closed_form, filled_state  # noqa: E402
+from oracle import glowtts_ref as R  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "float_golden.npz"))
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def close(a, b, tol=2e-5):
+    scale = max(1.0, float(b.abs().max()))
+    return torch.allclose(a, b, atol=tol * scale, rtol=tol)
+
+
+def module_state(mod, prefix):
+    return {prefix + k: closed_form(prefix + k, v.shape) for k, v in mod.state_dict().items()}
+
+
+def test_actnorm_invconv():
+    P = filled_state({"logs": (1, 160, 1), "bias": (1, 160, 1)}, "an.")
+    z, ld = R.actnorm_fwd(P, "an.", t("an_x"), t("an_mask"))
+    assert close(z, t("an_z")) and close(ld, t("an_logdet"))
+    P = filled_state({"weight": (4, 4)}, "ic.")
+    z, ld = R.invconv_fwd(P, "ic.", t("an_x"), t("an_mask"))
+    assert close(z, t("ic_z")) and close(ld, t("ic_logdet"))
+
+
+def test_wn_matches_reference_and_product_state_dict(built):
+    from glow_tts_amd import modules
+    P = module_state(modules.WN(160, 192, 5, 1, 4, 0, 0.05), "wn.")
+    assert close(R.wn_fwd(P, "wn.", t("wn_x"), t("an_mask")), t("wn_out"))
+    P = module_state(modules.WN(160, 192, 5, 1, 4, 8, 0.05), "wng.")
+    assert close(R.wn_fwd(P, "wng.", t("wn_x"), t("an_mask"), t("wng_g")), t("wng_out"))
+
+
+def test_coupling_fwd_bwd(built):
+    from glow_tts_amd import attentions
+    P = module_state(attentions.CouplingBlock(160, 192, 5, 1, 4, p_dropout=0.05), "cb.")
+    x = t("cb_x").clone().requires_grad_(True)
+    z, ld = R.coupling_fwd(P, "cb.", x, t("an_mask"))
+    assert close(z, t("cb_z")) and close(ld, t("cb_logdet"))
+    tot = (z * torch.randn(z.shape, generator=torch.Generator().manual_seed(1))).sum() + \
+          (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(2))).sum()
+    (gx,) = torch.autograd.grad(tot, [x])
+    assert close(gx, t("cb_gx"), 1e-4)
+
+
+def test_decoder_fwd_bwd(built):
+    from glow_tts_amd import models
+    P = module_state(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05), "decoder.")
+    y = t("dec_y").clone().requires_grad_(True)
+    z, ld = R.decoder_fwd(P, "decoder.", y, t("dec_mask"), n_blocks=2)
+    assert close(z, t("dec_z"), 1e-4) and close(ld, t("dec_logdet"), 1e-4)
+    tot = (z * torch.randn(z.shape, generator=torch.Generator().manual_seed(3))).sum() + \
+          (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(4))).sum()
+    (gy,) = torch.autograd.grad(tot, [y])
+    assert close(gy, t("dec_gy"), 2e-4)
+
+
+MHA_SHAPES = {"conv_q.weight": (192, 192, 1), "conv_q.bias": (192,), "conv_k.weight": (192, 192, 1), "conv_k.bias": (192,),
+              "conv_v.weight": (192, 192, 1), "conv_v.bias": (192,), "conv_o.weight": (192, 192, 1), "conv_o.bias": (192,),
+              "emb_rel_k": (1, 9, 96), "emb_rel_v": (1, 9, 96)}
+FFN_SHAPES = {"conv_1.weight": (768, 192, 3), "conv_1.bias": (768,), "conv_2.weight": (192, 768, 3), "conv_2.bias": (192,)}
+
+
+@pytest.mark.parametrize("T", [3, 5, 37])
+def test_mha_band_formulation(T):
+    """Both branches of attentions.py:292-305 (T < window+1 and T > window+1) equal the 9-diagonal band."""
+    P = filled_state(MHA_SHAPES, f"mha{T}.")
+    x = t(f"mha{T}_x").clone().requires_grad_(True)
+    xm = t(f"mha{T}_mask")
+    am = xm.unsqueeze(2) * xm.unsqueeze(-1)
+    o, p = R.mha_fwd(P, f"mha{T}.", x, x, am)
+    assert close(o, t(f"mha{T}_out")) and close(p, t(f"mha{T}_p"))
+    (gx,) = torch.autograd.grad((o * torch.randn(o.shape, generator=torch.Generator().manual_seed(5))).sum(), [x])
+    assert close(gx, t(f"mha{T}_gx"), 1e-4)
+
+
+def enc_shapes(n_layers):
+    s = {}
+    for i in range(n_layers):
+        s.update({f"attn_layers.{i}.{k}": v for k, v in MHA_SHAPES.items()})
+        s.update({f"ffn_layers.{i}.{k}": v for k, v in FFN_SHAPES.items()})
+        for nm in ("norm_layers_1", "norm_layers_2"):
+            s[f"{nm}.{i}.gamma"] = (192,); s[f"{nm}.{i}.beta"] = (192,)
+    return s
+
+
+PRE_SHAPES = {**{f"conv_layers.{i}.weight": (192, 192, 5) for i in range(3)}, **{f"conv_layers.{i}.bias": (192,) for i in range(3)},
+              **{f"norm_layers.{i}.gamma": (192,) for i in range(3)}, **{f"norm_layers.{i}.beta": (192,) for i in range(3)},
+              "proj.weight": (192, 192, 1), "proj.bias": (192,)}
+DP_SHAPES = {"conv_1.weight": (256, 192, 3), "conv_1.bias": (256,), "norm_1.gamma": (256,), "norm_1.beta": (256,),
+             "conv_2.weight": (256, 256, 3), "conv_2.bias": (256,), "norm_2.gamma": (256,), "norm_2.beta": (256,),
+             "proj.weight": (1, 256, 1), "proj.bias": (1,)}
+
+
+def test_encoder_pieces():
+    x, m = t("enc_x"), t("enc_mask")
+    assert close(R.ffn_fwd(filled_state(FFN_SHAPES, "ffn."), "ffn.", x, m), t("ffn_out"))
+    P = filled_state({"gamma": (192,), "beta": (192,)}, "ln.")
+    assert close(R.layer_norm_c(x, P["ln.gamma"], P["ln.beta"]), t("ln_out"))
+    assert close(R.conv_relu_norm_fwd(filled_state(PRE_SHAPES, "pre."), "pre.", x, m), t("crn_out"))
+    assert close(R.encoder_fwd(filled_state(enc_shapes(2), "enc."), "enc.", x, m, n_layers=2), t("encoder_out"), 1e-4)
+    assert close(R.duration_predictor_fwd(filled_state(DP_SHAPES, "dp."), "dp.", x, m), t("dp_out"), 1e-4)
+
+
+def test_text_encoder():
+    shapes = {"emb.weight": (148, 192), "proj_m.weight": (80, 192, 1), "proj_m.bias": (80,)}
+    shapes.update({"pre." + k: v for k, v in PRE_SHAPES.items()})
+    shapes.update({"encoder." + k: v for k, v in enc_shapes(2).items()})
+    shapes.update({"proj_w." + k: v for k, v in DP_SHAPES.items()})
+    P = filled_state(shapes, "encoder.")
+    x, xm_, xl, mask = R.text_encoder_fwd(P, "encoder.", torch.from_numpy(G["te_ids"]), torch.from_numpy(G["te_len"]), n_layers=2)
+    assert close(x, t("te_x"), 1e-4) and close(xm_, t("te_m"), 1e-4) and torch.equal(mask, t("te_mask"))
+
+
+def test_glue_logp_mas_mle(built):
+    from oracle import mas as omas
+    logp = R.logp_lattice(t("glue_xm"), torch.zeros_like(t("glue_xm")), t("glue_z"))
+    assert close(logp, t("glue_logp"), 1e-5)
+    xm, ym = t("enc_mask"), t("dec_mask")
+    amask = (xm.unsqueeze(-1) * ym.unsqueeze(2)).squeeze(1)
+    attn = torch.from_numpy(omas.oracle_maximum_path(t("glue_logp").numpy(), amask.numpy())).float()
+    assert torch.equal(attn, t("glue_attn"))
+    z_m = torch.matmul(attn.transpose(1, 2), t("glue_xm").transpose(1, 2)).transpose(1, 2)
+    assert close(z_m, t("glue_zm"))
+    mle = R.mle_loss(t("glue_z"), z_m, torch.zeros_like(z_m), torch.tensor([1.5, -0.5]), ym)
+    assert close(mle, t("glue_mle"))
