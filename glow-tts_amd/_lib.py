@@ -42,8 +42,26 @@ PROTOTYPES = {
                                 c_int, c_int, c_int, c_int, c_void_p]),
     "gt_gate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_relu_drop_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_rows_add_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_rows_f32_to_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "gt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p]),
+    "gt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "gt_logp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_prior_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_prior_expand_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_mle_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gt_mle_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gt_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -81,3 +81,136 @@ class _CouplingRunner:
         if self.has_cond:
             out.append(dcond)
         return out + [grads.get(p) for p in self.params]
+
+
+# ======================================================================================= text encoder
+from . import encoder_impl  # noqa: E402
+from .modules import LayerNorm  # noqa: E402
+
+
+class MultiHeadAttention(nn.Module):
+    """reference attentions.MultiHeadAttention (attentions.py:197-347), self-attention with the
+    windowed relative-position terms (heads_share=True as in every reference use)."""
+
+    def __init__(self, channels, out_channels, n_heads, window_size=None, heads_share=True, p_dropout=0.,
+                 block_length=None, proximal_bias=False, proximal_init=False):
+        super().__init__()
+        assert channels % n_heads == 0
+        assert window_size is not None and heads_share and block_length is None and not proximal_bias, \
+            "kernels implement the configuration every reference config uses (window_size=4, shared heads)"
+        self.channels, self.out_channels, self.n_heads, self.window_size = channels, out_channels, n_heads, window_size
+        self.heads_share, self.block_length, self.proximal_bias, self.p_dropout = heads_share, block_length, proximal_bias, p_dropout
+        self.attn = None
+        self.k_channels = channels // n_heads
+        self.conv_q = ConvP(channels, channels, 1)
+        self.conv_k = ConvP(channels, channels, 1)
+        self.conv_v = ConvP(channels, channels, 1)
+        rel_stddev = self.k_channels ** -0.5
+        self.emb_rel_k = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * rel_stddev)
+        self.emb_rel_v = nn.Parameter(torch.randn(1, window_size * 2 + 1, self.k_channels) * rel_stddev)
+        self.conv_o = ConvP(channels, out_channels, 1)
+        nn.init.xavier_uniform_(self.conv_q.weight)
+        nn.init.xavier_uniform_(self.conv_k.weight)
+        if proximal_init:
+            self.conv_k.weight.data.copy_(self.conv_q.weight.data)
+            self.conv_k.bias.data.copy_(self.conv_q.bias.data)
+        nn.init.xavier_uniform_(self.conv_v.weight)
+
+    def forward(self, x, c, attn_mask=None):
+        """x is c (self-attention); attn_mask [b,1,t,t] = x_mask ⊗ x_mask as attentions.py:61 builds it."""
+        assert x is c, "relative attention is only available for self-attention (attentions.py:250)"
+        prepare_all(self)
+        x_mask = attn_mask[:, :, :, 0].clone() if attn_mask is not None else torch.ones_like(x[:, :1])
+        x_mask = (attn_mask.amax(dim=3) > 0).to(x.dtype) if attn_mask is not None else x_mask
+        runner = _MHARunner(self, x_mask, self.training)
+        out, p = _RowsFn.apply(runner, 1, x, *runner.params)
+        self.attn = p
+        return out
+
+
+class _MHARunner:
+    def __init__(self, att, x_mask, train, seed=0):
+        self.att, self.x_mask, self.train, self.seed = att, x_mask, train, seed
+        self.params = list(att.parameters())
+
+    def forward(self, x, *_):
+        B, C, T = x.shape
+        rc = RowsCtx(_mask_lengths(self.x_mask), T)
+        xb = rc.to_rows(x.detach() * self.x_mask, torch.bfloat16)
+        y, saved = encoder_impl.mha_fwd(rc, self.att, xb, self.att.p_dropout if self.train else 0.0, self.seed)
+        return (rc.from_rows(y, torch.float32), saved[5]), (rc, saved)
+
+    def backward(self, saved_all, dy, _dp):
+        rc, saved = saved_all
+        grads = {}
+        dxb = encoder_impl.mha_bwd(rc, self.att, saved, rc.to_rows(dy, torch.bfloat16), grads)
+        return [rc.from_rows(dxb, torch.float32) * self.x_mask] + [grads.get(p) for p in self.params]
+
+
+class FFN(nn.Module):
+    """reference attentions.FFN (attentions.py:350-372), relu activation."""
+
+    def __init__(self, in_channels, out_channels, filter_channels, kernel_size, p_dropout=0., activation=None):
+        super().__init__()
+        assert activation is None, "the reference configs use relu"
+        self.in_channels, self.out_channels, self.filter_channels = in_channels, out_channels, filter_channels
+        self.kernel_size, self.p_dropout, self.activation = kernel_size, p_dropout, activation
+        self.conv_1 = ConvP(in_channels, filter_channels, kernel_size)
+        self.conv_2 = ConvP(filter_channels, out_channels, kernel_size)
+
+
+class Encoder(nn.Module):
+    """reference attentions.Encoder (attentions.py:12-86): post-LN transformer with conv FFN."""
+
+    def __init__(self, hidden_channels, filter_channels, n_heads, n_layers, kernel_size=1, p_dropout=0., window_size=None,
+                 block_length=None, gin_channels=0, emoin_channels=0, **kwargs):
+        super().__init__()
+        self.hidden_channels, self.filter_channels, self.n_heads, self.n_layers = hidden_channels, filter_channels, n_heads, n_layers
+        self.kernel_size, self.p_dropout, self.window_size, self.block_length, self.gin_channels = \
+            kernel_size, p_dropout, window_size, block_length, gin_channels
+        self.attn_layers = nn.ModuleList()
+        self.norm_layers_1 = nn.ModuleList()
+        self.ffn_layers = nn.ModuleList()
+        self.norm_layers_2 = nn.ModuleList()
+        for _ in range(n_layers):
+            self.attn_layers.append(MultiHeadAttention(hidden_channels, hidden_channels, n_heads, window_size=window_size,
+                                                       p_dropout=p_dropout, block_length=block_length))
+            self.norm_layers_1.append(LayerNorm(hidden_channels))
+            self.ffn_layers.append(FFN(hidden_channels, hidden_channels, filter_channels, kernel_size, p_dropout=p_dropout))
+            self.norm_layers_2.append(LayerNorm(hidden_channels))
+        if gin_channels != 0:
+            self.cond_g = nn.Linear(gin_channels, hidden_channels)
+
+    def forward(self, x, x_mask, g=None, emo=None):
+        if g is not None:
+            raise NotImplementedError("speaker conditioning inside the encoder (cfg 4/5) is out of the round-1 scope")
+        prepare_all(self)
+        runner = _EncoderRunner(self, x_mask, self.training)
+        (out,) = _RowsFn.apply(runner, 1, x, *runner.params)
+        return out
+
+
+class _EncoderRunner:
+    def __init__(self, enc, x_mask, train, seed=0):
+        self.enc, self.x_mask, self.train, self.seed = enc, x_mask, train, seed
+        self.params = list(enc.parameters())
+
+    def forward(self, x, *_):
+        B, C, T = x.shape
+        rc = RowsCtx(_mask_lengths(self.x_mask), T)
+        xm = x.detach().float() * self.x_mask
+        xr, xb = rc.to_rows(xm), rc.to_rows(xm, torch.bfloat16)
+        saved = []
+        for i in range(self.enc.n_layers):
+            xr, xb, s = encoder_impl.layer_fwd(rc, self.enc, i, xr, xb, self.train, self.seed + 8 * i)
+            saved.append(s)
+        return (rc.from_rows(xr),), (rc, saved)
+
+    def backward(self, saved_all, dout):
+        rc, saved = saved_all
+        grads = {}
+        dx, dxb = rc.to_rows(dout.float() * self.x_mask), None
+        for i in reversed(range(self.enc.n_layers)):
+            dx, dxb = encoder_impl.layer_bwd(rc, self.enc, i, saved[i], dx, dxb, grads)
+        tot = rc.from_rows(dx) + rc.from_rows(dxb, torch.float32)
+        return [tot * self.x_mask] + [grads.get(p) for p in self.params]

@@ -179,6 +179,10 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
           if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
           if (a.cond) { const float* cp = a.cond + (size_t)b * a.ldc + n; v[0] += cp[0]; v[1] += cp[1]; v[2] += cp[2]; v[3] += cp[3]; }
           if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          if (a.drop_thresh) {                                       // dropout after the activation (attentions.py:370)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = drop_keep(a.drop_seed, m, n + i, a.drop_thresh) ? v[i] * a.drop_scale : 0.0f;
+          }
           if (a.out_f32) {
             if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n);
                             v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w; }
@@ -261,7 +265,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   a.out_f32 = out_f32; a.relu = relu;
   a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f;
   if (drop_p > 0.0f) {
-    if (!gate || drop_p >= 1.0f) return GT_E_UNSUPPORTED;
+    if (drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p);
   }
   hipStream_t st = static_cast<hipStream_t>(stream);

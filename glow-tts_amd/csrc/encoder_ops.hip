@@ -1,0 +1,644 @@
+// Text-encoder / glue kernels for gfx950 in the rows layout (see glowtts_hip.h):
+//   channel LayerNorm (+residual, dropout, relu)   modules.py:26-44, attentions.py:79-84, modules.py:95-102
+//   relative-position multi-head attention          attentions.py:241-336 (9-diagonal band form, SURVEY App. A iii)
+//   embedding * sqrt(H)                             models.py:693
+//   logp lattice                                    models.py:1076-1082
+//   prior expansion (gather) + mle loss             models.py:1118-1119, commons.py:28-33
+// fp32 math throughout; bf16 only for tensors that feed MFMA GEMMs.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int HALO = GT_HALO;
+
+// ------------------------------------------------------------------ LayerNorm over channels
+// s = a + drop_in(y);  n = (s-mean)*rstd*gamma + beta;  o = drop_out(relu?(n));
+// out_f32 = o*mask, out_bf16 = o*mask.  One wave per row, C <= 256 (4 values per lane).
+struct LnArgs {
+  const float* a; const bf16_t* y; int ldy;
+  const float* gamma; const float* beta;
+  const float* rowmask;
+  float* out_f32; bf16_t* out_bf16; int ldo;
+  float* mean; float* rstd;
+  int R, C; float eps;
+  uint32_t din_thresh, din_seed; float din_scale;
+  uint32_t dout_thresh, dout_seed; float dout_scale;
+  int relu;
+};
+
+__global__ __launch_bounds__(256) void gt_layernorm_fwd_kernel(LnArgs p)
+{
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= p.R) return;
+  float s[4]; float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    float v = 0.f;
+    if (c < p.C) {
+      if (p.a) v = p.a[(size_t)m * p.C + c];
+      if (p.y) {
+        float yy = bf2f(p.y[(size_t)m * p.ldy + c]);
+        if (p.din_thresh) yy = drop_keep(p.din_seed, m, c, p.din_thresh) ? yy * p.din_scale : 0.f;
+        v += yy;
+      }
+      sum += v;
+    }
+    s[k] = v;
+  }
+  const float mean = wave_sum(sum) / (float)p.C;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const int c = lane + 64 * k; if (c < p.C) { const float d = s[k] - mean; var += d * d; } }
+  const float rstd = rsqrtf(wave_sum(var) / (float)p.C + p.eps);
+  if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+  const float rm = p.rowmask ? p.rowmask[m] : 1.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane + 64 * k;
+    if (c < p.C) {
+      float o = (s[k] - mean) * rstd * p.gamma[c] + p.beta[c];
+      if (p.relu) o = fmaxf(o, 0.f);
+      if (p.dout_thresh) o = drop_keep(p.dout_seed, m, c, p.dout_thresh) ? o * p.dout_scale : 0.f;
+      o *= rm;
+      if (p.out_f32) p.out_f32[(size_t)m * p.C + c] = o;
+      if (p.out_bf16) p.out_bf16[(size_t)m * p.ldo + c] = f2bf(o);
+    }
+  }
+}
+
+struct LnBwdArgs {
+  LnArgs f;                                    // forward description (inputs, mean/rstd, flags)
+  const float* dout_f32; const bf16_t* dout_bf16; int lddo;
+  float* da; bf16_t* dy; int lddy;             // gradients wrt a (fp32) and y (bf16, dropout replayed)
+  float* dgamma; float* dbeta;                 // accumulated (atomics)
+  int rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void gt_layernorm_bwd_kernel(LnBwdArgs q)
+{
+  const LnArgs& p = q.f;
+  __shared__ float sg[4][256], sb[4][256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float accg[4] = {0, 0, 0, 0}, accb[4] = {0, 0, 0, 0};
+  const int m0 = blockIdx.x * q.rows_per_block, m1 = min(p.R, m0 + q.rows_per_block);
+  for (int m = m0 + w; m < m1; m += 4) {
+    const float mean = p.mean[m], rstd = p.rstd[m];
+    const float rm = p.rowmask ? p.rowmask[m] : 1.0f;
+    float xh[4], dn[4]; bool keep_in[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane + 64 * k;
+      xh[k] = 0.f; dn[k] = 0.f; keep_in[k] = true;
+      if (c < p.C) {
+        float v = p.a ? p.a[(size_t)m * p.C + c] : 0.f;
+        if (p.y) {
+          float yy = bf2f(p.y[(size_t)m * p.ldy + c]);
+          if (p.din_thresh) { keep_in[k] = drop_keep(p.din_seed, m, c, p.din_thresh); yy = keep_in[k] ? yy * p.din_scale : 0.f; }
+          v += yy;
+        }
+        xh[k] = (v - mean) * rstd;
+        float d = 0.f;
+        if (q.dout_f32) d += q.dout_f32[(size_t)m * p.C + c];
+        if (q.dout_bf16) d += bf2f(q.dout_bf16[(size_t)m * q.lddo + c]);
+        d *= rm;
+        if (p.dout_thresh) d = drop_keep(p.dout_seed, m, c, p.dout_thresh) ? d * p.dout_scale : 0.f;
+        if (p.relu && (xh[k] * p.gamma[c] + p.beta[c]) <= 0.f) d = 0.f;
+        accg[k] += d * xh[k]; accb[k] += d;
+        dn[k] = d * p.gamma[c];
+        s1 += dn[k]; s2 += dn[k] * xh[k];
+      }
+    }
+    s1 = wave_sum(s1) / (float)p.C; s2 = wave_sum(s2) / (float)p.C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = lane + 64 * k;
+      if (c < p.C) {
+        const float ds = rstd * (dn[k] - s1 - xh[k] * s2);
+        if (q.da) q.da[(size_t)m * p.C + c] = ds;
+        if (q.dy) q.dy[(size_t)m * q.lddy + c] = f2bf(p.din_thresh ? (keep_in[k] ? ds * p.din_scale : 0.f) : ds);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sg[w][lane + 64 * k] = accg[k]; sb[w][lane + 64 * k] = accb[k]; }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < p.C) {
+    atomicAdd(q.dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    atomicAdd(q.dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+// ------------------------------------------------------------------ relative-position attention
+// q,k,v: rows [R, H*D] bf16 (head h = channels [h*D, (h+1)*D)), D <= 96, window w (2w+1 taps, shared
+// by heads).  One workgroup per (query tile of 16 rows, head, utterance); K and V of the
+// utterance-head staged in LDS as fp32-convertible bf16 with an odd dword pitch.
+//   score[i,j] = (q_i.k_j + [|j-i|<=w] q_i.Ek[j-i+w]) / sqrt(D);  key j >= len -> -1e4
+//   p = softmax_j(score);  pd = dropout(p);  out_i = sum_j pd[i,j] v_j + sum_{|j-i|<=w} pd[i,j] Ev[j-i+w]
+// P (pre-dropout, fp32) is saved to Pout [B,H,T,T] for the backward pass.
+constexpr int AT_QT = 16;
+constexpr int AT_MAXD = 96;
+
+__device__ __forceinline__ void at_stage(bf16_t* dst, const bf16_t* src, int ld, size_t rbase, int h, int T, int D, int KP, int tid)
+{
+  for (int i = tid; i < T * (D / 2); i += 256) {
+    const int j = i / (D / 2), c2 = i - j * (D / 2);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)j * KP + 2 * c2) = *reinterpret_cast<const uint32_t*>(src + (rbase + j) * ld + h * D + 2 * c2);
+  }
+}
+__device__ __forceinline__ float at_dot(const float* qv, const bf16_t* row, int D)
+{
+  float s = 0.f;
+  for (int c = 0; c < D; c += 2) {
+    const uint32_t kk = *reinterpret_cast<const uint32_t*>(row + c);
+    s += qv[c] * bf2f(kk & 0xffff) + qv[c + 1] * bf2f(kk >> 16);
+  }
+  return s;
+}
+
+// LDS: one [T][D+2] bf16 staging buffer (K then V), band tables, per-wave q row, [16][T] score rows.
+__global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
+    const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
+    bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
+    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int KP = D + 2, NW = 2 * win + 1;                // odd dword pitch
+  bf16_t* St = reinterpret_cast<bf16_t*>(smem);          // [T][KP]
+  float* Es = reinterpret_cast<float*>(St + (size_t)T * KP + (((size_t)T * KP) & 1));   // Ek [NW][D], Ev [NW][D]
+  float* Qs = Es + 2 * NW * D;                           // [4 waves][D]
+  float* Ps = Qs + 4 * D;                                // [AT_QT][T]
+  const int len = lens[b];
+  const size_t rbase = (size_t)b * Tp + HALO;
+  at_stage(St, k, ld, rbase, h, T, D, KP, tid);
+  for (int i = tid; i < NW * D; i += 256) { Es[i] = Ek[i]; Es[NW * D + i] = Ev[i]; }
+  __syncthreads();
+  const float inv_sqrt = rsqrtf((float)D);
+  float* qv = Qs + w * D;
+  for (int ii = w; ii < AT_QT; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T) break;                                   // wave-uniform
+    float* pv = Ps + (size_t)ii * T;
+    for (int c = lane; c < D; c += 64) qv[c] = bf2f(q[(rbase + i) * ld + h * D + c]);
+    __builtin_amdgcn_wave_barrier();
+    float mx = -3.0e38f;
+    for (int j = lane; j < T; j += 64) {
+      float s = at_dot(qv, St + (size_t)j * KP, D);
+      const int rel = j - i + win;
+      if (rel >= 0 && rel <= 2 * win) { const float* e = Es + rel * D; float t = 0.f; for (int c = 0; c < D; ++c) t += qv[c] * e[c]; s += t; }
+      s *= inv_sqrt;
+      if (j >= len || i >= len) s = -1e4f;                // masked_fill(mask == 0, -1e4), attentions.py:260
+      pv[j] = s; mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float den = 0.f;
+    for (int j = lane; j < T; j += 64) { const float e = __expf(pv[j] - mx); pv[j] = e; den += e; }
+    den = wave_sum(den);
+    const float rden = 1.0f / den;
+    float* prow = Pout + (((size_t)b * H + h) * T + i) * T;
+    for (int j = lane; j < T; j += 64) {
+      const float pj = pv[j] * rden;
+      prow[j] = pj;
+      float pd = pj;
+      if (drop_thresh) pd = drop_keep(drop_seed, (uint32_t)((b * H + h) * T + i), j, drop_thresh) ? pj * drop_scale : 0.f;
+      pv[j] = pd;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  at_stage(St, v, ld, rbase, h, T, D, KP, tid);
+  __syncthreads();
+  for (int ii = w; ii < AT_QT; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T) break;
+    const float* pv = Ps + (size_t)ii * T;
+    for (int c = lane; c < D; c += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < T; ++j) acc += pv[j] * bf2f(St[(size_t)j * KP + c]);
+      for (int rel = 0; rel <= 2 * win; ++rel) { const int j = i + rel - win; if (j >= 0 && j < T) acc += pv[j] * Es[NW * D + rel * D + c]; }
+      out[(rbase + i) * ldo + h * D + c] = f2bf(acc);
+    }
+  }
+}
+
+// backward, pass 1 (per query row): dS row -> dSout [B,H,T,T] fp32 (scaled by 1/sqrt(D)), dQ, dEk, dEv.
+__global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
+    const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
+    const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P, float* __restrict__ dS,
+    bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
+    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int KP = D + 2, NW = 2 * win + 1;
+  bf16_t* St = reinterpret_cast<bf16_t*>(smem);
+  float* Es = reinterpret_cast<float*>(St + (size_t)T * KP + (((size_t)T * KP) & 1));
+  float* Acc = Es + 2 * NW * D;                          // block-local dEk | dEv accumulators [2][NW][D]
+  float* Qs = Acc + 2 * NW * D;                          // [AT_QT][2*D]: q row and dO row
+  float* Ps = Qs + AT_QT * 2 * D;                        // [AT_QT][T]
+  const int len = lens[b];
+  const size_t rbase = (size_t)b * Tp + HALO;
+  at_stage(St, v, ld, rbase, h, T, D, KP, tid);
+  for (int i = tid; i < NW * D; i += 256) { Es[i] = Ek[i]; Es[NW * D + i] = Ev[i]; Acc[i] = 0.f; Acc[NW * D + i] = 0.f; }
+  __syncthreads();
+  const float inv_sqrt = rsqrtf((float)D);
+  for (int ii = w; ii < AT_QT; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T) break;
+    float* qv = Qs + ii * 2 * D; float* dov = qv + D;
+    float* pv = Ps + (size_t)ii * T;
+    for (int c = lane; c < D; c += 64) { qv[c] = bf2f(q[(rbase + i) * ld + h * D + c]); dov[c] = bf2f(dout[(rbase + i) * lddo + h * D + c]); }
+    __builtin_amdgcn_wave_barrier();
+    const float* prow = P + (((size_t)b * H + h) * T + i) * T;
+    // dPd_j = dO.V_j + [band] dO.Ev[rel];  dP_j = dropout'(dPd_j);  Dsum = sum_j dP_j P_j
+    float dsum = 0.f;
+    for (int j = lane; j < T; j += 64) {
+      float s = at_dot(dov, St + (size_t)j * KP, D);
+      const int rel = j - i + win;
+      if (rel >= 0 && rel <= 2 * win) { const float* e = Es + NW * D + rel * D; float t = 0.f; for (int c = 0; c < D; ++c) t += dov[c] * e[c]; s += t; }
+      if (drop_thresh) s = drop_keep(drop_seed, (uint32_t)((b * H + h) * T + i), j, drop_thresh) ? s * drop_scale : 0.f;
+      pv[j] = s;
+      dsum += s * prow[j];
+    }
+    dsum = wave_sum(dsum);
+    float* dsrow = dS + (((size_t)b * H + h) * T + i) * T;
+    for (int j = lane; j < T; j += 64) {
+      float ds = prow[j] * (pv[j] - dsum) * inv_sqrt;
+      if (j >= len || i >= len) ds = 0.f;                 // masked_fill blocks the gradient
+      pv[j] = ds; dsrow[j] = ds;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  at_stage(St, k, ld, rbase, h, T, D, KP, tid);
+  __syncthreads();
+  for (int ii = w; ii < AT_QT; ii += 4) {
+    const int i = i0 + ii;
+    if (i >= T) break;
+    const float* qv = Qs + ii * 2 * D; const float* dov = qv + D;
+    const float* pv = Ps + (size_t)ii * T;
+    const float* prow = P + (((size_t)b * H + h) * T + i) * T;
+    for (int c = lane; c < D; c += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < T; ++j) acc += pv[j] * bf2f(St[(size_t)j * KP + c]);
+      for (int rel = 0; rel <= 2 * win; ++rel) {
+        const int j = i + rel - win;
+        if (j >= 0 && j < T) {
+          acc += pv[j] * Es[rel * D + c];
+          if (pv[j] != 0.f) atomicAdd(Acc + rel * D + c, pv[j] * qv[c]);
+          float pd = prow[j];                              // dEv[rel] += dropout(P)[i,j] * dO_i
+          if (drop_thresh) pd = drop_keep(drop_seed, (uint32_t)((b * H + h) * T + i), j, drop_thresh) ? pd * drop_scale : 0.f;
+          if (pd != 0.f && i < len) atomicAdd(Acc + NW * D + rel * D + c, pd * dov[c]);
+        }
+      }
+      dq[(rbase + i) * lddq + h * D + c] = f2bf(acc);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < NW * D; i += 256) {
+    if (Acc[i] != 0.f) atomicAdd(dEk + i, Acc[i]);
+    if (Acc[NW * D + i] != 0.f) atomicAdd(dEv + i, Acc[NW * D + i]);
+  }
+}
+
+// backward, pass 2 (per key row j): dK_j = sum_i dS[i,j] q_i ;  dV_j = sum_i pd[i,j] dO_i.
+__global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
+    const bf16_t* __restrict__ q, int ld, const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
+    const float* __restrict__ dS, const int32_t* __restrict__ lens, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk,
+    int T, int Tp, int H, int D, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * AT_QT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int KP = D + 2;
+  bf16_t* St = reinterpret_cast<bf16_t*>(smem);          // [T][KP] q rows, then dO rows
+  float* Cs = reinterpret_cast<float*>(St + (size_t)T * KP + (((size_t)T * KP) & 1));   // [AT_QT][2*T] dS column | pd column
+  const size_t rbase = (size_t)b * Tp + HALO;
+  const int len = lens[b];
+  at_stage(St, q, ld, rbase, h, T, D, KP, tid);
+  for (int jj = w; jj < AT_QT; jj += 4) {
+    const int j = j0 + jj;
+    if (j >= T) break;
+    float* dsc = Cs + (size_t)jj * 2 * T; float* pdc = dsc + T;
+    for (int i = lane; i < T; i += 64) {
+      const size_t o = (((size_t)b * H + h) * T + i) * T + j;
+      dsc[i] = dS[o];
+      float pd = (i < len) ? P[o] : 0.f;                  // query rows >= len carry no upstream gradient
+      if (drop_thresh) pd = drop_keep(drop_seed, (uint32_t)((b * H + h) * T + i), j, drop_thresh) ? pd * drop_scale : 0.f;
+      pdc[i] = pd;
+    }
+  }
+  __syncthreads();
+  for (int jj = w; jj < AT_QT; jj += 4) {
+    const int j = j0 + jj;
+    if (j >= T) break;
+    const float* dsc = Cs + (size_t)jj * 2 * T;
+    for (int c = lane; c < D; c += 64) {
+      float ak = 0.f;
+      for (int i = 0; i < T; ++i) ak += dsc[i] * bf2f(St[(size_t)i * KP + c]);
+      dk[(rbase + j) * lddk + h * D + c] = f2bf(ak);
+    }
+  }
+  __syncthreads();
+  at_stage(St, dout, lddo, rbase, h, T, D, KP, tid);
+  __syncthreads();
+  for (int jj = w; jj < AT_QT; jj += 4) {
+    const int j = j0 + jj;
+    if (j >= T) break;
+    const float* pdc = Cs + (size_t)jj * 2 * T + T;
+    for (int c = lane; c < D; c += 64) {
+      float av = 0.f;
+      for (int i = 0; i < T; ++i) av += pdc[i] * bf2f(St[(size_t)i * KP + c]);
+      dv[(rbase + j) * lddk + h * D + c] = f2bf(av);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ embedding
+// rows[b*Tp+HALO+t, :] = emb[ids[b,t], :] * scale * (t < len[b]);  fp32 + bf16 copies; halos zero.
+__global__ __launch_bounds__(256) void gt_embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
+                                                               const int32_t* __restrict__ lens, float* __restrict__ out_f32,
+                                                               bf16_t* __restrict__ out_bf16, int B, int T, int Tp, int C, float scale)
+{
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= B * Tp) return;
+  const int b = m / Tp, t = m - b * Tp - HALO;
+  const bool valid = t >= 0 && t < T && t < lens[b];
+  const int64_t id = valid ? ids[(size_t)b * T + t] : 0;
+  for (int c = lane; c < C; c += 64) {
+    const float v = valid ? emb[(size_t)id * C + c] * scale : 0.f;
+    if (out_f32) out_f32[(size_t)m * C + c] = v;
+    if (out_bf16) out_bf16[(size_t)m * C + c] = f2bf(v);
+  }
+}
+__global__ __launch_bounds__(256) void gt_embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
+                                                               const int32_t* __restrict__ lens, float* __restrict__ demb,
+                                                               int B, int T, int Tp, int C, float scale)
+{
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= B * Tp) return;
+  const int b = m / Tp, t = m - b * Tp - HALO;
+  if (t < 0 || t >= T || t >= lens[b]) return;
+  const int64_t id = ids[(size_t)b * T + t];
+  for (int c = lane; c < C; c += 64) atomicAdd(demb + (size_t)id * C + c, dx[(size_t)m * C + c] * scale);
+}
+
+// ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
+// logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
+//               + sum_d -0.5 m_id^2 e^{-2 s_id}
+// x_m, x_logs: [B, C, T_x] fp32; z: [B, C, T_y] fp32.  exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): one wave
+// per 32x32 lattice tile, K = 2C interleaved as (e^{-2s}, -0.5 z^2) and (m e^{-2s}, z) pairs.
+__global__ __launch_bounds__(256) void gt_logp_kernel(const float* __restrict__ xm, const float* __restrict__ xlogs,
+                                                      const float* __restrict__ z, float* __restrict__ logp,
+                                                      int B, int C, int Tx, int Ty)
+{
+  const int b = blockIdx.z;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + w) * 32;
+  if (j0 >= Ty) return;
+  const int r = lane & 31, kh = lane >> 5;
+  const int i = i0 + r, j = j0 + r;
+  const float* xmb = xm + (size_t)b * C * Tx;
+  const float* xsb = xlogs ? xlogs + (size_t)b * C * Tx : nullptr;
+  const float* zb = z + (size_t)b * C * Ty;
+  f32x16_t acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float rowc = 0.f;                                       // logp1 + logp4 of row i (lanes kh==0 and kh==1 split d)
+  for (int d = 0; d < C; d += 2) {
+    const int dd = d + kh;                                // this lane's k index
+    float m = 0.f, s = 0.f, zz = 0.f;
+    if (i < Tx) { m = xmb[(size_t)dd * Tx + i]; if (xsb) s = xsb[(size_t)dd * Tx + i]; }
+    if (j < Ty) zz = zb[(size_t)dd * Ty + j];
+    const float e2 = xsb ? __expf(-2.0f * s) : 1.0f;
+    rowc += -0.9189385332046727f - s - 0.5f * m * m * e2;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e2, -0.5f * zz * zz, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m * e2, zz, acc, 0, 0, 0);
+  }
+  rowc += __shfl_xor(rowc, 32);                           // both k halves -> full sum over d, indexed by r = row i0+r
+  // C/D layout: col = lane&31 (= j), row = (e&3) + 8*(e>>2) + 4*kh (= i offset)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int ri = (e & 3) + 8 * (e >> 2) + 4 * kh;
+    const float rc = __shfl(rowc, ri);                    // lane ri holds row i0+ri's constant
+    if (i0 + ri < Tx && j < Ty) logp[((size_t)b * Tx + i0 + ri) * Ty + j] = acc[e] + rc;
+  }
+}
+
+// ------------------------------------------------------------------ prior expansion + mle loss
+// z_m[b,c,j] = x_m[b,c,tok[b,j]] (0 where tok < 0)  — models.py:1118 as a gather.
+__global__ __launch_bounds__(256) void gt_prior_expand_kernel(const float* __restrict__ xm, const int32_t* __restrict__ tok,
+                                                              float* __restrict__ zm, int B, int C, int Tx, int Ty)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * C * Ty) return;
+  const int j = idx % Ty, bc = idx / Ty, b = bc / C;
+  const int t = tok[(size_t)b * Ty + j];
+  zm[idx] = t >= 0 ? xm[(size_t)bc * Tx + t] : 0.f;
+}
+// backward of the gather: dxm[b,c,i] = sum_{j in [start_i, start_{i+1})} dzm[b,c,j]  (segments, no atomics)
+__global__ __launch_bounds__(256) void gt_prior_expand_bwd_kernel(const float* __restrict__ dzm, const int32_t* __restrict__ starts,
+                                                                  float* __restrict__ dxm, int B, int C, int Tx, int Ty, int Txs)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * C * Tx) return;
+  const int i = idx % Tx, bc = idx / Tx, b = bc / C;
+  const int s0 = starts[(size_t)b * (Txs + 1) + i], s1 = starts[(size_t)b * (Txs + 1) + i + 1];
+  float a = 0.f;
+  for (int j = s0; j < s1; ++j) a += dzm[(size_t)bc * Ty + j];
+  dxm[idx] = a;
+}
+// mle loss partial sums (commons.py:28-33): acc[0] += sum(logs*?) ... computed over [B,C,T] tensors:
+//   acc[0] += sum logs,  acc[1] += sum exp(-2 logs) (z-m)^2   (logs may be NULL = 0)
+__global__ __launch_bounds__(256) void gt_mle_sums_kernel(const float* __restrict__ z, const float* __restrict__ m,
+                                                          const float* __restrict__ logs, float* __restrict__ acc, size_t n)
+{
+  float a0 = 0.f, a1 = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float l = logs ? logs[i] : 0.f, d = z[i] - m[i];
+    a0 += l; a1 += __expf(-2.0f * l) * d * d;
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(acc, a0); atomicAdd(acc + 1, a1); }
+}
+// dz = g * exp(-2 logs) (z-m);  dm = -dz;  dlogs = g * (1 - exp(-2 logs)(z-m)^2)   with g = *gscale
+__global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ m,
+                                                         const float* __restrict__ logs, const float* __restrict__ gscale,
+                                                         float* __restrict__ dz, float* __restrict__ dm, float* __restrict__ dlogs, size_t n)
+{
+  const float g = *gscale;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float l = logs ? logs[i] : 0.f, e = __expf(-2.0f * l), d = z[i] - m[i];
+    const float v = g * e * d;
+    if (dz) dz[i] = v;
+    if (dm) dm[i] = -v;
+    if (dlogs) dlogs[i] = g * (1.0f - e * d * d);
+  }
+}
+
+}  // namespace
+
+#define GT_ST(s) static_cast<hipStream_t>(s)
+#define GT_RET() return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH
+
+static void fill_drop(float p, uint32_t seed, uint32_t& th, uint32_t& sd, float& sc)
+{
+  th = 0; sd = seed; sc = 1.0f;
+  if (p > 0.f) { th = (uint32_t)((double)p * 4294967296.0); sc = 1.0f / (1.0f - p); }
+}
+
+static int fill_ln(LnArgs& p, const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                   float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
+                   float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu)
+{
+  if ((!a && !y) || !gamma || !beta || !mean || !rstd || R <= 0 || C <= 0 || C > 256) return GT_E_INVAL;
+  if (p_in >= 1.f || p_out >= 1.f) return GT_E_INVAL;
+  p.a = a; p.y = static_cast<const bf16_t*>(y); p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask;
+  p.out_f32 = out_f32; p.out_bf16 = static_cast<bf16_t*>(out_bf16); p.ldo = ldo; p.mean = mean; p.rstd = rstd;
+  p.R = R; p.C = C; p.eps = eps; p.relu = relu;
+  fill_drop(p_in, seed_in, p.din_thresh, p.din_seed, p.din_scale);
+  fill_drop(p_out, seed_out, p.dout_thresh, p.dout_seed, p.dout_scale);
+  return GT_OK;
+}
+
+extern "C" int gt_layernorm_fwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                                float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
+                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, void* stream)
+{
+  LnArgs p;
+  const int rc = fill_ln(p, a, y, ldy, gamma, beta, rowmask, out_f32, out_bf16, ldo, mean, rstd, R, C, eps, p_in, seed_in, p_out, seed_out, relu);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gt_layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), p);
+  GT_RET();
+}
+
+extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                                const float* mean, const float* rstd, int R, int C, float eps,
+                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu,
+                                const float* dout_f32, const void* dout_bf16, int lddo,
+                                float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream)
+{
+  LnBwdArgs q;
+  const int rc = fill_ln(q.f, a, y, ldy, gamma, beta, rowmask, nullptr, nullptr, 0, const_cast<float*>(mean), const_cast<float*>(rstd),
+                         R, C, eps, p_in, seed_in, p_out, seed_out, relu);
+  if (rc) return rc;
+  if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
+  q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 64;
+  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 63) / 64), dim3(256), 0, GT_ST(stream), q);
+  GT_RET();
+}
+
+static size_t attn_lds(int T, int D, int win, size_t extra_floats)
+{
+  size_t halfs = (size_t)T * (D + 2); halfs += halfs & 1;     // keep the float area 4-byte aligned
+  return halfs * 2 + (size_t)2 * (2 * win + 1) * D * 4 + extra_floats * 4;
+}
+
+extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                           const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
+                           float drop_p, uint32_t drop_seed, void* stream)
+{
+  if (!q || !k || !v || !Ek || !Ev || !lens || !out || !P || B <= 0 || T <= 0 || H <= 0) return GT_E_INVAL;
+  if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
+  const size_t lds = attn_lds(T, D, win, (size_t)4 * D + (size_t)AT_QT * T);
+  if (lds > 160 * 1024) return GT_E_UNSUPPORTED;
+  static bool attr = false;
+  if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH; attr = true; }
+  uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
+  hipLaunchKernelGGL(gt_attn_fwd_kernel, dim3((T + AT_QT - 1) / AT_QT, H, B), dim3(256), lds, GT_ST(stream),
+                     static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
+                     static_cast<bf16_t*>(out), ldo, P, T, Tp, H, D, win, th, sd, sc);
+  GT_RET();
+}
+
+extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                           const int32_t* lens, const void* dout, int lddo, const float* P, float* dS_ws,
+                           void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
+                           int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream)
+{
+  if (!q || !k || !v || !Ek || !Ev || !lens || !dout || !P || !dS_ws || !dq || !dk || !dv || !dEk || !dEv) return GT_E_INVAL;
+  if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
+  const size_t lds1 = attn_lds(T, D, win, (size_t)2 * (2 * win + 1) * D + (size_t)AT_QT * 2 * D + (size_t)AT_QT * T);
+  size_t halfs2 = (size_t)T * (D + 2); halfs2 += halfs2 & 1;
+  const size_t lds2 = halfs2 * 2 + (size_t)AT_QT * 2 * T * 4;
+  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return GT_E_UNSUPPORTED;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
+    attr = true;
+  }
+  uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
+  const dim3 grid((T + AT_QT - 1) / AT_QT, H, B);
+  hipLaunchKernelGGL(gt_attn_bwd_q_kernel, grid, dim3(256), lds1, GT_ST(stream),
+                     static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
+                     static_cast<const bf16_t*>(dout), lddo, P, dS_ws, static_cast<bf16_t*>(dq), lddq, dEk, dEv,
+                     T, Tp, H, D, win, th, sd, sc);
+  hipLaunchKernelGGL(gt_attn_bwd_kv_kernel, grid, dim3(256), lds2, GT_ST(stream),
+                     static_cast<const bf16_t*>(q), ld, static_cast<const bf16_t*>(dout), lddo, P, dS_ws, lens,
+                     static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), lddq, T, Tp, H, D, th, sd, sc);
+  GT_RET();
+}
+
+extern "C" int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
+                                int B, int T, int Tp, int C, float scale, void* stream)
+{
+  if (!ids || !emb || !lens || (!out_f32 && !out_bf16) || B <= 0 || T <= 0 || C <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_embedding_fwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, GT_ST(stream), ids, emb, lens, out_f32,
+                     static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale);
+  GT_RET();
+}
+extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
+                                int B, int T, int Tp, int C, float scale, void* stream)
+{
+  if (!ids || !dx || !lens || !demb || B <= 0 || T <= 0 || C <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_embedding_bwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, GT_ST(stream), ids, dx, lens, demb, B, T, Tp, C, scale);
+  GT_RET();
+}
+
+extern "C" int gt_logp_f32(const float* x_m, const float* x_logs, const float* z, float* logp, int B, int C, int Tx, int Ty, void* stream)
+{
+  if (!x_m || !z || !logp || B <= 0 || C <= 0 || (C & 1) || Tx <= 0 || Ty <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_logp_kernel, dim3((Ty + 127) / 128, (Tx + 31) / 32, B), dim3(256), 0, GT_ST(stream), x_m, x_logs, z, logp, B, C, Tx, Ty);
+  GT_RET();
+}
+
+extern "C" int gt_prior_expand(const float* x_m, const int32_t* frame2token, float* z_m, int B, int C, int Tx, int Ty, void* stream)
+{
+  if (!x_m || !frame2token || !z_m || B <= 0 || C <= 0 || Tx <= 0 || Ty <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_prior_expand_kernel, dim3(((size_t)B * C * Ty + 255) / 256), dim3(256), 0, GT_ST(stream), x_m, frame2token, z_m, B, C, Tx, Ty);
+  GT_RET();
+}
+extern "C" int gt_prior_expand_bwd(const float* dz_m, const int32_t* starts, float* dx_m, int B, int C, int Tx, int Ty, void* stream)
+{
+  if (!dz_m || !starts || !dx_m || B <= 0 || C <= 0 || Tx <= 0 || Ty <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_prior_expand_bwd_kernel, dim3(((size_t)B * C * Tx + 255) / 256), dim3(256), 0, GT_ST(stream), dz_m, starts, dx_m, B, C, Tx, Ty, Tx);
+  GT_RET();
+}
+extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream)
+{
+  if (!z || !m || !acc2) return GT_E_INVAL;
+  if (n == 0) return GT_OK;
+  size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gt_mle_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, acc2, n);
+  GT_RET();
+}
+extern "C" int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
+                          size_t n, void* stream)
+{
+  if (!z || !m || !gscale) return GT_E_INVAL;
+  if (n == 0) return GT_OK;
+  size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gt_mle_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, gscale, dz, dm, dlogs, n);
+  GT_RET();
+}

@@ -279,6 +279,17 @@ __global__ __launch_bounds__(256) void gt_gate_bwd_kernel(const bf16_t* __restri
   *reinterpret_cast<uint2*>(dpre + (size_t)m * ldp + half + c) = make_uint2(pack2bf(gs[0], gs[1]), pack2bf(gs[2], gs[3]));
 }
 
+// backward of y = mask * dropout(relu(c)):  dc = (y != 0) ? d * scale : 0   (bf16 rows)
+__global__ __launch_bounds__(256) void gt_relu_drop_bwd_kernel(const bf16_t* __restrict__ d, int ldd, const bf16_t* __restrict__ y, int ldy,
+                                                               bf16_t* __restrict__ dc, int ldc, int R, int n, float scale)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * n) return;
+  const int m = idx / n, c = idx - m * n;
+  const bool on = (y[(size_t)m * ldy + c] & 0x7fff) != 0;
+  dc[(size_t)m * ldc + c] = on ? f2bf(bf2f(d[(size_t)m * ldd + c]) * scale) : (bf16_t)0;
+}
+
 // generic: out_bf16[m, :n] = in_f32[m, :n] * (rowmask ? rowmask[m] : 1)
 __global__ __launch_bounds__(256) void gt_rows_f32_to_bf16_kernel(const float* __restrict__ in, int ldi, bf16_t* __restrict__ out, int ldo,
                                                                   const float* __restrict__ rowmask, int R, int n)
@@ -370,6 +381,13 @@ extern "C" int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void
   hipLaunchKernelGGL(gt_gate_bwd_kernel, dim3((R * (half / 4) + 255) / 256), dim3(256), 0, GT_ST(stream),
                      static_cast<const bf16_t*>(dacts), ldd, static_cast<const bf16_t*>(T), static_cast<const bf16_t*>(S), ldts,
                      static_cast<bf16_t*>(dpre), ldp, static_cast<bf16_t*>(dpre_cond), R, half, th, drop_seed, sc);
+  GT_RET();
+}
+extern "C" int gt_relu_drop_bwd(const void* d, int ldd, const void* y, int ldy, void* dc, int ldc, int R, int n, float drop_p, void* stream)
+{
+  if (!d || !y || !dc || R <= 0 || n <= 0 || drop_p >= 1.f) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_relu_drop_bwd_kernel, dim3((R * n + 255) / 256), dim3(256), 0, GT_ST(stream), static_cast<const bf16_t*>(d), ldd,
+                     static_cast<const bf16_t*>(y), ldy, static_cast<bf16_t*>(dc), ldc, R, n, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f);
   GT_RET();
 }
 extern "C" int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const float* rowmask, int R, int n, void* stream)

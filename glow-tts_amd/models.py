@@ -122,3 +122,6 @@ class _DecoderRunner:
         if self.has_cond:
             out += dconds
         return out + [grads.get(p) for p in self.params]
+
+
+from .text_models import DurationPredictor, FlowGenerator, TextEncoder, mle_loss  # noqa: E402,F401

@@ -169,3 +169,18 @@ class WN(nn.Module):
             last = i == n_layers - 1
             self.res_skip_layers.append(WNConvP(hidden_channels, hidden_channels if last else 2 * hidden_channels, 1,
                                                 split_res_skip=not last))
+
+
+class ConvReluNorm(nn.Module):
+    """reference modules.ConvReluNorm (modules.py:70-102): the text-encoder prenet."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, kernel_size, n_layers, p_dropout):
+        super().__init__()
+        assert n_layers > 1, "Number of layers should be larger than 0."
+        assert in_channels == hidden_channels == out_channels, "prenet kernels assume equal widths (models.py:674)"
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, hidden_channels, out_channels
+        self.kernel_size, self.n_layers, self.p_dropout = kernel_size, n_layers, p_dropout
+        self.conv_layers = nn.ModuleList([ConvP(in_channels if i == 0 else hidden_channels, hidden_channels, kernel_size)
+                                          for i in range(n_layers)])
+        self.norm_layers = nn.ModuleList([LayerNorm(hidden_channels) for _ in range(n_layers)])
+        self.proj = ConvP(hidden_channels, out_channels, 1, zero_init=True)      # modules.py:91-92

@@ -14,14 +14,15 @@ _DT = {torch.float32: _lib.GT_DT_F32, torch.int32: _lib.GT_DT_I32, torch.float16
 
 class MASResult:
     """Everything the kernel produces in one launch."""
-    __slots__ = ("path", "durations", "frame2token", "status")
+    __slots__ = ("path", "durations", "frame2token", "status", "workspace")
 
-    def __init__(self, path, durations, frame2token, status):
+    def __init__(self, path, durations, frame2token, status, workspace=None):
         self.path, self.durations, self.frame2token, self.status = path, durations, frame2token, status
+        self.workspace = workspace          # int32 [B, T_x+1] row start columns (gt_mas_f32 workspace)
 
 
 def maximum_path_lengths(value, t_x, t_y, mask=None, out_dtype=None, want_durations=False,
-                         want_frame2token=False, validate=False):
+                         want_frame2token=False, validate=False, keep_workspace=False):
     """MAS from explicit lengths (the native form: no mask traffic).
 
     value: [b, t_x_max, t_y_max] float tensor on the GPU (fp32 is used as is; other float
@@ -56,9 +57,10 @@ def maximum_path_lengths(value, t_x, t_y, mask=None, out_dtype=None, want_durati
     dur = torch.empty((B, T_x), dtype=torch.float32, device=v.device) if want_durations else None
     f2t = torch.empty((B, T_y), dtype=torch.int32, device=v.device) if want_frame2token else None
     status = torch.zeros((1,), dtype=torch.int32, device=v.device) if validate else None
+    ws = None
     if B and T_x and T_y:
         ws_bytes = L.gt_mas_workspace_bytes(B, T_x, T_y)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=v.device)
+        ws = torch.empty((ws_bytes // 4,), dtype=torch.int32, device=v.device)
         rc = L.gt_mas_f32(_lib.ptr(v), _lib.ptr(m), _lib.ptr(t_x), _lib.ptr(t_y), _lib.ptr(path),
                           _DT[out_dtype], _lib.ptr(dur), _lib.ptr(f2t), B, T_x, T_y,
                           v.stride(0), v.stride(1), _lib.ptr(ws), ws_bytes, _lib.ptr(status),
@@ -74,7 +76,8 @@ def maximum_path_lengths(value, t_x, t_y, mask=None, out_dtype=None, want_durati
                              "bounds here, core.pyx:34); refusing")
         if st & 2:
             raise ValueError("maximum_path: a length is negative or exceeds the lattice")
-    return MASResult(path, dur, f2t, status)
+    starts = ws[:B * (T_x + 1)].view(B, T_x + 1) if (keep_workspace and ws is not None) else None
+    return MASResult(path, dur, f2t, status, starts)
 
 
 def lengths_from_mask(mask):

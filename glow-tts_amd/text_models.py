@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's models.py, text side + training glue.
+
+  DurationPredictor   reference models.py:560-612
+  TextEncoder         reference models.py:614-716
+  FlowGenerator       reference models.py:792-1133 — the upstream-equivalent live sub-graph of
+                      forward() for the base configs (the fork's own FlowGenerator
+                      only constructs for base_blank_emo_lang_pitch.json, which is outside the
+                      round-1 scope).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib, encoder_impl
+from . import monotonic_align
+from .attentions import Encoder
+from .modules import ConvP, ConvReluNorm, LayerNorm, _RowsFn, prepare_all
+from .ops import HALO, PackedConv, RowsCtx
+
+
+class _PaddedConv:
+    """An [1, C, 1] projection run as an 8-channel conv (MFMA tiles want N % 8 == 0)."""
+    weight_norm = False
+
+    def __init__(self, conv):
+        self.conv, self.pc, self.weight, self.bias = conv, None, None, None
+
+    def prepare(self):
+        c = self.conv
+        dev = c.weight.device
+        if self.pc is None or self.pc.fwd.device != dev:
+            self.pc = PackedConv(8, c.in_channels, c.kernel_size, False, device=dev)
+        self.weight = torch.zeros(8, c.in_channels, c.kernel_size, device=dev)
+        self.weight[:1] = c.weight.detach()
+        self.bias = torch.zeros(8, device=dev)
+        self.bias[:1] = c.bias.detach()
+        self.pc.pack(self.weight, None)
+
+
+class DurationPredictor(nn.Module):
+    def __init__(self, in_channels, filter_channels, kernel_size, p_dropout, gin_channels=0, lin_channels=0, emoin_channels=0):
+        super().__init__()
+        assert gin_channels == 0 and lin_channels == 0 and emoin_channels == 0, "conditioned predictor: cfg 4/5, next round"
+        self.in_channels, self.filter_channels, self.kernel_size, self.p_dropout = in_channels, filter_channels, kernel_size, p_dropout
+        self.conv_1 = ConvP(in_channels, filter_channels, kernel_size)
+        self.norm_1 = LayerNorm(filter_channels)
+        self.conv_2 = ConvP(filter_channels, filter_channels, kernel_size)
+        self.norm_2 = LayerNorm(filter_channels)
+        self.proj = ConvP(filter_channels, 1, 1)
+        self.proj_pad = _PaddedConv(self.proj)
+
+    def prepare_extra(self):
+        self.proj_pad.prepare()
+
+
+class TextEncoder(nn.Module):
+    def __init__(self, n_vocab, out_channels, hidden_channels, filter_channels, filter_channels_dp, n_heads, n_layers,
+                 kernel_size, p_dropout, window_size=None, block_length=None, mean_only=False, prenet=False, use_sdp=False,
+                 gin_channels=0, lin_channels=0, emoin_channels=0):
+        super().__init__()
+        assert not use_sdp, "StochasticDurationPredictor is SURVEY §8 (f1): next round"
+        assert lin_channels == 0 and gin_channels == 0, "language / speaker conditioning: cfg 4/5, next round"
+        self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
+        self.filter_channels, self.filter_channels_dp, self.n_heads, self.n_layers = filter_channels, filter_channels_dp, n_heads, n_layers
+        self.kernel_size, self.p_dropout, self.window_size, self.mean_only, self.prenet = kernel_size, p_dropout, window_size, mean_only, prenet
+        self.emb = nn.Embedding(n_vocab, hidden_channels)
+        nn.init.normal_(self.emb.weight, 0.0, hidden_channels ** -0.5)
+        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout)
+        if prenet:
+            self.pre = ConvReluNorm(hidden_channels, hidden_channels, hidden_channels, kernel_size=5, n_layers=3, p_dropout=0.5)
+        self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
+                               window_size=window_size, block_length=block_length, gin_channels=gin_channels)
+        self.proj_m = ConvP(hidden_channels, out_channels, 1)
+        if not mean_only:
+            self.proj_s = ConvP(hidden_channels, out_channels, 1)
+        self._step = 0
+
+    def forward(self, x, x_lengths, l=None, g=None, emo=None, prepared=False):
+        """ids [b, t] int64, lengths [b] -> (x [b,H,t], x_m [b,80,t], x_logs [b,80,t], x_mask [b,1,t])
+        exactly as reference models.py:692-716."""
+        assert l is None and g is None, "conditioning: cfg 4/5, next round"
+        if not prepared:
+            prepare_all(self)
+        self._step += 1
+        T = x.shape[1]
+        x_mask = (torch.arange(T, device=x.device)[None, :] < x_lengths[:, None]).unsqueeze(1).to(torch.float32)
+        runner = _TextEncoderRunner(self, x, x_lengths, self.training, seed=(self._step * 104729) & 0x7fffffff)
+        outs = _RowsFn.apply(runner, 3, *runner.params)
+        xo, x_m, x_logs = outs[0], outs[1], outs[2]
+        self._last_rows = runner.last            # (rc, xb_final) for the duration predictor
+        return xo, x_m, x_logs, x_mask
+
+
+class _TextEncoderRunner:
+    def __init__(self, te, ids, lengths, train, seed):
+        self.te, self.ids, self.lengths, self.train, self.seed = te, ids.contiguous(), lengths, train, seed
+        self.params = [p for n, p in te.named_parameters() if not n.startswith("proj_w.")]
+        self.last = None
+
+    def forward(self, *_):
+        L = _lib.lib()
+        te = self.te
+        B, T = self.ids.shape
+        dev = self.ids.device
+        C = te.hidden_channels
+        rc = RowsCtx(self.lengths.to(torch.int32), T)
+        x = torch.empty(rc.R, C, dtype=torch.float32, device=dev)
+        xb = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
+        emb = te.emb.weight.detach()
+        _lib.check(L.gt_embedding_fwd(_lib.ptr(self.ids), _lib.ptr(emb), _lib.ptr(rc.lengths), _lib.ptr(x), _lib.ptr(xb),
+                                      B, T, rc.Tp, C, math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_fwd")
+        s_pre = None
+        if te.prenet:
+            x, xb, s_pre = encoder_impl.crn_fwd(rc, te.pre, x, xb, self.train, self.seed)
+        s_layers = []
+        for i in range(te.encoder.n_layers):
+            x, xb, s = encoder_impl.layer_fwd(rc, te.encoder, i, x, xb, self.train, self.seed + 16 + 8 * i)
+            s_layers.append(s)
+        from .ops import conv_rows
+        xm_r = conv_rows(xb, te.proj_m.pc, rc, bias=te.proj_m.bias, mask=True, out_f32=True)
+        xs_r = None if te.mean_only else conv_rows(xb, te.proj_s.pc, rc, bias=te.proj_s.bias, mask=True, out_f32=True)
+        xo = rc.from_rows(x)
+        x_m = rc.from_rows(xm_r)
+        x_logs = torch.zeros_like(x_m) if xs_r is None else rc.from_rows(xs_r)
+        self.last = (rc, xb)
+        return (xo, x_m, x_logs), (rc, s_pre, s_layers, xb)
+
+    def backward(self, saved_all, dxo, dx_m, dx_logs):
+        L = _lib.lib()
+        from .flow_impl import conv_param_grads
+        from .ops import conv_rows
+        rc, s_pre, s_layers, xb_final = saved_all
+        te = self.te
+        dev = rc.device
+        C = te.hidden_channels
+        grads = {}
+        dxb = None
+        if dx_m is not None:
+            d = rc.to_rows(dx_m.float(), torch.bfloat16)
+            grads.update(conv_param_grads(te.proj_m, xb_final, d, rc.R))
+            dxb = conv_rows(d, te.proj_m.pc, rc, dgrad=True)
+        if not te.mean_only and dx_logs is not None:
+            d = rc.to_rows(dx_logs.float(), torch.bfloat16)
+            grads.update(conv_param_grads(te.proj_s, xb_final, d, rc.R))
+            dxb = conv_rows(d, te.proj_s.pc, rc, dgrad=True, addend=dxb)
+        dx = rc.to_rows(dxo.float()) if dxo is not None else None
+        if dx is None and dxb is None:
+            return [None] * len(self.params)
+        if dx is None:
+            dx = torch.zeros(rc.R, C, dtype=torch.float32, device=dev)
+        for i in reversed(range(te.encoder.n_layers)):
+            dx, dxb = encoder_impl.layer_bwd(rc, te.encoder, i, s_layers[i], dx, dxb, grads)
+        if te.prenet:
+            dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
+        tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
+        demb = torch.zeros_like(te.emb.weight)
+        B, T = self.ids.shape
+        _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, C,
+                                      math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_bwd")
+        grads[te.emb.weight] = demb
+        return [grads.get(p) for p in self.params]
+
+
+class _DurationRunner:
+    """logw = DurationPredictor(x.detach(), x_mask) as one autograd node over its own parameters."""
+
+    def __init__(self, dp, rc, xb, train, seed):
+        self.dp, self.rc, self.xb, self.train, self.seed = dp, rc, xb, train, seed
+        self.params = list(dp.parameters())
+
+    def forward(self, *_):
+        out, saved = encoder_impl.dp_fwd(self.rc, self.dp, self.xb, self.train, self.seed)
+        rc = self.rc
+        logw = out.reshape(rc.B, rc.Tp, 8)[:, HALO:HALO + rc.T, 0].unsqueeze(1).contiguous()      # [b,1,t]
+        return (logw,), saved
+
+    def backward(self, saved, dlogw):
+        rc = self.rc
+        grads = {}
+        dout = torch.zeros(rc.B, rc.Tp, 8, dtype=torch.float32, device=rc.device)
+        dout[:, HALO:HALO + rc.T, 0] = dlogw[:, 0].float()
+        encoder_impl.dp_bwd(rc, self.dp, saved, dout.reshape(rc.R, 8), grads)
+        return [grads.get(p) for p in self.params]
+
+
+class _LogpMasFn:
+    """no_grad block of models.py:1076-1083: logp lattice + MAS on the device."""
+
+    @staticmethod
+    def run(x_m, x_logs, z, x_lengths, y_lengths, mean_only):
+        L = _lib.lib()
+        B, C, Tx = x_m.shape
+        Ty = z.shape[2]
+        dev = z.device
+        logp = torch.empty(B, Tx, Ty, dtype=torch.float32, device=dev)
+        xm = x_m.detach().float().contiguous()
+        xs = None if mean_only else x_logs.detach().float().contiguous()
+        zz = z.detach().float().contiguous()
+        _lib.check(L.gt_logp_f32(_lib.ptr(xm), _lib.ptr(xs), _lib.ptr(zz), _lib.ptr(logp), B, C, Tx, Ty,
+                                 _lib.current_stream(dev)), "gt_logp_f32")
+        r = monotonic_align.maximum_path_lengths(logp, x_lengths.to(torch.int32), y_lengths.to(torch.int32),
+                                                 want_durations=True, want_frame2token=True, keep_workspace=True)
+        return logp, r
+
+
+class _PriorExpandFn(torch.autograd.Function):
+    """z_m = attn^T x_m (models.py:1118) as a gather; backward = segment sums over the MAS intervals."""
+
+    @staticmethod
+    def forward(ctx, x_m, f2t, starts):
+        L = _lib.lib()
+        B, C, Tx = x_m.shape
+        Ty = f2t.shape[1]
+        xm = x_m.detach().float().contiguous()
+        z_m = torch.empty(B, C, Ty, dtype=torch.float32, device=x_m.device)
+        _lib.check(L.gt_prior_expand(_lib.ptr(xm), _lib.ptr(f2t), _lib.ptr(z_m), B, C, Tx, Ty, _lib.current_stream(x_m.device)), "gt_prior_expand")
+        ctx.starts, ctx.shape = starts, (B, C, Tx, Ty)
+        return z_m
+
+    @staticmethod
+    def backward(ctx, dz_m):
+        L = _lib.lib()
+        B, C, Tx, Ty = ctx.shape
+        d = dz_m.float().contiguous()
+        dx_m = torch.empty(B, C, Tx, dtype=torch.float32, device=d.device)
+        _lib.check(L.gt_prior_expand_bwd(_lib.ptr(d), _lib.ptr(ctx.starts), _lib.ptr(dx_m), B, C, Tx, Ty, _lib.current_stream(d.device)),
+                   "gt_prior_expand_bwd")
+        return dx_m, None, None
+
+
+class _MleLossFn(torch.autograd.Function):
+    """commons.mle_loss (commons.py:28-33) with z_logs == None meaning zeros (mean_only)."""
+
+    @staticmethod
+    def forward(ctx, z, m, logs, logdet, mask):
+        L = _lib.lib()
+        dev = z.device
+        zc, mc = z.detach().float().contiguous(), m.detach().float().contiguous()
+        lc = None if logs is None else logs.detach().float().contiguous()
+        acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        _lib.check(L.gt_mle_sums(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(acc), zc.numel(), _lib.current_stream(dev)), "gt_mle_sums")
+        denom = (mask.sum() * z.shape[1]).to(torch.float32)                 # sum(ones_like(z) * mask)
+        loss = (acc[0] + 0.5 * acc[1] - logdet.sum()) / denom + 0.5 * math.log(2 * math.pi)
+        ctx.saved = (zc, mc, lc, denom, logdet.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        zc, mc, lc, denom, ld_shape = ctx.saved
+        dev = zc.device
+        gs = (g.float() / denom).reshape(1).contiguous()
+        dz = torch.empty_like(zc)
+        dm = torch.empty_like(mc)
+        dl = None if lc is None else torch.empty_like(lc)
+        _lib.check(L.gt_mle_bwd(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(gs), _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl),
+                                zc.numel(), _lib.current_stream(dev)), "gt_mle_bwd")
+        dlogdet = (-gs).expand(ld_shape).contiguous()
+        return dz, dm, dl, dlogdet, None
+
+
+def mle_loss(z, m, logs, logdet, mask):
+    """Drop-in for reference commons.mle_loss (commons.py:28-33); logs may be None (== zeros)."""
+    return _MleLossFn.apply(z, m, logs, logdet, mask)
+
+
+class FlowGenerator(nn.Module):
+    """Training forward of Glow-TTS for the base configs (configs/base.json, base_blank.json):
+    TextEncoder -> FlowSpecDecoder -> logp -> MAS -> durations / prior expansion, with the return
+    structure of reference models.py:1133 (entries this sub-graph does not produce are None)."""
+
+    def __init__(self, n_vocab, hidden_channels, filter_channels, filter_channels_dp, out_channels, kernel_size=3, n_heads=2,
+                 n_layers_enc=6, p_dropout=0., n_blocks_dec=12, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
+                 p_dropout_dec=0., n_speakers=0, gin_channels=0, n_split=4, n_sqz=1, sigmoid_scale=False, window_size=None,
+                 block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False, **kwargs):
+        super().__init__()
+        from .models import FlowSpecDecoder
+        assert gin_channels == 0 and n_speakers <= 1, "multi-speaker configs (cfg 4/5): next round"
+        self.n_sqz, self.mean_only, self.out_channels = n_sqz, mean_only, out_channels
+        self.encoder = TextEncoder(n_vocab, out_channels, hidden_channels_enc or hidden_channels, filter_channels,
+                                   filter_channels_dp, n_heads, n_layers_enc, kernel_size, p_dropout, window_size=window_size,
+                                   block_length=block_length, mean_only=mean_only, prenet=prenet, use_sdp=False)
+        self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec, dilation_rate,
+                                       n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec, n_split=n_split, n_sqz=n_sqz,
+                                       sigmoid_scale=sigmoid_scale, gin_channels=gin_channels)
+        self._step = 0
+
+    def prepare(self):
+        """Re-pack every conv weight for the MFMA kernels (once per optimizer step)."""
+        prepare_all(self)
+        self.encoder.proj_w.prepare_extra()
+
+    def preprocess(self, y, y_lengths, y_max_length):
+        """reference models.py:1248-1253"""
+        if y_max_length is not None:
+            y_max_length = (y_max_length // self.n_sqz) * self.n_sqz
+            y = y[:, :, :y_max_length]
+        y_lengths = torch.div(y_lengths, self.n_sqz, rounding_mode="floor") * self.n_sqz
+        return y, y_lengths, y_max_length
+
+    def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None):
+        assert g is None and emo is None and pitch is None and energy is None and l is None, "cfg 4/5 conditioning: next round"
+        self.prepare()
+        self._step += 1
+        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
+        y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
+        z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
+        z, logdet = self.decoder(y, z_mask, prepared=True)
+        with torch.no_grad():
+            logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
+            attn = mas.path.unsqueeze(1)
+        w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
+        logw_ = torch.log(w + 1e-8) * x_mask
+        rc, xb = self.encoder._last_rows
+        runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff)
+        (logw,) = _RowsFn.apply(runner, 1, *runner.params)
+        l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)  # models.py:1089-1092
+        z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
+        z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)
+        self.last_logp = logp
+        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, None, None), (None, None, None, None), None

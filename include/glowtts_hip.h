@@ -102,7 +102,8 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
  * Replaces the conv1d calls of modules.py:152,165 / attentions.py:144,172,232-238,365-371 /
  * modules.py:97 / models.py:710 and, with dgrad-packed weights, their data gradients.
  *   Y[m,n] = epi( sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci] + bias[n] + cond[m/Tp][n] )
- *   epi: optional relu, optional + addend[m,n], optional * rowmask[m]; output bf16 or fp32.
+ *   epi: optional relu, optional dropout (drop_p, counter-based on (m,n)), optional + addend[m,n],
+ *        optional * rowmask[m]; output bf16 or fp32.
  *   gate != 0 (WaveNet gate, commons.py:61-68; N = 2*half, packed with the gate interleave):
  *     pre = drop(acc + bias) + cond;  T = tanh(pre[:half]), S = sigmoid(pre[half:]),
  *     Y[m, :half] = T*S (bf16), T and S are saved to gate_t / gate_s ([R, ldts] bf16).
@@ -172,9 +173,60 @@ int gt_coupling_bwd(const float* out, const float* x, const float* dz, const flo
 int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void* S, int ldts, void* dpre, int ldp, void* dpre_cond,
                 int R, int half, float drop_p, uint32_t drop_seed, void* stream);
 
+/* backward of y = rowmask * dropout(relu(c)) given the saved y: dc = (y != 0) ? d/(1-p) : 0 (bf16 rows). */
+int gt_relu_drop_bwd(const void* d, int ldd, const void* y, int ldy, void* dc, int ldc, int R, int n, float drop_p, void* stream);
+
 /* small row helpers */
 int gt_rows_add_bf16(float* dx, int ldx, const void* add, int lda, int R, int n, void* stream);
 int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const float* rowmask, int R, int n, void* stream);
+
+/* Channel LayerNorm of the text encoder / predictors on rows (modules.py:26-44, eps 1e-4), with the
+ * surrounding elementwise work fused (attentions.py:79-84, modules.py:95-102, models.py:598-607):
+ *   s = a (fp32, optional) + dropout_in(y (bf16, optional));  n = LN(s)*gamma + beta;
+ *   o = dropout_out(relu?(n)) * rowmask;  out_f32 / out_bf16 (either optional).  C <= 256.
+ * Dropout masks are counter-based (seed) and replayed by the backward. dgamma/dbeta ACCUMULATE. */
+int gt_layernorm_fwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                     float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
+                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, void* stream);
+int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                     const float* mean, const float* rstd, int R, int C, float eps,
+                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu,
+                     const float* dout_f32, const void* dout_bf16, int lddo,
+                     float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream);
+
+/* Relative-position multi-head self-attention (attentions.py:241-336) in its banded form:
+ *   score[i,j] = (q_i.k_j + [|j-i|<=win] q_i.Ek[j-i+win]) / sqrt(D), masked keys/queries -> -1e4,
+ *   out_i = sum_j dropout(softmax)[i,j] v_j + sum_{|j-i|<=win} dropout(softmax)[i,j] Ev[j-i+win].
+ * q,k,v,out: bf16 rows [B*Tp, H*D]; Ek,Ev: [2*win+1, D] fp32 shared by heads; P: [B,H,T,T] fp32
+ * (softmax before dropout, kept for the backward); dS_ws: [B,H,T,T] fp32 scratch; dEk/dEv ACCUMULATE. */
+int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
+                float drop_p, uint32_t drop_seed, void* stream);
+int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                const int32_t* lens, const void* dout, int lddo, const float* P, float* dS_ws,
+                void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
+                int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream);
+
+/* Embedding * scale into rows (models.py:693): fp32 and/or bf16 output, zero halo / padded rows. */
+int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
+                     int B, int T, int Tp, int C, float scale, void* stream);
+int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
+                     int B, int T, int Tp, int C, float scale, void* stream);
+
+/* log-likelihood lattice (models.py:1076-1082) on exact-fp32 MFMA: x_m, x_logs (NULL = 0): [B,C,Tx],
+ * z: [B,C,Ty] -> logp [B,Tx,Ty] fp32. */
+int gt_logp_f32(const float* x_m, const float* x_logs, const float* z, float* logp, int B, int C, int Tx, int Ty, void* stream);
+
+/* Prior expansion models.py:1118-1119 as a gather by frame2token (from gt_mas_f32) and its backward as
+ * a segment sum over the MAS row intervals (`starts` = gt_mas_f32 workspace, [B, Tx+1]). */
+int gt_prior_expand(const float* x_m, const int32_t* frame2token, float* z_m, int B, int C, int Tx, int Ty, void* stream);
+int gt_prior_expand_bwd(const float* dz_m, const int32_t* starts, float* dx_m, int B, int C, int Tx, int Ty, void* stream);
+
+/* mle_loss pieces (commons.py:28-33): acc2[0] += sum(logs), acc2[1] += sum(exp(-2 logs)(z-m)^2);
+ * backward: dz = g e^{-2 logs}(z-m), dm = -dz, dlogs = g (1 - e^{-2 logs}(z-m)^2), g = *gscale. */
+int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream);
+int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
+               size_t n, void* stream);
 
 #ifdef __cplusplus
 }

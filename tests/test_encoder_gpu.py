@@ -1,0 +1,191 @@
+"""GPU parity tests: text encoder, rel-pos attention, logp, prior expansion, mle loss and the whole
+training forward/backward (glow_tts_amd, HIP through the C-ABI) vs the float oracle
+(oracle/glowtts_ref.py, pinned to the reference by tests/golden/float_golden.npz).
+
+Tolerances: bf16 GEMM operands / bf16 hidden activations -> 3e-2 of max-abs on activations,
+6e-2 on parameter gradients; fp32-only kernels (logp, expansion, loss) 1e-4."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from fill import fill_module  # noqa: E402
+from oracle import glowtts_ref as R  # noqa: E402
+from oracle import mas as omas  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
+
+
+def grad_ok(a, b, tol, atol=2e-3, name=""):
+    """Gradient agreement in relative L2 norm (plus a loose max-abs bound).  Max-abs alone is the wrong
+    yardstick downstream of a ReLU: a pre-activation within bf16 rounding of zero switches the unit
+    on/off relative to the fp32 oracle, which moves single elements by their full magnitude while the
+    tensor as a whole stays within tolerance.
+    The key bias of a softmax attention has a mathematically zero gradient (a constant added to every
+    key cancels in the softmax): both sides hold rounding noise only."""
+    if name.endswith("conv_k.bias"):
+        return a.abs().max().item() < 5e-2 and b.abs().max().item() < 1e-4
+    l2 = (a - b).norm().item() / max(1e-12, b.norm().item())
+    mx = (a - b).abs().max().item()
+    return l2 <= tol and mx <= 0.5 * b.abs().max().item() + atol
+
+
+def lens_mask(lengths, T):
+    l = torch.tensor(lengths)
+    return (torch.arange(T)[None, :] < l[:, None]).unsqueeze(1).float()
+
+
+def cpu_state(mod, prefix=""):
+    P = {prefix + k: v.detach().cpu().float().clone() for k, v in mod.state_dict().items()}
+    for v in P.values():
+        v.requires_grad_(True)
+    return P
+
+
+@pytest.mark.parametrize("T", [3, 5, 37, 150])
+def test_mha_fwd_bwd(built, T):
+    from glow_tts_amd import attentions
+    att = fill_module(attentions.MultiHeadAttention(192, 192, 2, window_size=4, p_dropout=0.1), "mha.").eval()
+    P = cpu_state(att, "mha.")
+    lens = [T, max(1, T - 2)]
+    xm = lens_mask(lens, T)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(2, 192, T, generator=g) * xm
+    xx = x.clone().requires_grad_(True)
+    am = xm.unsqueeze(2) * xm.unsqueeze(-1)
+    o, p = R.mha_fwd(P, "mha.", xx, xx, am)
+    r = torch.randn(o.shape, generator=g) * xm
+    (o * r).sum().backward()
+    att = att.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    od = att(xd, xd, am.to(dev()))
+    valid = xm.bool().expand_as(o)
+    assert relerr(od.detach().cpu()[valid], o.detach()[valid]) < 3e-2
+    pv = (xm.unsqueeze(-1) * xm.unsqueeze(2)).bool().expand_as(p)
+    assert (att.attn.cpu()[pv] - p.detach()[pv]).abs().max() < 2e-2
+    (od * r.to(dev())).sum().backward()
+    assert relerr(xd.grad.cpu(), xx.grad) < 4e-2
+    for name, prm in att.named_parameters():
+        assert grad_ok(prm.grad.cpu(), P["mha." + name].grad, 6e-2, name=name), name
+
+
+def test_encoder_stack_fwd_bwd(built):
+    from glow_tts_amd import attentions
+    enc = fill_module(attentions.Encoder(192, 768, 2, 2, 3, 0.1, window_size=4), "enc.").eval()
+    P = cpu_state(enc, "enc.")
+    T, lens = 41, [41, 17, 30]
+    xm = lens_mask(lens, T)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 192, T, generator=g) * xm
+    xx = x.clone().requires_grad_(True)
+    o = R.encoder_fwd(P, "enc.", xx, xm, n_layers=2)
+    r = torch.randn(o.shape, generator=g)
+    (o * r).sum().backward()
+    enc = enc.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    od = enc(xd, xm.to(dev()))
+    assert relerr(od.detach().cpu(), o.detach()) < 3e-2
+    (od * r.to(dev())).sum().backward()
+    assert relerr(xd.grad.cpu(), xx.grad) < 5e-2
+    for name, prm in enc.named_parameters():
+        assert grad_ok(prm.grad.cpu(), P["enc." + name].grad, 8e-2, name=name), name
+
+
+def test_logp_kernel(built):
+    from glow_tts_amd.text_models import _LogpMasFn
+    g = torch.Generator().manual_seed(4)
+    B, C, Tx, Ty = 3, 80, 45, 130
+    x_m = torch.randn(B, C, Tx, generator=g)
+    x_logs = torch.randn(B, C, Tx, generator=g) * 0.2
+    z = torch.randn(B, C, Ty, generator=g)
+    xl = torch.tensor([45, 20, 1]); yl = torch.tensor([130, 64, 2])
+    for mean_only in (True, False):
+        want = R.logp_lattice(x_m, torch.zeros_like(x_m) if mean_only else x_logs, z)
+        logp, mas = _LogpMasFn.run(x_m.to(dev()), x_logs.to(dev()), z.to(dev()), xl.to(dev()), yl.to(dev()), mean_only)
+        assert relerr(logp.cpu(), want) < 1e-5
+        # MAS on exactly this lattice is bit-exact with the oracle
+        mask = (lens_mask(xl.tolist(), Tx).unsqueeze(-1) * lens_mask(yl.tolist(), Ty).unsqueeze(2)).squeeze(1)
+        p = omas.oracle_maximum_path(logp.cpu().numpy(), mask.numpy())
+        assert np.array_equal(mas.path.cpu().numpy().astype(np.int32), p)
+
+
+HP = dict(hidden_channels=192, n_layers_enc=2, n_heads=2, window_size=4, kernel_size=3, prenet=True, mean_only=True,
+          n_blocks_dec=2, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
+
+
+def _make_generator():
+    from glow_tts_amd import models
+    return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1,
+                                            n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
+                                            p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True), "").eval()
+
+
+def test_text_encoder_fwd(built):
+    gen = _make_generator()
+    P = cpu_state(gen)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(1, 148, (2, 23), generator=g); xl = torch.tensor([23, 9])
+    x, x_m, x_logs, m = R.text_encoder_fwd(P, "encoder.", ids, xl, n_layers=2)
+    gen = gen.to(dev())
+    gen.prepare()
+    xd, xmd, xld, md = gen.encoder(ids.to(dev()), xl.to(dev()), prepared=True)
+    assert torch.equal(md.cpu(), m)
+    assert relerr(xd.detach().cpu(), x.detach()) < 3e-2 and relerr(xmd.detach().cpu(), x_m.detach()) < 3e-2
+    assert xld.abs().max().item() == 0
+
+
+def test_train_forward_backward_vs_oracle(built):
+    """Whole hot path: TextEncoder -> decoder -> logp -> MAS -> losses, forward and backward.  The
+    alignment is compared on the HIP path's own lattice (bit-exact), then injected into the oracle so
+    that the remaining quantities are comparable."""
+    from glow_tts_amd import models
+    gen = _make_generator()
+    P = cpu_state(gen)
+    g = torch.Generator().manual_seed(7)
+    B, Tx, Ty = 2, 21, 64
+    ids = torch.randint(1, 148, (B, Tx), generator=g); xl = torch.tensor([21, 12])
+    yl = torch.tensor([64, 37])
+    y = torch.randn(B, 80, Ty, generator=g) * lens_mask(yl.tolist(), Ty)
+
+    gen = gen.to(dev())
+    (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
+        gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()))
+    l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
+    loss = l_mle + l_length.sum()
+    loss.backward()
+
+    # alignment: bit-exact on the HIP lattice
+    amask = (x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)).squeeze(1)
+    p = omas.oracle_maximum_path(gen.last_logp.cpu().numpy(), amask.cpu().numpy())
+    assert np.array_equal(attn.squeeze(1).cpu().numpy().astype(np.int32), p)
+
+    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), HP)
+    out["loss"].backward()
+    assert relerr(gen.last_logp.cpu(), out["logp"]) < 3e-2
+    assert relerr(z.detach().cpu(), out["z"].detach()) < 3e-2
+    assert relerr(z_m.detach().cpu(), out["z_m"].detach()) < 3e-2
+    assert abs(l_mle.item() - out["l_mle"].item()) < 2e-2 * max(1.0, abs(out["l_mle"].item()))
+    assert relerr(l_length.detach().cpu(), out["l_length"].detach()) < 5e-2
+    worst = []
+    for name, prm in gen.named_parameters():
+        ref = P[name].grad
+        if ref is None:
+            assert prm.grad is None or prm.grad.abs().max().item() == 0, name
+            continue
+        assert prm.grad is not None, name
+        e = relerr(prm.grad.cpu(), ref)
+        worst.append((e, name))
+        assert grad_ok(prm.grad.cpu(), ref, 0.1, name=name), (name, e)
+    worst.sort(reverse=True)
+    print("worst grad errors:", worst[:5])
