@@ -3,18 +3,25 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3]
 
-One "step" = one pass of the hot path over one synthetic LJSpeech-shaped batch resident in HBM
-(seed 1234 + rank).  With N > 1 the driver launches this file under
-torch.distributed.run, one rank per GPU; utterances are sharded across ranks (independent
-units, no data-path collective for MAS; the gradient all-reduce belongs to the train-step leg).
+One "step" = one full training step of the hot path (zero_grad, TextEncoder + FlowSpecDecoder
+forward, logp + MAS, mle + duration loss, backward, gradient all-reduce, grad-norm, AdamW) on
+one synthetic LJSpeech-shaped batch resident in HBM (seed 1234 + rank, random-init
+weights of configs/base.json).  With N > 1 the driver launches this file under
+torch.distributed.run, one rank per GPU: the batch is sharded by utterance (weak scaling,
+B per GPU fixed) and the only collective is the RCCL gradient all-reduce.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0:
+  value            = valid mel-frames / s over all ranks (BASELINE.json metric, first half)
+  mas              = MAS alignments / s of gt_mas_f32 alone on the step's own lattice shape (second half)
+  roofline         = dominant kernel (WaveNet in_layer implicit-GEMM conv, bf16 MFMA), timed live with
+                     HIP events around each of its launches inside the timed steps
+  cpu_baseline     = the oracle's training step (PyTorch-CPU fp32 restatement of the reference,
+                     oracle/glowtts_ref.py + reference Cython MAS from oracle/_ref) on a bounded sample
 """
 import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,80 +30,89 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (B per GPU, T_x max, T_y max)      SURVEY.md §8 / configs/base.json batch_size=32
-    "cfg2": dict(B=32, T_x=150, T_y=800, desc="configs/base.json LJSpeech-shaped, B=32, T_x<=150, T_y<=800"),
-    "cfg3": dict(B=32, T_x=375, T_y=872, desc="configs/base_blank.json-shaped, B=32, T_x<=375, T_y<=872"),
+    "cfg2": dict(B=32, T_x=150, T_y=800, desc="configs/base.json, LJSpeech-shaped synthetic batch, B=32/GPU, T_x<=150, T_y<=800, bf16 GEMMs"),
+    "cfg3": dict(B=32, T_x=375, T_y=872, desc="configs/base_blank.json-shaped synthetic batch, B=32/GPU, T_x<=375, T_y<=872, bf16 GEMMs"),
 }
 
 
-def synth_batch(wl, rank, device):
-    """Synthetic LJSpeech-shaped lattice batch: T_x~U{60..150}, T_y~2*U{150..400},
-    one sample pinned at max; logp ~ N(-100, 5^2) fp32."""
+def mas_leg(dev, wl, rank, iters=100):
+    """MAS alone on a lattice of the workload's shape: alignments/s and achieved HBM GB/s."""
+    from glow_tts_amd import _lib
+    L = _lib.lib()
     g = torch.Generator().manual_seed(1234 + rank)
     B, T_x, T_y = wl["B"], wl["T_x"], wl["T_y"]
     t_x = torch.randint(max(1, int(T_x * 0.4)), T_x + 1, (B,), generator=g, dtype=torch.int32)
-    t_y = torch.randint(max(1, T_y // 2 * 3 // 8), T_y // 2 + 1, (B,), generator=g, dtype=torch.int32) * 2
+    t_y = torch.randint(max(1, T_y * 3 // 16), T_y // 2 + 1, (B,), generator=g, dtype=torch.int32) * 2
     t_y = torch.maximum(t_y, t_x + (t_x % 2))
     t_x[0], t_y[0] = T_x, T_y
-    logp = torch.randn(B, T_x, T_y, generator=g) * 5.0 - 100.0
-    return logp.to(device), t_x.to(device), t_y.to(device)
+    logp = (torch.randn(B, T_x, T_y, generator=g) * 5.0 - 100.0).to(dev)
+    t_x, t_y = t_x.to(dev), t_y.to(dev)
+    path = torch.empty_like(logp)
+    ws_bytes = L.gt_mas_workspace_bytes(B, T_x, T_y)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def run():
+        rc = L.gt_mas_f32(_lib.ptr(logp), None, _lib.ptr(t_x), _lib.ptr(t_y), _lib.ptr(path), _lib.GT_DT_F32, None, None,
+                          B, T_x, T_y, logp.stride(0), logp.stride(1), _lib.ptr(ws), ws_bytes, None, _lib.current_stream(dev))
+        assert rc == 0, rc
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / iters
+    assert int(path.sum().item()) == int(t_y.sum().item())
+    algo_bytes = 8.0 * B * T_x * T_y + 8.0 * B
+    return {"alignments_per_sec": B / (ms * 1e-3), "ms_per_batch": ms, "achieved_GBps": algo_bytes / (ms * 1e-3) / 1e9,
+            "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes, "logp": logp, "t_x": t_x, "t_y": t_y}
 
 
-def cpu_baseline_mas(logp, t_x, t_y, budget_s=12.0):
-    """The reference's own Cython MAS (oracle/_ref, built from /root/reference by oracle/Makefile)
-    or, if that build is absent, our C restatement — timed on this box's host cores on a bounded
-    sample of the same batch.  Returns dict for the JSON line."""
+def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4):
+    """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
+    from oracle import glowtts_ref as R
     from oracle import mas as omas
-    kind = "reference" if omas.ref_module() is not None else "port"
-    core = omas.ref_maximum_path_c if kind == "reference" else omas.oracle_maximum_path_c
-    v = logp.cpu().numpy().astype(np.float32)
-    tx = t_x.cpu().numpy().astype(np.int32)
-    ty = t_y.cpu().numpy().astype(np.int32)
-    B = v.shape[0]
-    n, t0 = 0, time.perf_counter()
-    while True:
-        vv = v.copy()                               # the core mutates its input
-        p = np.zeros(vv.shape, dtype=np.int32)
-        t1 = time.perf_counter()
-        core(p, vv, tx, ty)
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 200:
-            break
-    # time only the core calls: re-measure tightly
-    reps = max(3, min(n, 50))
-    dts = []
-    for _ in range(reps):
-        vv = v.copy(); p = np.zeros(vv.shape, dtype=np.int32)
-        t1 = time.perf_counter(); core(p, vv, tx, ty); dts.append(time.perf_counter() - t1)
-    dt = float(np.median(dts))
-    out = {"value": B / dt, "unit": "alignments/s", "cores": 1, "kind": kind,
-           "sample": f"{reps} passes of the same B={B} batch, serial C core only (no wrapper copies), median"}
-    # all-cores variant of our port (one utterance range per thread; ctypes releases the GIL)
-    try:
-        nthr = min(os.cpu_count() or 1, B)
-        def run_all():
-            vv = v.copy(); p = np.zeros(vv.shape, dtype=np.int32)
-            bounds = np.linspace(0, B, nthr + 1).astype(int)
-            ths = [threading.Thread(target=omas.oracle_maximum_path_range, args=(p, vv, tx, ty, bounds[i], bounds[i + 1]))
-                   for i in range(nthr)]
-            t1 = time.perf_counter()
-            [t.start() for t in ths]; [t.join() for t in ths]
-            return time.perf_counter() - t1
-        dta = float(np.median([run_all() for _ in range(5)]))
-        out["all_cores"] = {"value": B / dta, "cores": nthr, "kind": "port"}
-    except Exception as e:  # pragma: no cover
-        out["all_cores"] = {"error": str(e)}
-    return out
+    kind = "port"
+    mas_core = omas.ref_maximum_path_c if omas.ref_module() is not None else omas.oracle_maximum_path_c
+
+    def mp(logp, mask):
+        p = omas.oracle_maximum_path(logp.numpy(), mask.numpy(), core=mas_core)
+        return torch.from_numpy(p).float()
+    n = min(budget_utts, ids.shape[0])
+    P = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    hp = dict(hidden_channels=192, n_layers_enc=6, n_heads=2, window_size=4, kernel_size=3, prenet=True, mean_only=True,
+              n_blocks_dec=12, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
+    ids_c, tx_c, y_c, ty_c = ids[:n].cpu(), t_x[:n].cpu().long(), y[:n].cpu(), t_y[:n].cpu().long()
+    Tx, Ty = int(tx_c.max()), int(ty_c.max())
+    ids_c, y_c = ids_c[:, :Tx], y_c[:, :, :Ty]
+    cores = torch.get_num_threads()
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp)
+        out["loss"].backward()
+        times.append(time.perf_counter() - t0)
+        for v in P.values():
+            v.grad = None
+    dt = min(times)
+    return {"value": float(ty_c.sum()) / dt, "unit": "mel-frames/s", "cores": cores, "kind": kind,
+            "sample": f"fwd+loss+bwd (no optimizer) of the first {n} utterances of the batch ({int(ty_c.sum())} valid frames), "
+                      f"PyTorch-CPU fp32 oracle + {'reference Cython' if mas_core is omas.ref_maximum_path_c else 'C port'} MAS, best of 2",
+            "s_per_step": dt}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -104,33 +120,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist
-        dist.init_process_group("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
 
-    from glow_tts_amd import _lib, monotonic_align as ma
-    L = _lib.lib()                                   # fails loudly if the HIP library is missing
+    from glow_tts_amd import _lib, ops, train
+    _lib.lib()                                       # fails loudly if the HIP library is missing
     wl = WORKLOADS[args.workload]
-    logp, t_x, t_y = synth_batch(wl, rank, dev)
-    B, T_x, T_y = logp.shape
-
-    # preallocated outputs: the timed region holds kernels only
-    path = torch.empty_like(logp)
-    dur = torch.empty(B, T_x, device=dev)
-    f2t = torch.empty(B, T_y, dtype=torch.int32, device=dev)
-    ws_bytes = L.gt_mas_workspace_bytes(B, T_x, T_y)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream(dev)
-
-    def step():
-        rc = L.gt_mas_f32(_lib.ptr(logp), None, _lib.ptr(t_x), _lib.ptr(t_y), _lib.ptr(path), _lib.GT_DT_F32,
-                          _lib.ptr(dur), _lib.ptr(f2t), B, T_x, T_y, logp.stride(0), logp.stride(1),
-                          _lib.ptr(ws), ws_bytes, None, _lib.current_stream(dev))
-        assert rc == 0, rc
+    torch.manual_seed(1234)                          # identical initial weights on every rank
+    model = train.build_model(device=dev).train()
+    if world > 1:
+        for p in model.parameters():
+            torch.distributed.broadcast(p.data, 0)
+    tr = train.Trainer(model, world=world)
+    ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
+    valid_frames = int(t_y.sum().item())
+    padded_frames = wl["B"] * wl["T_y"]
 
     def barrier():
         if world > 1:
@@ -138,48 +147,61 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        step()
+        tr.step(ids, t_x, y, t_y)
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.KERNEL_TIMER.enable("in_layer_gate_conv")     # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
-    ev0.record(stream)
     for _ in range(args.steps):
-        step()
-    ev1.record(stream)
+        loss, mle = tr.step(ids, t_x, y, t_y)
     barrier()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)                   # HIP events on the launch stream
+    kt = ops.KERNEL_TIMER.collect()
     if world > 1:
-        t = torch.tensor([wall], device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        wall = float(t.item())
-
-    # sanity: the result of the timed kernels is a valid alignment
-    assert int(path.sum().item()) == int(t_y.sum().item())
+        t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)
+        tmax = t.clone(); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tsum = t.clone(); torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        wall, total_valid = float(tmax[0]), float(tsum[1])
+    else:
+        total_valid = float(valid_frames)
+    assert torch.isfinite(loss).item(), "training step diverged"
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        kern_ms = dev_ms / args.steps                # DP + expand kernels, back to back on the stream
-        algo_bytes = 8.0 * B * T_x * T_y + 8.0 * B   # read fp32 logp once + write fp32 path once
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+        R_dec = wl["B"] * (wl["T_y"] // 2 + 2 * ops.HALO)
+        flops_launch = 2.0 * R_dec * 384 * 192 * 5                   # in_layer 192 -> 384, k = 5, per row
         line = {
-            "metric": "mas_alignments_per_sec",
-            "value": world * B / (wall / args.steps),
-            "unit": "alignments/s",
+            "metric": "mel_frames_per_sec_train_step",
+            "value": total_valid / (wall / args.steps),
+            "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["desc"], "batch_per_gpu": B, "T_x": T_x, "T_y": T_y,
-                       "sharding": f"utterances sharded over {world} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "gt_mas_dp_kernel + gt_mas_expand_kernel",
-                         "algorithmic_bytes_per_launch": algo_bytes, "launch_ms": kern_ms},
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": wl["desc"], "batch_per_gpu": wl["B"], "T_x": wl["T_x"], "T_y": wl["T_y"],
+                       "valid_frames_per_gpu_step": valid_frames, "padded_frames_per_gpu_step": padded_frames,
+                       "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
+                       "sub_graph": "upstream-equivalent live sub-graph of configs/base.json (one WN per coupling block, "
+                                    "deterministic DurationPredictor) — SURVEY F1/F2/F4",
+                       "final_loss": float(loss)},
+            "padded_frames_per_sec": world * padded_frames / (wall / args.steps),
         }
+        if kt["count"]:
+            avg_ms = kt["ms"] / kt["count"]
+            tf = flops_launch / (avg_ms * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                                "kernel": "gt_conv_gemm_kernel<128,true> (WN in_layer k=5 conv + gate, 48 launches/step)",
+                                "algorithmic_flops_per_launch": flops_launch, "launch_ms": avg_ms, "launches_timed": kt["count"]}
+        m = mas_leg(dev, wl, rank)
+        line["mas"] = {"metric": "mas_alignments_per_sec", "value": world * m["alignments_per_sec"], "unit": "alignments/s",
+                       "ms_per_batch": m["ms_per_batch"],
+                       "roofline": {"bound": "hbm", "achieved": m["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": m["hbm_frac"], "traffic": None, "kernel": "gt_mas_dp_kernel + gt_mas_expand_kernel",
+                                    "algorithmic_bytes_per_launch": m["algorithmic_bytes"]}}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_mas(logp, t_x, t_y)
+            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model)
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

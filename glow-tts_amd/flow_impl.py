@@ -112,7 +112,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed):
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True,
-                               drop_p=p, seed=seed + i)
+                               drop_p=p, seed=seed + i, tag="in_layer_gate_conv")
         ts.append(t); ss.append(s); acts_l.append(acts)
         rs = wn.res_skip_layers[i]
         if i < n - 1:

@@ -14,6 +14,43 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class _KernelTimer:
+    """HIP events around every launch carrying a given tag (bench.py: live duration of the dominant
+    kernel inside the timed region, on the stream the kernel is launched on)."""
+
+    def __init__(self):
+        self.tag, self.pairs = None, []
+
+    def enable(self, tag):
+        self.tag, self.pairs = tag, []
+
+    def disable(self):
+        self.tag = None
+
+    def start(self, tag):
+        if self.tag is None or tag != self.tag:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def stop(self, e0):
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((e0, e1))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        out = {"ms": ms, "count": len(self.pairs)}
+        self.tag, self.pairs = None, []
+        return out
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
 class RowsCtx:
     """Geometry of one batch in the rows layout: utterance b owns rows [b*Tp, (b+1)*Tp),
     frame t is row b*Tp + HALO + t; rowmask is 1 on valid frames."""
@@ -72,7 +109,7 @@ class PackedConv:
 
 
 def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=None, out_f32=False,
-              addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None):
+              addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None, tag=None):
     """Y = epilogue(conv(x)) in the rows layout via gt_conv_gemm_bf16.  x: [R, >=Cin] bf16.
     `out`/`addend` may be column-slices of wider row buffers (row stride taken from .stride(0))."""
     L = _lib.lib()
@@ -90,6 +127,7 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
         if gate_t is None:
             gate_t = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
             gate_s = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
+    _ev = KERNEL_TIMER.start(tag)
     rc = L.gt_conv_gemm_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
                              _lib.ptr(cond), 0 if cond is None else cond.stride(0),
                              _lib.ptr(ctx.rowmask) if mask else None,
@@ -98,5 +136,6 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
                              _lib.current_stream(x.device))
+    KERNEL_TIMER.stop(_ev)
     _lib.check(rc, "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate else out
