@@ -27,7 +27,7 @@ PROTOTYPES = {
                                   c_int, c_int, c_float, c_u32, c_void_p]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_void_p]),
     "gt_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

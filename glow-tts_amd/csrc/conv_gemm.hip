@@ -138,27 +138,47 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
 #undef load_X
 #undef store_X
   // ------------------------------------------------------------------ epilogue
+  // Side loads (bias / cond / addend / mask) of one 32-row block are issued as a batch under ONE
+  // uniform branch each, then consumed: a load-and-wait per 4-channel group would serialise ~16
+  // L2 round trips behind the last MFMA.
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int bm = 0; bm < MB; ++bm) {
     const int m = m0 + mrow0 + 32 * bm + r;
-    if (m >= a.R) continue;
-    const float rm = a.rowmask ? a.rowmask[m] : 1.0f;
-    const int b = a.cond ? (m / a.Tp) : 0;
+    const bool mvalid = m < a.R;
+    const int mm = mvalid ? m : a.R - 1;
+    const float rm = a.rowmask ? a.rowmask[mm] : 1.0f;
+    const int b = a.cond ? (mm / a.Tp) : 0;
     if (GATE) {
       const int half = a.N >> 1;
+      const int cb = (n0 >> 1) + 32 * wn + 4 * h;                    // gate channel of group 0 (+ 8g)
+      float4 bt[4] = {z4, z4, z4, z4}, bs[4] = {z4, z4, z4, z4}, ct[4] = {z4, z4, z4, z4}, cs[4] = {z4, z4, z4, z4};
+      if (a.bias) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { bt[g] = *reinterpret_cast<const float4*>(a.bias + cb + 8 * g);
+                                      bs[g] = *reinterpret_cast<const float4*>(a.bias + half + cb + 8 * g); }
+      }
+      if (a.cond) {
+        const float* cp = a.cond + (size_t)b * a.ldc + cb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { ct[g] = *reinterpret_cast<const float4*>(cp + 8 * g);
+                                      cs[g] = *reinterpret_cast<const float4*>(cp + half + 8 * g); }
+      }
+      if (!mvalid) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = (n0 >> 1) + 32 * wn + 8 * g + 4 * h;          // gate channel of element 0
+        const int c = cb + 8 * g;
+        const float bt_[4] = {bt[g].x, bt[g].y, bt[g].z, bt[g].w}, bs_[4] = {bs[g].x, bs[g].y, bs[g].z, bs[g].w};
+        const float ct_[4] = {ct[g].x, ct[g].y, ct[g].z, ct[g].w}, cs_[4] = {cs[g].x, cs[g].y, cs[g].z, cs[g].w};
         float tt[4], ss[4], aa[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float pt = acc[0][bm][4 * g + i], ps = acc[1][bm][4 * g + i];
-          if (a.bias) { pt += a.bias[c + i]; ps += a.bias[half + c + i]; }
+          float pt = acc[0][bm][4 * g + i] + bt_[i], ps = acc[1][bm][4 * g + i] + bs_[i];
           if (a.drop_thresh) {                                       // x_in = drop(conv(x))
             pt = drop_keep(a.drop_seed, m, c + i, a.drop_thresh) ? pt * a.drop_scale : 0.0f;
             ps = drop_keep(a.drop_seed, m, half + c + i, a.drop_thresh) ? ps * a.drop_scale : 0.0f;
           }
-          if (a.cond) { pt += a.cond[(size_t)b * a.ldc + c + i]; ps += a.cond[(size_t)b * a.ldc + half + c + i]; }
+          pt += ct_[i]; ps += cs_[i];
           tt[i] = tanhf_(pt); ss[i] = sigmoidf_(ps); aa[i] = tt[i] * ss[i];
         }
         *reinterpret_cast<uint2*>(a.Tout + (size_t)m * a.ldts + c) = make_uint2(pack2bf(tt[0], tt[1]), pack2bf(tt[2], tt[3]));
@@ -168,33 +188,49 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
       }
     } else {
 #pragma unroll
-      for (int bn = 0; bn < 2; ++bn)
+      for (int bn = 0; bn < 2; ++bn) {
+        const int nb = n0 + 64 * wn + 32 * bn + 4 * h;               // channel of group 0 (+ 8g)
+        int nn[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int n = nb + 8 * g; nn[g] = n < a.N ? n : a.N - 4; }   // clamped load address
+        float4 bb[4] = {z4, z4, z4, z4}, cc[4] = {z4, z4, z4, z4}, ad[4] = {z4, z4, z4, z4};
+        if (a.bias) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const float4*>(a.bias + nn[g]);
+        }
+        if (a.cond) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const float4*>(a.cond + (size_t)b * a.ldc + nn[g]);
+        }
+        if (a.addend) {
+          if (a.out_f32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ad[g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.addend) + (size_t)mm * a.ldadd + nn[g]);
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(a.addend) + (size_t)mm * a.ldadd + nn[g]);
+              ad[g] = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
+            }
+          }
+        }
+        if (!mvalid) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + 64 * wn + 32 * bn + 8 * g + 4 * h;
+          const int n = nb + 8 * g;
           if (n >= a.N) continue;                                    // N % 4 == 0
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = acc[bn][bm][4 * g + i];
-          if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-          if (a.cond) { const float* cp = a.cond + (size_t)b * a.ldc + n; v[0] += cp[0]; v[1] += cp[1]; v[2] += cp[2]; v[3] += cp[3]; }
+          float v[4] = {acc[bn][bm][4 * g] + bb[g].x + cc[g].x, acc[bn][bm][4 * g + 1] + bb[g].y + cc[g].y,
+                        acc[bn][bm][4 * g + 2] + bb[g].z + cc[g].z, acc[bn][bm][4 * g + 3] + bb[g].w + cc[g].w};
           if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
           if (a.drop_thresh) {                                       // dropout after the activation (attentions.py:370)
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = drop_keep(a.drop_seed, m, n + i, a.drop_thresh) ? v[i] * a.drop_scale : 0.0f;
           }
-          if (a.out_f32) {
-            if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n);
-                            v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w; }
-            *reinterpret_cast<float4*>(static_cast<float*>(a.Y) + (size_t)m * a.ldy + n) =
-                make_float4(v[0] * rm, v[1] * rm, v[2] * rm, v[3] * rm);
-          } else {
-            if (a.addend) { const uint2 ad = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(a.addend) + (size_t)m * a.ldadd + n);
-                            v[0] += bf2f(ad.x & 0xffff); v[1] += bf2f(ad.x >> 16); v[2] += bf2f(ad.y & 0xffff); v[3] += bf2f(ad.y >> 16); }
-            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) =
-                make_uint2(pack2bf(v[0] * rm, v[1] * rm), pack2bf(v[2] * rm, v[3] * rm));
-          }
+          v[0] = (v[0] + ad[g].x) * rm; v[1] = (v[1] + ad[g].y) * rm; v[2] = (v[2] + ad[g].z) * rm; v[3] = (v[3] + ad[g].w) * rm;
+          if (a.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(a.Y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+          else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
         }
+      }
     }
   }
 }

@@ -37,17 +37,20 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p0, const bf16_t* p1) 
 template <int TAPS>
 __global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy,
-    float* __restrict__ part, int R, int Cin, int Cout, int slab_rows)
+    float* __restrict__ part, float* __restrict__ part_bias, int R, int Cin, int Cout, int slab_rows)
 {
-  __shared__ __attribute__((aligned(16))) bf16_t Ys[KB * YP];
-  __shared__ __attribute__((aligned(16))) bf16_t Xs[XROWS * XP];
+  __shared__ __attribute__((aligned(16))) bf16_t Ys[2][KB * YP];
+  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][XROWS * XP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64, slab = blockIdx.z;
   const int padl = TAPS >> 1;
   const int mbeg = slab * slab_rows;
   const int mend = min(R, mbeg + slab_rows);
+  const bool do_bias = (blockIdx.y == 0) && part_bias;          // column sums of dY ride along as one more MFMA
 
-  f32x16_t acc[TAPS][2];
+  f32x16_t acc[TAPS][2], accb;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accb[e] = 0.0f;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -60,46 +63,67 @@ __global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
   const int li = lane & 15, q = li >> 2, p = li & 3;
   const int colhalf = ((lane >> 4) & 1) * 16;          // which 16 columns of the 32-wide MFMA block
   const int h = lane >> 5;                             // k half (rows 8h..8h+7 of a 16-row step)
+  typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8_t;
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
-  for (int mb = mbeg; mb < mend; mb += KB) {
-    // ---- stage dY[mb .. mb+64) x [co0 .. co0+128) and X[mb-padl .. mb+64+padl) x [ci0 .. ci0+64)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
-      const int m = mb + row, co = co0 + c8 * 8;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < mend && co < Cout) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
-      *reinterpret_cast<uint4*>(&Ys[row * YP + c8 * 8]) = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-      if (row < KB + TAPS - 1) {
-        const int m = mb - padl + row, ci = ci0 + c8 * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m >= 0 && m < R && ci < Cin) v = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + ci);
-        *reinterpret_cast<uint4*>(&Xs[row * XP + c8 * 8]) = v;
-      }
-    }
-    __syncthreads();
+  // register prefetch of the next 64-row step (named scalars: see conv_gemm.hip)
+  uint4 y0 = {}, y1 = {}, y2 = {}, y3 = {}, x0 = {}, x1 = {}, x2 = {};
+  auto ldy1 = [&](int mb, int i) -> uint4 {
+    const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
+    const int m = mb + row, co = co0 + c8 * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < mend && co < Cout) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
+    return v;
+  };
+  auto ldx1 = [&](int mb, int i) -> uint4 {
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    const int m = mb - padl + row, ci = ci0 + c8 * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < KB + TAPS - 1 && m >= 0 && m < R && ci < Cin) v = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + ci);
+    return v;
+  };
+  auto sty1 = [&](int buf, int i, const uint4& v) {
+    const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
+    *reinterpret_cast<uint4*>(&Ys[buf][row * YP + c8 * 8]) = v;
+  };
+  auto stx1 = [&](int buf, int i, const uint4& v) {
+    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    if (row < KB + TAPS - 1) *reinterpret_cast<uint4*>(&Xs[buf][row * XP + c8 * 8]) = v;
+  };
+#define WG_LOAD(mb)  do { y0 = ldy1(mb, 0); y1 = ldy1(mb, 1); y2 = ldy1(mb, 2); y3 = ldy1(mb, 3); x0 = ldx1(mb, 0); x1 = ldx1(mb, 1); x2 = ldx1(mb, 2); } while (0)
+#define WG_STORE(bf) do { sty1(bf, 0, y0); sty1(bf, 1, y1); sty1(bf, 2, y2); sty1(bf, 3, y3); stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); } while (0)
+
+  if (mbeg < mend) { WG_LOAD(mbeg); WG_STORE(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int mb = mbeg; mb < mend; mb += KB, buf ^= 1) {
+    const bool has = mb + KB < mend;
+    if (has) WG_LOAD(mb + KB);
+    const bf16_t* ysb = Ys[buf];
+    const bf16_t* xsb = Xs[buf];
 #pragma unroll
     for (int ks = 0; ks < KB / 16; ++ks) {
       const int kb = ks * 16 + 8 * h;
       // A: dY^T block (32 co of this wave) — rows kb..kb+7
-      const bf16_t* ya = &Ys[(kb + q) * YP + wave * 32 + colhalf + 4 * p];
+      const bf16_t* ya = ysb + (kb + q) * YP + wave * 32 + colhalf + 4 * p;
       const bf16x8_t af = tr_frag(ya, ya + 4 * YP);
+      if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const bf16_t* xa = &Xs[(kb + t + q) * XP + j * 32 + colhalf + 4 * p];
+          const bf16_t* xa = xsb + (kb + t + q) * XP + j * 32 + colhalf + 4 * p;
           const bf16x8_t bfg = tr_frag(xa, xa + 4 * XP);
           acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfg, acc[t][j], 0, 0, 0);
         }
       }
     }
+    if (has) WG_STORE(buf ^ 1);
     __syncthreads();
   }
+#undef WG_LOAD
+#undef WG_STORE
 
   // ---- slab partial: part[slab][tap][co][ci], lane = ci (128-byte rows per register)
   const int r = lane & 31;
@@ -115,35 +139,49 @@ __global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
         if (co < Cout) part[(((size_t)slab * TAPS + t) * Cout + co) * Cin + ci] = acc[t][j][e];
       }
     }
+  if (do_bias && r == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (co < Cout) part_bias[(size_t)slab * Cout + co] = accb[e];
+    }
+  }
 }
 
 // Sum the S slab partials and map to the parameter gradient(s).  One workgroup per co.
 //   plain conv:   dw[co][ci][tap] (+)= dW
 //   weight-norm:  w = g v / ||v||  =>  dg = <dW, v>/||v|| ;  dv = g/||v|| (dW - v <dW,v>/||v||^2)
+//   bias:         db[co] (+)= sum of the slab column sums
 __global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
-    const float* __restrict__ part, int S, const float* __restrict__ v, const float* __restrict__ g,
-    const float* __restrict__ inv_norm, float* __restrict__ dv, float* __restrict__ dg,
-    int Cout, int Cin, int taps, int accumulate)
+    const float* __restrict__ part, const float* __restrict__ part_bias, int S, const float* __restrict__ v,
+    const float* __restrict__ g, const float* __restrict__ inv_norm, float* __restrict__ dv, float* __restrict__ dg,
+    float* __restrict__ dbias, int Cout, int Cin, int taps, int accumulate)
 {
-  extern __shared__ float dws[];               // [Cin*taps] summed dW of this co, natural order
+  extern __shared__ float dws[];               // [Cin*taps] summed dW of this co, natural (ci, tap) order
   __shared__ float red[4];
   const int co = blockIdx.x, tid = threadIdx.x, n = Cin * taps;
-  float dot = 0.f;
+  if (dbias && tid == 0) {
+    float sb = 0.f;
+    for (int k = 0; k < S; ++k) sb += part_bias[(size_t)k * Cout + co];
+    dbias[co] = accumulate ? dbias[co] + sb : sb;
+  }
+  // coalesced pass over the partials: consecutive threads = consecutive ci of one (slab, tap) row
   for (int i = tid; i < n; i += 256) {
-    const int ci = i / taps, tap = i - ci * taps;
+    const int tap = i / Cin, ci = i - tap * Cin;
     float s = 0.f;
     for (int k = 0; k < S; ++k) s += part[(((size_t)k * taps + tap) * Cout + co) * Cin + ci];
-    dws[i] = s;
-    if (g) dot += s * v[(size_t)co * n + i];
+    dws[ci * taps + tap] = s;
   }
+  __syncthreads();
   if (!g) {
-    __syncthreads();
     for (int i = tid; i < n; i += 256) {
       const size_t o = (size_t)co * n + i;
       dv[o] = accumulate ? dv[o] + dws[i] : dws[i];
     }
     return;
   }
+  float dot = 0.f;
+  for (int i = tid; i < n; i += 256) dot += dws[i] * v[(size_t)co * n + i];
   dot = wave_sum(dot);
   if ((tid & 63) == 0) red[tid >> 6] = dot;
   __syncthreads();
@@ -189,7 +227,7 @@ extern "C" size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int ta
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
   if (slabs_out) *slabs_out = S;
-  return (size_t)S * taps * Cout * Cin * sizeof(float);
+  return ((size_t)S * taps * Cout * Cin + (size_t)S * Cout) * sizeof(float);     // weight partials | bias partials
 }
 
 extern "C" int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, int Cin, int Cout,
@@ -207,14 +245,15 @@ extern "C" int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ld
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bf16_t* x = static_cast<const bf16_t*>(X); const bf16_t* dy = static_cast<const bf16_t*>(dY);
   float* part = static_cast<float*>(workspace);
-  if (taps == 5)      hipLaunchKernelGGL(gt_conv_wgrad_kernel<5>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
-  else if (taps == 3) hipLaunchKernelGGL(gt_conv_wgrad_kernel<3>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
-  else                hipLaunchKernelGGL(gt_conv_wgrad_kernel<1>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, R, Cin, Cout, slab_rows);
+  float* pb = part + (size_t)S * taps * Cout * Cin;
+  if (taps == 5)      hipLaunchKernelGGL(gt_conv_wgrad_kernel<5>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
+  else if (taps == 3) hipLaunchKernelGGL(gt_conv_wgrad_kernel<3>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
+  else                hipLaunchKernelGGL(gt_conv_wgrad_kernel<1>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
   return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
 }
 
 extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
-                                 float* dv, float* dg, int Cout, int Cin, int taps, int accumulate, void* stream)
+                                 float* dv, float* dg, float* dbias, int Cout, int Cin, int taps, int accumulate, void* stream)
 {
   if (!workspace || !v || !dv || Cout <= 0 || Cin <= 0 || taps <= 0) return GT_E_INVAL;
   if (g && (!inv_norm || !dg)) return GT_E_INVAL;
@@ -222,8 +261,9 @@ extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, c
   gt_conv_wgrad_workspace_bytes(R, Cin, Cout, taps, &S);
   const size_t lds = (size_t)Cin * taps * sizeof(float);
   if (lds > 60 * 1024) return GT_E_UNSUPPORTED;
+  const float* part = static_cast<const float*>(workspace);
   hipLaunchKernelGGL(gt_weightnorm_bwd_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     static_cast<const float*>(workspace), S, v, g, inv_norm, dv, dg, Cout, Cin, taps, accumulate);
+                     part, part + (size_t)S * taps * Cout * Cin, S, v, g, inv_norm, dv, dg, dbias, Cout, Cin, taps, accumulate);
   return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
 }
 

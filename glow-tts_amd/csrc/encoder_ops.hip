@@ -533,8 +533,8 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
-  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 64;
-  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 63) / 64), dim3(256), 0, GT_ST(stream), q);
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 16;
+  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 15) / 16), dim3(256), 0, GT_ST(stream), q);
   GT_RET();
 }
 

@@ -187,26 +187,37 @@ __global__ void gt_flow_logdet_bwd_kernel(const float* __restrict__ scal, const 
 
 // ------------------------------------------------------------------ affine coupling
 // out = [m | logs] ([R, C] fp32 from the `end` conv), x = [x0 | x1]:
-//   z = [x0 | (m + exp(logs) * x1) * mask],  logdet[b] += sum logs*mask.   One wave per row.
+//   z = [x0 | (m + exp(logs) * x1) * mask],  logdet[b] += sum logs*mask.
+// One workgroup per (64-row chunk, utterance): a wave walks 16 rows, the log-det of the chunk is
+// reduced in registers/LDS and leaves as ONE atomic per workgroup (per-row atomics onto B addresses
+// serialise: guide G12).
 __global__ __launch_bounds__(256) void gt_coupling_fwd_kernel(const float* __restrict__ out, const float* __restrict__ x,
                                                               float* __restrict__ z, const float* __restrict__ rowmask,
                                                               float* __restrict__ logdet, int R, int C, int Tp, int sigmoid_scale)
 {
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, half = C >> 1;
-  if (m >= R) return;
-  const float rm = rowmask[m];
+  __shared__ float red[4];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = C >> 1;
+  const int t0 = blockIdx.x * 64 + w * 16;
   float s = 0.f;
-  for (int c = lane; c < half; c += 64) {
-    const float mm = out[(size_t)m * C + c];
-    float lg = out[(size_t)m * C + half + c];
-    if (sigmoid_scale) lg = __logf(1e-6f + sigmoidf_(lg + 2.0f));
-    const float x1 = x[(size_t)m * C + half + c];
-    z[(size_t)m * C + c] = x[(size_t)m * C + c];
-    z[(size_t)m * C + half + c] = (mm + __expf(lg) * x1) * rm;
-    s += lg * rm;
+  for (int tt = 0; tt < 16; ++tt) {
+    const int t = t0 + tt;
+    if (t >= Tp) break;
+    const int m = b * Tp + t;
+    const float rm = rowmask[m];
+    for (int c = lane; c < half; c += 64) {
+      const float mm = out[(size_t)m * C + c];
+      float lg = out[(size_t)m * C + half + c];
+      if (sigmoid_scale) lg = __logf(1e-6f + sigmoidf_(lg + 2.0f));
+      const float x1 = x[(size_t)m * C + half + c];
+      z[(size_t)m * C + c] = x[(size_t)m * C + c];
+      z[(size_t)m * C + half + c] = (mm + __expf(lg) * x1) * rm;
+      s += lg * rm;
+    }
   }
   s = wave_sum(s);
-  if (lane == 0 && rm != 0.f) atomicAdd(logdet + m / Tp, s);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float tot = red[0] + red[1] + red[2] + red[3]; if (tot != 0.f) atomicAdd(logdet + b, tot); }
 }
 
 // backward: dz -> dx (x0 part passed through, the start-conv contribution is added later),
@@ -355,7 +366,8 @@ extern "C" int gt_coupling_fwd(const float* out, const float* x, float* z, const
                                int R, int C, int Tp, int sigmoid_scale, void* stream)
 {
   if (!out || !x || !z || !rowmask || !logdet || R <= 0 || (C & 1)) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_coupling_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), out, x, z, rowmask, logdet, R, C, Tp, sigmoid_scale);
+  if (Tp <= 0 || R % Tp) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_coupling_fwd_kernel, dim3((Tp + 63) / 64, R / Tp), dim3(256), 0, GT_ST(stream), out, x, z, rowmask, logdet, R, C, Tp, sigmoid_scale);
   GT_RET();
 }
 extern "C" int gt_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const float* rowmask,

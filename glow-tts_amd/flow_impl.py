@@ -45,20 +45,18 @@ def conv_param_grads(conv, x, dy, R, want_bias=True):
     out = {}
     v = conv.weight_v if conv.weight_norm else conv.weight
     dv = torch.empty_like(v)
+    db = torch.empty_like(conv.bias) if (want_bias and conv.bias is not None) else None
     if conv.weight_norm:
         dg = torch.empty_like(conv.weight_g)
         _lib.check(L.gt_weightnorm_bwd(_lib.ptr(ws), R, _lib.ptr(v), _lib.ptr(conv.weight_g), _lib.ptr(pc.inv_norm),
-                                       _lib.ptr(dv), _lib.ptr(dg), pc.Cout, pc.Cin, pc.taps, 0, _st(dev)), "gt_weightnorm_bwd")
+                                       _lib.ptr(dv), _lib.ptr(dg), _lib.ptr(db), pc.Cout, pc.Cin, pc.taps, 0, _st(dev)), "gt_weightnorm_bwd")
         out[conv.weight_v] = dv
         out[conv.weight_g] = dg
     else:
-        _lib.check(L.gt_weightnorm_bwd(_lib.ptr(ws), R, _lib.ptr(v), None, None, _lib.ptr(dv), None,
+        _lib.check(L.gt_weightnorm_bwd(_lib.ptr(ws), R, _lib.ptr(v), None, None, _lib.ptr(dv), None, _lib.ptr(db),
                                        pc.Cout, pc.Cin, pc.taps, 0, _st(dev)), "gt_weightnorm_bwd")
         out[conv.weight] = dv
-    if want_bias and conv.bias is not None:
-        db = torch.zeros_like(conv.bias)
-        _lib.check(L.gt_colsum(_lib.ptr(dy), dy.stride(0), int(dy.dtype == torch.float32), _lib.ptr(db), R, pc.Cout, _st(dev)),
-                   "gt_colsum")
+    if db is not None:
         out[conv.bias] = db
     return out
 

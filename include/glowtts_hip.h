@@ -135,9 +135,11 @@ int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, i
 
 /* Reduce the wgrad workspace and map it onto the parameter gradient(s) in the parameter's own
  * [Cout, Cin, taps] layout: plain conv (g == NULL): dv (+)= dW; weight-normed conv
- * (torch weight_norm dim 0): dg = <dW,v>/||v||, dv = g/||v|| (dW - v <dW,v>/||v||^2). */
+ * (torch weight_norm dim 0): dg = <dW,v>/||v||, dv = g/||v|| (dW - v <dW,v>/||v||^2).
+ * dbias (optional) receives the bias gradient: the wgrad kernel also leaves the column sums of dY
+ * per slab in the workspace (one extra MFMA against a ones operand). */
 int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
-                      float* dv, float* dg, int Cout, int Cin, int taps, int accumulate, void* stream);
+                      float* dv, float* dg, float* dbias, int Cout, int Cin, int taps, int accumulate, void* stream);
 
 /* out[n] += sum_m Y[m,n]  (bias gradients); Y bf16 (is_f32 == 0) or fp32 rows. */
 int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void* stream);
