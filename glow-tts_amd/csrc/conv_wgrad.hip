@@ -12,6 +12,7 @@
 // partials go to a workspace [S][taps][Cout][Cin] with plain 128-byte-coalesced stores (float
 // atomics would cap at ~1.3 TB/s) and are summed by the weight-norm backward kernel, which then
 // maps dW to (dv, dg) or to a plain dw in the parameter's own [Cout, Cin, taps] layout.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/glowtts_hip.h"
 
@@ -221,8 +222,12 @@ extern "C" size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int ta
 {
   if (R <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0) { if (slabs_out) *slabs_out = 0; return 0; }
   const int tiles = ((Cout + 127) / 128) * ((Cin + 63) / 64);
-  int S = (256 + tiles - 1) / tiles;            // ~one workgroup per CU
-  if (S > 32) S = 32;
+  // slabs: enough workgroups to cover the chip, but every slab costs one full dW of partial traffic
+  // (written here, re-read by gt_weightnorm_bwd) — GT_WGRAD_WGS workgroups in total, at most 16 slabs
+  static int target = 0;
+  if (!target) { const char* e = getenv("GT_WGRAD_WGS"); target = e ? atoi(e) : 160; if (target < 1) target = 160; }
+  int S = (target + tiles - 1) / tiles;
+  if (S > 16) S = 16;
   const int max_s = (R + KB - 1) / KB;
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;

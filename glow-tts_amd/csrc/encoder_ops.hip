@@ -462,13 +462,30 @@ __global__ __launch_bounds__(256) void gt_prior_expand_bwd_kernel(const float* _
 __global__ __launch_bounds__(256) void gt_mle_sums_kernel(const float* __restrict__ z, const float* __restrict__ m,
                                                           const float* __restrict__ logs, float* __restrict__ acc, size_t n)
 {
+  __shared__ float red[2][4];
   float a0 = 0.f, a1 = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float l = logs ? logs[i] : 0.f, d = z[i] - m[i];
-    a0 += l; a1 += __expf(-2.0f * l) * d * d;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 zz = reinterpret_cast<const float4*>(z)[i], mm = reinterpret_cast<const float4*>(m)[i];
+    float4 ll = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (logs) ll = reinterpret_cast<const float4*>(logs)[i];
+    const float d0 = zz.x - mm.x, d1 = zz.y - mm.y, d2 = zz.z - mm.z, d3 = zz.w - mm.w;
+    a0 += ll.x + ll.y + ll.z + ll.w;
+    a1 += __expf(-2.0f * ll.x) * d0 * d0 + __expf(-2.0f * ll.y) * d1 * d1 + __expf(-2.0f * ll.z) * d2 * d2 + __expf(-2.0f * ll.w) * d3 * d3;
+  }
+  if (blockIdx.x == 0) {
+    for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      const float l = logs ? logs[i] : 0.f, d = z[i] - m[i];
+      a0 += l; a1 += __expf(-2.0f * l) * d * d;
+    }
   }
   a0 = wave_sum(a0); a1 = wave_sum(a1);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(acc, a0); atomicAdd(acc + 1, a1); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a0; red[1][threadIdx.x >> 6] = a1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {                                   // one atomic pair per workgroup
+    atomicAdd(acc, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(acc + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
 }
 // dz = g * exp(-2 logs) (z-m);  dm = -dz;  dlogs = g * (1 - exp(-2 logs)(z-m)^2)   with g = *gscale
 __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ m,
@@ -629,7 +646,8 @@ extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, fl
 {
   if (!z || !m || !acc2) return GT_E_INVAL;
   if (n == 0) return GT_OK;
-  size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  if (((uintptr_t)z | (uintptr_t)m | (uintptr_t)logs) & 15) return GT_E_ALIGN;
+  size_t blocks = (n / 4 + 255) / 256; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gt_mle_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, acc2, n);
   GT_RET();
 }
