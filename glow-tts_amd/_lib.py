@@ -62,9 +62,20 @@ PROTOTYPES = {
     "gt_prior_expand_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_mle_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gt_mle_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gt_pack_conv_weights_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gt_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
+
+
+
+class PackDesc(ctypes.Structure):
+    """struct gt_pack_desc (include/glowtts_hip.h)"""
+    _fields_ = [("v", c_void_p), ("g", c_void_p), ("pack_fwd", c_void_p), ("pack_dgrad", c_void_p), ("inv_norm", c_void_p),
+                ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("Np_fwd", ctypes.c_int32),
+                ("Kp_fwd", ctypes.c_int32), ("Np_dgrad", ctypes.c_int32), ("Kp_dgrad", ctypes.c_int32), ("gate", ctypes.c_int32),
+                ("row_start", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
 
 GT_DT_F32, GT_DT_I32, GT_DT_F16, GT_DT_BF16, GT_DT_U8 = 0, 1, 2, 3, 4
 GT_ERRORS = {-1: "GT_E_INVAL", -2: "GT_E_UNSUPPORTED", -3: "GT_E_ALIGN", -4: "GT_E_LAUNCH"}

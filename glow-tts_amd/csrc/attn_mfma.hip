@@ -1,0 +1,249 @@
+// Relative-position multi-head attention forward on bf16 MFMA for gfx950 (reference
+// attentions.py:241-336 in its 9-diagonal band form; D = 96, window 4, T <= 256).
+//
+// One workgroup = 4 waves = 128 query rows of one (utterance, head); K and V of that (utterance,
+// head) are staged once in LDS.  Per wave (32 query rows), everything stays in registers:
+//   S^T = K Q^T            MFMA A = K rows from LDS (ds_read_b128, pitch 208 B), B = Q^T fragments loaded
+//                          straight from HBM; a lane then owns ONE query and 16 keys per 32-key tile, so
+//                          the softmax row reductions are in-lane + one xor-32 exchange.
+//   QE  = Ek Q^T           the relative-key logits q_i.Ek[r] as one more MFMA chain (Ek padded to 32 rows)
+//   P   = softmax((S^T + band(QE)) / sqrt(D)), saved fp32 for the backward, dropout replayable
+//   O^T = V^T P^T          "accumulator tile as the next MFMA's operand" (guide §3): P^T registers are
+//                          converted pairwise to bf16 and fed as B; V^T comes from LDS through
+//                          ds_read_b64_tr_b16 (pitch 192 B) in the permuted k order that map requires.
+//   O^T += Ev^T band(P)^T  the relative-value term as one K=16 MFMA per 32 channels.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+#include "internal.h"
+
+namespace {
+
+constexpr int HALO = GT_HALO;
+constexpr int D = 96, WIN = 4, NW = 9;
+constexpr int KP = 104;            // K / Ek pitch in halfs (208 B): conflict-free ds_read_b128 over 16 rows
+constexpr int VP = 96;             // V pitch in halfs (192 B): conflict-free transposing reads
+
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4_t;
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8_t;
+
+__device__ __forceinline__ bf16x8_t tr_frag8(const bf16_t* p0, const bf16_t* p1) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)p1);
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t pack8(const float* f) {
+  const uint4 u = make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+template <int NT>   // key tiles of 32 (T <= 32*NT)
+__global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
+    const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
+    bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
+    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TPAD = NT * 32;
+  bf16_t* Ks  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]
+  bf16_t* Vs  = Ks + TPAD * KP;                                  // [TPAD][VP]
+  bf16_t* Eks = Vs + TPAD * VP;                                  // [32][KP]   rows >= 9 are zero
+  bf16_t* EvT = Eks + 32 * KP;                                   // [96][16]   EvT[d][r], r >= 9 zero
+  float*  QE  = reinterpret_cast<float*>(EvT + D * 16);          // [4 waves][32][NW]
+  bf16_t* PB  = reinterpret_cast<bf16_t*>(QE + 4 * 32 * NW);     // [4 waves][32][16]
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int len = lens[b];
+  const size_t rbase = (size_t)b * Tp + HALO;
+
+  // ---- stage K, V (zero rows >= T), Ek, Ev^T
+  for (int i = tid; i < TPAD * (D / 8); i += 256) {
+    const int j = i / (D / 8), c8 = i - j * (D / 8);
+    uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+    if (j < T) {
+      kk = *reinterpret_cast<const uint4*>(k + (rbase + j) * ld + h * D + c8 * 8);
+      vv = *reinterpret_cast<const uint4*>(v + (rbase + j) * ld + h * D + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(Ks + j * KP + c8 * 8) = kk;
+    *reinterpret_cast<uint4*>(Vs + j * VP + c8 * 8) = vv;
+  }
+  for (int i = tid; i < 32 * D; i += 256) { const int rr = i / D, c = i - rr * D; Eks[rr * KP + c] = rr < NW ? f2bf(Ek[rr * D + c]) : (bf16_t)0; }
+  for (int i = tid; i < D * 16; i += 256) { const int d = i >> 4, rr = i & 15; EvT[i] = rr < NW ? f2bf(Ev[rr * D + d]) : (bf16_t)0; }
+  for (int i = tid; i < 4 * 32 * 16; i += 256) PB[i] = 0;
+  __syncthreads();
+
+  const int i0 = blockIdx.x * 128 + 32 * w;
+  if (i0 >= T) return;                                           // wave-uniform, after the only block barrier
+  const int i = i0 + r;                                          // this lane's query
+  const int ic = i < T ? i : T - 1;
+  float* qe = QE + w * 32 * NW;
+  bf16_t* pb = PB + w * 32 * 16;
+
+  // ---- Q^T fragments straight from HBM: lane (query r, k-half hh), 6 k-steps of 16 channels
+  bf16x8_t qf[6];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(q + (rbase + ic) * ld + h * D + ks * 16 + 8 * hh);
+
+  // ---- QE = Ek Q^T  (rows r' < 9 used)
+  {
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Eks + r * KP + ks * 16 + 8 * hh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[ks], acc, 0, 0, 0);
+    }
+    // D layout: column = query (lane&31), row r' = (e&3) + 8*(e>>2) + 4*hh
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qe[r * NW + e + 4 * hh] = acc[e];
+    if (hh == 0) qe[r * NW + 8] = acc[4];
+  }
+
+  // ---- S^T = K Q^T
+  f32x16_t s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Ks + (32 * t + r) * KP + ks * 16 + 8 * hh);
+      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[ks], s[t], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                               // qe written by both lane halves
+
+  // ---- softmax over keys (in-lane + xor 32)
+  const float inv_sqrt = rsqrtf((float)D);
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      float sc = s[t][e];
+      const int rel = j - i + WIN;
+      if ((unsigned)rel <= 2u * WIN) sc += qe[r * NW + rel];
+      sc *= inv_sqrt;
+      if (j >= T) sc = -3.0e38f;                                 // not a key at all
+      else if (j >= len || i >= len) sc = -1e4f;                 // masked_fill(mask == 0, -1e4), attentions.py:260
+      s[t][e] = sc;
+      mx = fmaxf(mx, sc);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { const float ex = __expf(s[t][e] - mx); s[t][e] = ex; den += ex; }
+  den += __shfl_xor(den, 32);
+  const float rden = 1.0f / den;
+  float* prow = Pout + (((size_t)b * H + h) * T + ic) * T;
+  const uint32_t drow = (uint32_t)((b * H + h) * T + i);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j0 = 32 * t + 8 * g + 4 * hh;
+      float p4[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) p4[e2] = s[t][4 * g + e2] * rden;
+      if (i < T) {
+        if (j0 + 3 < T && (T & 3) == 0) *reinterpret_cast<float4*>(prow + j0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+        else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) prow[j0 + e2] = p4[e2];
+        }
+      }
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int j = j0 + e2;
+        float pd = p4[e2];
+        if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
+        s[t][4 * g + e2] = pd;
+        const int rel = j - i + WIN;
+        if ((unsigned)rel <= 2u * WIN && j < T) pb[r * 16 + rel] = f2bf(pd);
+      }
+    }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- O^T = V^T P^T (+ Ev^T band(P)^T)
+  const int li = lane & 15, qd = li >> 2, pp = li & 3, colhalf = ((lane >> 4) & 1) * 16;
+  f32x16_t o[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float f8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f8[e] = s[t][8 * s2 + e];
+      const bf16x8_t pf = pack8(f8);                             // k order: row 16*s2 + 8*(e>>2) + 4*hh + (e&3) of the tile
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const bf16_t* va = Vs + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+        const bf16x8_t af = tr_frag8(va, va + 8 * VP);           // V^T[d][keys 4hh..4hh+3 | 8+4hh..8+4hh+3]
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+      }
+    }
+  {
+    const bf16x8_t bfp = *reinterpret_cast<const bf16x8_t*>(pb + r * 16 + 8 * hh);      // band(P)^T: k = rel
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(EvT + (32 * dt + r) * 16 + 8 * hh);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfp, o[dt], 0, 0, 0);
+    }
+  }
+  if (i < T) {
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * hh;
+        *reinterpret_cast<uint2*>(out + (rbase + i) * ldo + h * D + d) =
+            make_uint2(pack2bf(o[dt][4 * g], o[dt][4 * g + 1]), pack2bf(o[dt][4 * g + 2], o[dt][4 * g + 3]));
+      }
+  }
+}
+
+template <int NT>
+int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
+               bf16_t* out, int ldo, float* P, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, hipStream_t st)
+{
+  constexpr int TPAD = NT * 32;
+  const size_t lds = (size_t)TPAD * KP * 2 + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 4 * 32 * NW * 4 + 4 * 32 * 16 * 2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_fwd_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return GT_E_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gt_attn_fwd_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds, st,
+                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, H, th, sd, sc);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
+}  // namespace
+
+// returns 1 if the shape is not handled here (caller falls back to the generic kernel)
+int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                          const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int Dh, int win,
+                          uint32_t th, uint32_t sd, float sc, void* stream)
+{
+  if (Dh != D || win != WIN || T > 256 || (ld & 7) || (ldo & 3)) return 1;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bf16_t* qq = static_cast<const bf16_t*>(q); const bf16_t* kk = static_cast<const bf16_t*>(k); const bf16_t* vv = static_cast<const bf16_t*>(v);
+  bf16_t* oo = static_cast<bf16_t*>(out);
+  if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, st);
+  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, st);
+}

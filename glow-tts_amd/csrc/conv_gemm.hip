@@ -242,12 +242,11 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
 //   dgrad Pd[taps-1-tap][ci][co]           (data-gradient conv: roles swapped, taps flipped)
 // One workgroup per output channel.  Padding entries of Pf/Pd are never written (callers zero
 // the buffers once).
-__global__ __launch_bounds__(256) void gt_pack_conv_weights_kernel(
+__device__ __forceinline__ void pack_one_row(
     const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
-    float* __restrict__ inv_norm, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate)
+    float* __restrict__ inv_norm, int co, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate, float* red)
 {
-  __shared__ float red[4];
-  const int co = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int n = Cin * taps;
   const float* vr = v + (size_t)co * n;
   float scale = 1.0f;
@@ -274,6 +273,26 @@ __global__ __launch_bounds__(256) void gt_pack_conv_weights_kernel(
     if (Pf) Pf[((size_t)tap * Npf + pn) * Kpf + ci] = w;
     if (Pd) Pd[((size_t)(taps - 1 - tap) * Npd + ci) * Kpd + co] = w;
   }
+}
+
+__global__ __launch_bounds__(256) void gt_pack_conv_weights_kernel(
+    const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
+    float* __restrict__ inv_norm, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate)
+{
+  __shared__ float red[4];
+  pack_one_row(v, g, Pf, Pd, inv_norm, blockIdx.x, Cout, Cin, taps, Npf, Kpf, Npd, Kpd, gate, red);
+}
+
+// every conv of a model in ONE launch: block -> (conv, output channel) through a prefix table
+__global__ __launch_bounds__(256) void gt_pack_conv_weights_multi_kernel(const gt_pack_desc* __restrict__ descs, int n)
+{
+  __shared__ float red[4];
+  int lo = 0, hi = n - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].row_start <= blk) lo = mid; else hi = mid - 1; }
+  const gt_pack_desc d = descs[lo];
+  pack_one_row(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, blk - d.row_start,
+               d.Cout, d.Cin, d.taps, d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, red);
 }
 
 }  // namespace
@@ -331,5 +350,13 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
   hipLaunchKernelGGL(gt_pack_conv_weights_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream),
                      v, g, static_cast<bf16_t*>(pack_fwd), static_cast<bf16_t*>(pack_dgrad), inv_norm,
                      Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
+extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, void* stream)
+{
+  if (!descs_device || n_convs <= 0 || total_rows <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_pack_conv_weights_multi_kernel, dim3(total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const gt_pack_desc*>(descs_device), n_convs);
   return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
 }

@@ -5,8 +5,10 @@
 //   logp lattice                                    models.py:1076-1082
 //   prior expansion (gather) + mle loss             models.py:1118-1119, commons.py:28-33
 // fp32 math throughout; bf16 only for tensors that feed MFMA GEMMs.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/glowtts_hip.h"
+#include "internal.h"
 
 namespace {
 
@@ -567,6 +569,14 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
 {
   if (!q || !k || !v || !Ek || !Ev || !lens || !out || !P || B <= 0 || T <= 0 || H <= 0) return GT_E_INVAL;
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
+  {
+    uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
+    static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
+    if (!no_mfma) {
+      const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, H, D, win, th, sd, sc, stream);
+      if (rc != 1) return rc;                      // handled (or failed loudly) on the MFMA path
+    }
+  }
   const size_t lds = attn_lds(T, D, win, (size_t)4 * D + (size_t)AT_QT * T);
   if (lds > 160 * 1024) return GT_E_UNSUPPORTED;
   static bool attr = false;

@@ -1,0 +1,9 @@
+// Cross-translation-unit helpers that are NOT part of the C-ABI (include/glowtts_hip.h).
+#pragma once
+#include <stdint.h>
+
+// MFMA attention forward for the configuration every reference config uses (D = 96, window 4) and
+// T <= 256; returns 1 when the shape is not handled (caller falls back to the generic kernel).
+int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                          const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int Dh, int win,
+                          uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, void* stream);

@@ -42,10 +42,16 @@ class ConvP(nn.Module):
     def _new_pc(self, Cout=None):
         return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device)
 
-    def prepare(self):
-        """(Re)pack the current weights for the MFMA kernels — once per optimizer step."""
+    def _ensure_pcs(self):
         if self._pc is None or self._pc.fwd.device != self.weight.device:
             self._pc = self._new_pc()
+
+    def _pack_entries(self):
+        return [(self.weight, None, self._pc)]
+
+    def prepare(self):
+        """(Re)pack the current weights for the MFMA kernels — once per optimizer step."""
+        self._ensure_pcs()
         self._pc.pack(self.weight, None)
         return self
 
@@ -63,7 +69,7 @@ class WNConvP(ConvP):
         self.split_res_skip = split_res_skip
         self.pc_res = self.pc_skip = None
 
-    def prepare(self):
+    def _ensure_pcs(self):
         dev = self.weight_v.device
         if self._pc is None or self._pc.fwd.device != dev:
             self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev)
@@ -71,6 +77,16 @@ class WNConvP(ConvP):
                 h = self.out_channels // 2
                 self.pc_res = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
                 self.pc_skip = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
+
+    def _pack_entries(self):
+        out = [(self.weight_v, self.weight_g, self._pc)]
+        if self.split_res_skip:
+            h = self.out_channels // 2
+            out += [(self.weight_v[:h], self.weight_g[:h], self.pc_res), (self.weight_v[h:], self.weight_g[h:], self.pc_skip)]
+        return out
+
+    def prepare(self):
+        self._ensure_pcs()
         self._pc.pack(self.weight_v, self.weight_g)
         if self.split_res_skip:
             h = self.out_channels // 2
@@ -79,10 +95,59 @@ class WNConvP(ConvP):
         return self
 
 
+class _PackPlan:
+    """All conv weights of a module tree packed by ONE kernel launch (gt_pack_conv_weights_multi).
+    The descriptor table lives on the device and is rebuilt only when a parameter's storage moves."""
+
+    def __init__(self, module):
+        import ctypes
+        entries = []                                     # (v, g, PackedConv)
+        for m in module.modules():
+            if isinstance(m, ConvP):
+                m._ensure_pcs()
+                entries += m._pack_entries()
+            elif hasattr(m, "_pack_entries_extra"):
+                entries += m._pack_entries_extra()
+        self.n = len(entries)
+        self.key = tuple(e[0].data_ptr() for e in entries)
+        self.keep = entries
+        if self.n == 0:
+            return
+        arr = (_lib.PackDesc * self.n)()
+        row = 0
+        for d, (v, g, pc) in zip(arr, entries):
+            d.v, d.g = v.data_ptr(), (g.data_ptr() if g is not None else None)
+            d.pack_fwd, d.pack_dgrad, d.inv_norm = pc.fwd.data_ptr(), pc.dgrad.data_ptr(), pc.inv_norm.data_ptr()
+            d.Cout, d.Cin, d.taps = pc.Cout, pc.Cin, pc.taps
+            d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, int(pc.gate), row
+            row += pc.Cout
+        self.rows = row
+        dev = entries[0][0].device
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.table = raw.to(dev)
+
+    def run(self):
+        if self.n == 0:
+            return
+        dev = self.keep[0][0].device
+        _lib.check(_lib.lib().gt_pack_conv_weights_multi(_lib.ptr(self.table), self.n, self.rows, _lib.current_stream(dev)),
+                   "gt_pack_conv_weights_multi")
+
+
 def prepare_all(module):
+    """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step."""
     for m in module.modules():
-        if isinstance(m, ConvP):
-            m.prepare()
+        if hasattr(m, "_refresh_padded"):
+            m._refresh_padded()
+    plan = getattr(module, "_pack_plan", None)
+    if plan is not None:
+        cur = tuple(e[0].data_ptr() for e in plan.keep)
+        if cur != plan.key:
+            plan = None
+    if plan is None:
+        plan = _PackPlan(module)
+        object.__setattr__(module, "_pack_plan", plan)
+    plan.run()
 
 
 class _RowsFn(torch.autograd.Function):

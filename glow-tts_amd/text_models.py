@@ -20,21 +20,25 @@ from .ops import HALO, PackedConv, RowsCtx
 
 
 class _PaddedConv:
-    """An [1, C, 1] projection run as an 8-channel conv (MFMA tiles want N % 8 == 0)."""
+    """An [1, C, 1] projection run as an 8-channel conv (MFMA tiles want N % 8 == 0).  The padded
+    weight/bias live in persistent buffers refreshed in place, so the pack table's pointers stay valid."""
     weight_norm = False
 
     def __init__(self, conv):
         self.conv, self.pc, self.weight, self.bias = conv, None, None, None
 
-    def prepare(self):
+    def refresh(self):
         c = self.conv
         dev = c.weight.device
         if self.pc is None or self.pc.fwd.device != dev:
             self.pc = PackedConv(8, c.in_channels, c.kernel_size, False, device=dev)
-        self.weight = torch.zeros(8, c.in_channels, c.kernel_size, device=dev)
-        self.weight[:1] = c.weight.detach()
-        self.bias = torch.zeros(8, device=dev)
-        self.bias[:1] = c.bias.detach()
+            self.weight = torch.zeros(8, c.in_channels, c.kernel_size, device=dev)
+            self.bias = torch.zeros(8, device=dev)
+        self.weight[:1].copy_(c.weight.detach())
+        self.bias[:1].copy_(c.bias.detach())
+
+    def prepare(self):
+        self.refresh()
         self.pc.pack(self.weight, None)
 
 
@@ -50,8 +54,14 @@ class DurationPredictor(nn.Module):
         self.proj = ConvP(filter_channels, 1, 1)
         self.proj_pad = _PaddedConv(self.proj)
 
+    def _refresh_padded(self):
+        self.proj_pad.refresh()
+
+    def _pack_entries_extra(self):
+        return [(self.proj_pad.weight, None, self.proj_pad.pc)]
+
     def prepare_extra(self):
-        self.proj_pad.prepare()
+        pass
 
 
 class TextEncoder(nn.Module):

@@ -125,6 +125,14 @@ int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* p
                          float* inv_norm, int Cout, int Cin, int taps,
                          int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
 
+/* The same for every conv of a model in ONE launch: `descs_device` is a device array of n_convs
+ * descriptors sorted by row_start (row_start = prefix sum of Cout), total_rows = sum of Cout. */
+typedef struct gt_pack_desc {
+  const float* v; const float* g; void* pack_fwd; void* pack_dgrad; float* inv_norm;
+  int32_t Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate, row_start, pad_;
+} gt_pack_desc;
+int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, void* stream);
+
 /* Weight gradient of the rows-layout convolution: partial sums over S row slabs into
  * workspace [S][taps][Cout][Cin] fp32 (S from gt_conv_wgrad_workspace_bytes), bf16 MFMA with
  * transposing LDS reads.  dW[tap][co][ci] = sum_m dY[m,co] * X[m + tap - k/2, ci].
