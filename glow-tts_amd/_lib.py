@@ -52,8 +52,9 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
+    "gt_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gt_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                            c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
     "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -232,7 +232,366 @@ int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
 }
 
+// =========================================================================================
+// Backward.  Pass 1 (per 32-query block, same wave/lane mapping as the forward):
+//   dPd^T = V dO^T (+ band: Ev dO^T)      dP = dropout'(dPd)       Dsum_i = sum_j dP P
+//   dS^T  = P (dP - Dsum) / sqrt(D), masked entries 0
+//   dQ^T  = K^T dS^T + Ek^T band(dS)^T     (accumulator-as-operand, K^T through transposing reads)
+//   dEk  += band(dS)^T Q,  dEv += band(dropout(P))^T dO   (MFMA over the 32 queries of the wave)
+//   dS^T and dropout(P)^T leave as bf16 [B,H,T,TI] (query index contiguous) for pass 2.
+// Pass 2 (per 32-key block): dK^T = Q^T dS, dV^T = dO^T dropout(P) with Q^T / dO^T through
+// transposing reads of LDS-staged Q / dO and the B operands straight from the pass-1 buffers.
+constexpr int BTP = 40;            // pitch (halfs) of the transposed band tables [16][32 + pad]
+
+template <int NT, int WV>
+__global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
+    const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
+    const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
+    bf16_t* __restrict__ dST, bf16_t* __restrict__ PdT, int TI,
+    bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
+    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TPAD = NT * 32, NTH = 64 * WV;
+  bf16_t* Vs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]  A of dPd^T (ds_read_b128)
+  bf16_t* Ks  = Vs + TPAD * KP;                                  // [TPAD][VP]  A of dQ^T (transposing reads)
+  bf16_t* Evs = Ks + TPAD * VP;                                  // [32][KP]    rows >= 9 zero
+  bf16_t* EkT = Evs + 32 * KP;                                   // [96][16]
+  float*  Acc = reinterpret_cast<float*>(EkT + D * 16);          // [2][NW][D]  block-local dEk | dEv
+  float*  DOE = Acc + 2 * NW * D;                                // [WV][32][NW]
+  bf16_t* WB  = reinterpret_cast<bf16_t*>(DOE + WV * 32 * NW);   // per wave: dSB[32][16] | dSBT[16][BTP] | PdBT[16][BTP] | Qw[32][VP] | dOw[32][VP]
+  constexpr int WBN = 32 * 16 + 2 * 16 * BTP + 2 * 32 * VP;
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int len = lens[b];
+  const size_t rbase = (size_t)b * Tp + HALO;
+
+  for (int i = tid; i < TPAD * (D / 8); i += NTH) {
+    const int j = i / (D / 8), c8 = i - j * (D / 8);
+    uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+    if (j < T) {
+      kk = *reinterpret_cast<const uint4*>(k + (rbase + j) * ld + h * D + c8 * 8);
+      vv = *reinterpret_cast<const uint4*>(v + (rbase + j) * ld + h * D + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(Ks + j * VP + c8 * 8) = kk;
+    *reinterpret_cast<uint4*>(Vs + j * KP + c8 * 8) = vv;
+  }
+  for (int i = tid; i < 32 * D; i += NTH) { const int rr = i / D, c = i - rr * D; Evs[rr * KP + c] = rr < NW ? f2bf(Ev[rr * D + c]) : (bf16_t)0; }
+  for (int i = tid; i < D * 16; i += NTH) { const int d = i >> 4, rr = i & 15; EkT[i] = rr < NW ? f2bf(Ek[rr * D + d]) : (bf16_t)0; }
+  for (int i = tid; i < 2 * NW * D; i += NTH) Acc[i] = 0.f;
+  for (int i = tid; i < WV * (32 * 16 + 2 * 16 * BTP); i += NTH) {            // band tables start at zero
+    const int ww = i / (32 * 16 + 2 * 16 * BTP), o = i - ww * (32 * 16 + 2 * 16 * BTP);
+    WB[ww * WBN + o] = 0;
+  }
+  __syncthreads();
+
+  const int i0 = (blockIdx.x * WV + w) * 32;
+  const bool active = i0 < T;                                    // wave-uniform
+  const int i = i0 + r;
+  const int ic = i < T ? i : T - 1;
+  float* doe = DOE + w * 32 * NW;
+  bf16_t* dSB = WB + w * WBN;
+  bf16_t* dSBT = dSB + 32 * 16;
+  bf16_t* PdBT = dSBT + 16 * BTP;
+  bf16_t* Qw = PdBT + 16 * BTP;
+  bf16_t* dOw = Qw + 32 * VP;
+  const int li = lane & 15, qd = li >> 2, pp = li & 3, colhalf = ((lane >> 4) & 1) * 16;
+
+  if (active) {
+    // per-wave Q / dO tiles (rows >= T zero) for the dEk / dEv contraction
+    for (int c = lane; c < 32 * (D / 8); c += 64) {
+      const int rr = c / (D / 8), c8 = c - rr * (D / 8);
+      uint4 qq = make_uint4(0, 0, 0, 0), dd = qq;
+      if (i0 + rr < T) {
+        qq = *reinterpret_cast<const uint4*>(q + (rbase + i0 + rr) * ld + h * D + c8 * 8);
+        dd = *reinterpret_cast<const uint4*>(dout + (rbase + i0 + rr) * lddo + h * D + c8 * 8);
+      }
+      *reinterpret_cast<uint4*>(Qw + rr * VP + c8 * 8) = qq;
+      *reinterpret_cast<uint4*>(dOw + rr * VP + c8 * 8) = dd;
+    }
+    bf16x8_t dof[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks)
+      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dout + (rbase + ic) * lddo + h * D + ks * 16 + 8 * hh);
+    {
+      f32x16_t acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Evs + r * KP + ks * 16 + 8 * hh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) doe[r * NW + e + 4 * hh] = acc[e];
+      if (hh == 0) doe[r * NW + 8] = acc[4];
+    }
+    f32x16_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], s[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const float inv_sqrt = rsqrtf((float)D);
+    const float* prow = P + (((size_t)b * H + h) * T + ic) * T;
+    const uint32_t drow = (uint32_t)((b * H + h) * T + i);
+    const bool vec = (T & 3) == 0;
+    // pass A: dP in place, Dsum
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j0 = 32 * t + 8 * g + 4 * hh;
+        float p4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
+        else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int j = j0 + e2;
+          float dp = s[t][4 * g + e2];
+          const int rel = j - i + WIN;
+          if ((unsigned)rel <= 2u * WIN) dp += doe[r * NW + rel];
+          if (drop_thresh) dp = drop_keep(drop_seed, drow, j, drop_thresh) ? dp * drop_scale : 0.f;
+          if (j >= T) dp = 0.f;
+          s[t][4 * g + e2] = dp;
+          dsum += dp * p4[e2];
+        }
+      }
+    dsum += __shfl_xor(dsum, 32);
+    // pass B: dS in place; write dS^T, dropout(P)^T and the band tables
+    bf16_t* dst_base = dST + ((size_t)b * H + h) * T * TI;
+    bf16_t* pdt_base = PdT + ((size_t)b * H + h) * T * TI;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int j0 = 32 * t + 8 * g + 4 * hh;
+        float p4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
+        else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const int j = j0 + e2;
+          float ds = p4[e2] * (s[t][4 * g + e2] - dsum) * inv_sqrt;
+          float pd = p4[e2];
+          if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
+          if (j >= T || j >= len || i >= len || i >= T) ds = 0.f;          // masked_fill blocks the gradient
+          if (i >= len || i >= T) pd = 0.f;                                // padded queries carry no upstream gradient
+          s[t][4 * g + e2] = ds;
+          if (j < T) {
+            dst_base[(size_t)j * TI + i] = f2bf(ds);
+            pdt_base[(size_t)j * TI + i] = f2bf(pd);
+            const int rel = j - i + WIN;
+            if ((unsigned)rel <= 2u * WIN) { const bf16_t db = f2bf(ds); dSB[r * 16 + rel] = db; dSBT[rel * BTP + r] = db; PdBT[rel * BTP + r] = f2bf(pd); }
+          }
+        }
+      }
+    __builtin_amdgcn_wave_barrier();
+
+    // dQ^T = K^T dS^T + Ek^T band(dS)^T
+    f32x16_t o[3];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float f8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f8[e] = s[t][8 * s2 + e];
+        const bf16x8_t pf = pack8(f8);
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          const bf16_t* ka = Ks + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+          const bf16x8_t af = tr_frag8(ka, ka + 8 * VP);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+        }
+      }
+    {
+      const bf16x8_t bfp = *reinterpret_cast<const bf16x8_t*>(dSB + r * 16 + 8 * hh);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(EkT + (32 * dt + r) * 16 + 8 * hh);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfp, o[dt], 0, 0, 0);
+      }
+    }
+    if (i < T) {
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = 32 * dt + 8 * g + 4 * hh;
+          *reinterpret_cast<uint2*>(dq + (rbase + i) * lddq + h * D + d) =
+              make_uint2(pack2bf(o[dt][4 * g], o[dt][4 * g + 1]), pack2bf(o[dt][4 * g + 2], o[dt][4 * g + 3]));
+        }
+    }
+    // dEk[r'][d] += sum_i dSBT[r'][i] Q[i][d];  dEv[r'][d] += sum_i PdBT[r'][i] dO[i][d]   (K = 32 queries)
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const bf16_t* At = which ? PdBT : dSBT;
+      const bf16_t* Bt = which ? dOw : Qw;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        f32x16_t acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(At + (r & 15) * BTP + 16 * ks + 8 * hh);
+          if (r >= 16) { const uint4 z = make_uint4(0, 0, 0, 0); af = __builtin_bit_cast(bf16x8_t, z); }
+          const bf16_t* ba = Bt + (16 * ks + 8 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+          const bf16x8_t bf_ = tr_frag8(ba, ba + 4 * VP);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf_, acc, 0, 0, 0);
+        }
+        float* dstA = Acc + which * NW * D;
+        const int d = 32 * dt + r;                                   // D layout: column = d (lane&31), row r' = (e&3)+8(e>>2)+4hh
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dstA + (e + 4 * hh) * D + d, acc[e]);
+        if (hh == 0) atomicAdd(dstA + 8 * D + d, acc[4]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int x = tid; x < NW * D; x += NTH) {
+    if (Acc[x] != 0.f) atomicAdd(dEk + x, Acc[x]);
+    if (Acc[NW * D + x] != 0.f) atomicAdd(dEv + x, Acc[NW * D + x]);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
+    const bf16_t* __restrict__ q, int ld, const bf16_t* __restrict__ dout, int lddo,
+    const bf16_t* __restrict__ dST, const bf16_t* __restrict__ PdT, int TI,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk, int T, int Tp, int H)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TPAD = NT * 32;
+  bf16_t* Qs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][VP]
+  bf16_t* dOs = Qs + TPAD * VP;                                  // [TPAD][VP]
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const size_t rbase = (size_t)b * Tp + HALO;
+  for (int i = tid; i < TPAD * (D / 8); i += 256) {
+    const int j = i / (D / 8), c8 = i - j * (D / 8);
+    uint4 qq = make_uint4(0, 0, 0, 0), dd = qq;
+    if (j < T) {
+      qq = *reinterpret_cast<const uint4*>(q + (rbase + j) * ld + h * D + c8 * 8);
+      dd = *reinterpret_cast<const uint4*>(dout + (rbase + j) * lddo + h * D + c8 * 8);
+    }
+    *reinterpret_cast<uint4*>(Qs + j * VP + c8 * 8) = qq;
+    *reinterpret_cast<uint4*>(dOs + j * VP + c8 * 8) = dd;
+  }
+  __syncthreads();
+  const int j0 = blockIdx.x * 128 + 32 * w;
+  if (j0 >= T) return;
+  const int j = j0 + r, jc = j < T ? j : T - 1;
+  const int li = lane & 15, qd = li >> 2, pp = li & 3, colhalf = ((lane >> 4) & 1) * 16;
+  const bf16_t* dsr = dST + (((size_t)b * H + h) * T + jc) * TI;
+  const bf16_t* pdr = PdT + (((size_t)b * H + h) * T + jc) * TI;
+  f32x16_t ak[3], av[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ak[dt][e] = 0.f; av[dt][e] = 0.f; }
+  }
+  const int nks = TI / 16;
+  for (int ks = 0; ks < nks; ++ks) {
+    const bf16x8_t bds = *reinterpret_cast<const bf16x8_t*>(dsr + 16 * ks + 8 * hh);     // dS[i = 16ks+8hh.., j]
+    const bf16x8_t bpd = *reinterpret_cast<const bf16x8_t*>(pdr + 16 * ks + 8 * hh);
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const bf16_t* qa = Qs + (16 * ks + 8 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+      const bf16_t* da = dOs + (16 * ks + 8 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+      ak[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag8(qa, qa + 4 * VP), bds, ak[dt], 0, 0, 0);
+      av[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag8(da, da + 4 * VP), bpd, av[dt], 0, 0, 0);
+    }
+  }
+  if (j < T) {
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * hh;
+        *reinterpret_cast<uint2*>(dk + (rbase + j) * lddk + h * D + d) =
+            make_uint2(pack2bf(ak[dt][4 * g], ak[dt][4 * g + 1]), pack2bf(ak[dt][4 * g + 2], ak[dt][4 * g + 3]));
+        *reinterpret_cast<uint2*>(dv + (rbase + j) * lddk + h * D + d) =
+            make_uint2(pack2bf(av[dt][4 * g], av[dt][4 * g + 1]), pack2bf(av[dt][4 * g + 2], av[dt][4 * g + 3]));
+      }
+  }
+}
+
+template <int NT, int WV>
+int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
+               const bf16_t* dout, int lddo, const float* P, bf16_t* ws, bf16_t* dq, bf16_t* dk, bf16_t* dv, int lddq,
+               float* dEk, float* dEv, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, hipStream_t st)
+{
+  constexpr int TPAD = NT * 32;
+  constexpr int WBN = 32 * 16 + 2 * 16 * BTP + 2 * 32 * VP;
+  const int TI = ((T + 31) / 32) * 32;
+  bf16_t* dST = ws;
+  bf16_t* PdT = ws + (size_t)B * H * T * TI;
+  const size_t lds1 = (size_t)TPAD * KP * 2 + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 2 * NW * D * 4 +
+                      (size_t)WV * 32 * NW * 4 + (size_t)WV * WBN * 2;
+  const size_t lds2 = (size_t)2 * TPAD * VP * 2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_q_mfma_kernel<NT, WV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_kv_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
+    attr = true;
+  }
+  if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return 1;
+  hipLaunchKernelGGL((gt_attn_bwd_q_mfma_kernel<NT, WV>), dim3((T + 32 * WV - 1) / (32 * WV), H, B), dim3(64 * WV), lds1, st,
+                     q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, H, th, sd, sc);
+  hipLaunchKernelGGL(gt_attn_bwd_kv_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds2, st,
+                     q, ld, dout, lddo, dST, PdT, TI, dk, dv, lddq, T, Tp, H);
+  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+}
+
 }  // namespace
+
+size_t gt_attn_bwd_mfma_ws_bytes(int B, int T, int H)
+{
+  const size_t TI = (size_t)((T + 31) / 32) * 32;
+  return (size_t)2 * B * H * T * TI * 2;
+}
+
+int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
+                          const int32_t* lens, const void* dout, int lddo, const float* P, void* ws, size_t ws_bytes,
+                          void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
+                          int B, int T, int Tp, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, void* stream)
+{
+  if (Dh != D || win != WIN || T > 256 || (ld & 7) || (lddo & 7) || (lddq & 3)) return 1;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)ws) & 15) return 1;
+  if (ws_bytes < gt_attn_bwd_mfma_ws_bytes(B, T, H)) return 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bf16_t* qq = static_cast<const bf16_t*>(q); const bf16_t* kk = static_cast<const bf16_t*>(k); const bf16_t* vv = static_cast<const bf16_t*>(v);
+  const bf16_t* dd = static_cast<const bf16_t*>(dout);
+  bf16_t* w16 = static_cast<bf16_t*>(ws);
+  bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
+  if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, st);
+  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, st);
+}
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,

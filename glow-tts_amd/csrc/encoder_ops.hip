@@ -588,13 +588,32 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
   GT_RET();
 }
 
+extern "C" size_t gt_attn_bwd_workspace_bytes(int B, int T, int H)
+{
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  const size_t generic = (size_t)B * H * T * T * sizeof(float);
+  const size_t mfma = gt_attn_bwd_mfma_ws_bytes(B, T, H);
+  return (generic > mfma ? generic : mfma) + 256;
+}
+
 extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
-                           const int32_t* lens, const void* dout, int lddo, const float* P, float* dS_ws,
+                           const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                            void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
                            int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream)
 {
-  if (!q || !k || !v || !Ek || !Ev || !lens || !dout || !P || !dS_ws || !dq || !dk || !dv || !dEk || !dEv) return GT_E_INVAL;
+  if (!q || !k || !v || !Ek || !Ev || !lens || !dout || !P || !workspace || !dq || !dk || !dv || !dEk || !dEv) return GT_E_INVAL;
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
+  if (workspace_bytes < gt_attn_bwd_workspace_bytes(B, T, H)) return GT_E_INVAL;
+  float* dS_ws = static_cast<float*>(workspace);
+  {
+    uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
+    static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
+    if (!no_mfma) {
+      const int rc = gt_attn_bwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, dout, lddo, P, workspace, workspace_bytes, dq, dk, dv, lddq,
+                                           dEk, dEv, B, T, Tp, H, D, win, th, sd, sc, stream);
+      if (rc != 1) return rc;
+    }
+  }
   const size_t lds1 = attn_lds(T, D, win, (size_t)2 * (2 * win + 1) * D + (size_t)AT_QT * 2 * D + (size_t)AT_QT * T);
   size_t halfs2 = (size_t)T * (D + 2); halfs2 += halfs2 & 1;
   const size_t lds2 = halfs2 * 2 + (size_t)AT_QT * 2 * T * 4;

@@ -89,11 +89,13 @@ def mha_bwd(rc, att, saved, dy, grads):
     dv = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
     # halo / padded rows of dq,dk,dv are never written by the kernel: zero them once
     dq.zero_(); dk.zero_(); dv.zero_()
-    dS = torch.empty_like(P)
+    from .flow_impl import _scratch
+    ws_bytes = L.gt_attn_bwd_workspace_bytes(rc.B, rc.T, H)
+    ws = _scratch("attn_bwd", ws_bytes, dev)
     dEk = torch.zeros_like(Ek)
     dEv = torch.zeros_like(Ev)
     _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
-                             _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(dS), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C,
+                             _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C,
                              _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed), _st(dev)),
                "gt_attn_bwd")
     grads[att.emb_rel_k] = dEk.view_as(att.emb_rel_k)

@@ -208,12 +208,14 @@ int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma,
  *   score[i,j] = (q_i.k_j + [|j-i|<=win] q_i.Ek[j-i+win]) / sqrt(D), masked keys/queries -> -1e4,
  *   out_i = sum_j dropout(softmax)[i,j] v_j + sum_{|j-i|<=win} dropout(softmax)[i,j] Ev[j-i+win].
  * q,k,v,out: bf16 rows [B*Tp, H*D]; Ek,Ev: [2*win+1, D] fp32 shared by heads; P: [B,H,T,T] fp32
- * (softmax before dropout, kept for the backward); dS_ws: [B,H,T,T] fp32 scratch; dEk/dEv ACCUMULATE. */
+ * (softmax before dropout, kept for the backward); workspace: gt_attn_bwd_workspace_bytes(B,T,H) bytes of
+ * scratch, 16-byte aligned; dEk/dEv ACCUMULATE.  D = 96, win = 4, T <= 256 run on bf16 MFMA. */
 int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                 const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
                 float drop_p, uint32_t drop_seed, void* stream);
+size_t gt_attn_bwd_workspace_bytes(int B, int T, int H);
 int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
-                const int32_t* lens, const void* dout, int lddo, const float* P, float* dS_ws,
+                const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                 void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
                 int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream);
 

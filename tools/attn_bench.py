@@ -11,14 +11,14 @@ R, C = rc.R, H * D
 q, k, v, do = [torch.randn(R, C, device=dev).to(torch.bfloat16) for _ in range(4)]
 Ek = torch.randn(9, D, device=dev) * 0.1; Ev = torch.randn(9, D, device=dev) * 0.1
 o = torch.zeros(R, C, dtype=torch.bfloat16, device=dev); P = torch.empty(B, H, T, T, device=dev)
-dS = torch.empty_like(P); dq, dk, dv = [torch.zeros(R, C, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+wsb = L.gt_attn_bwd_workspace_bytes(B, T, H); dS = torch.empty(wsb, dtype=torch.uint8, device=dev); dq, dk, dv = [torch.zeros(R, C, dtype=torch.bfloat16, device=dev) for _ in range(3)]
 dEk = torch.zeros_like(Ek); dEv = torch.zeros_like(Ev)
 st = _lib.current_stream(dev)
 def fwd():
     assert L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(o), C, _lib.ptr(P),
                          B, T, rc.Tp, H, D, 4, 0.1, 7, st) == 0
 def bwd():
-    assert L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(dS),
+    assert L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(dS), wsb,
                          _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C, _lib.ptr(dEk), _lib.ptr(dEv), B, T, rc.Tp, H, D, 4, 0.1, 7, st) == 0
 def timeit(fn, n=30):
     for _ in range(3): fn()
