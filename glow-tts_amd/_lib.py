@@ -24,7 +24,7 @@ PROTOTYPES = {
     "gt_conv_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_float, c_u32, c_void_p]),
+                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -41,21 +41,21 @@ PROTOTYPES = {
     "gt_coupling_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_int, c_int, c_void_p]),
     "gt_gate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
-                            c_int, c_int, c_float, c_u32, c_void_p]),
+                            c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_relu_drop_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_rows_add_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_rows_f32_to_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p]),
     "gt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                 c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_int,
+                                 c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gt_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p]),
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_logp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -96,6 +96,10 @@ def lib():
             raise HipLibraryMissing(
                 f"{LIB_PATH} not found: the HIP extension is not built.  Run "
                 "`python glow-tts_amd/build.py` (or __graft_entry__.build()).  There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64: it must be in the process BEFORE our library is loaded,
+        # otherwise the loader binds us to a second HIP runtime (/opt/rocm) that then reports
+        # "no ROCm-capable device" next to torch's.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             try:

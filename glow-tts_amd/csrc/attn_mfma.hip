@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
-    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TPAD = NT * 32;
   bf16_t* Ks  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
 
 template <int NT>
 int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
-               bf16_t* out, int ldo, float* P, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, hipStream_t st)
+               bf16_t* out, int ldo, float* P, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
 {
   constexpr int TPAD = NT * 32;
   const size_t lds = (size_t)TPAD * KP * 2 + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 4 * 32 * NW * 4 + 4 * 32 * 16 * 2;
@@ -228,8 +229,8 @@ int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
     attr = true;
   }
   hipLaunchKernelGGL(gt_attn_fwd_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds, st,
-                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, H, th, sd, sc);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, H, th, sd, sc, seed_dev);
+  return gt_launch_status(__func__);
 }
 
 // =========================================================================================
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
     const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
     bf16_t* __restrict__ dST, bf16_t* __restrict__ PdT, int TI,
     bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
-    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TPAD = NT * 32, NTH = 64 * WV;
   bf16_t* Vs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]  A of dPd^T (ds_read_b128)
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
 template <int NT, int WV>
 int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
                const bf16_t* dout, int lddo, const float* P, bf16_t* ws, bf16_t* dq, bf16_t* dk, bf16_t* dv, int lddq,
-               float* dEk, float* dEv, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, hipStream_t st)
+               float* dEk, float* dEv, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
 {
   constexpr int TPAD = NT * 32;
   constexpr int WBN = 32 * 16 + 2 * 16 * BTP + 2 * 32 * VP;
@@ -562,10 +564,10 @@ int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   }
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return 1;
   hipLaunchKernelGGL((gt_attn_bwd_q_mfma_kernel<NT, WV>), dim3((T + 32 * WV - 1) / (32 * WV), H, B), dim3(64 * WV), lds1, st,
-                     q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, H, th, sd, sc);
+                     q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, H, th, sd, sc, seed_dev);
   hipLaunchKernelGGL(gt_attn_bwd_kv_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds2, st,
                      q, ld, dout, lddo, dST, PdT, TI, dk, dv, lddq, T, Tp, H);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }
 
 }  // namespace
@@ -579,7 +581,7 @@ size_t gt_attn_bwd_mfma_ws_bytes(int B, int T, int H)
 int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                           const int32_t* lens, const void* dout, int lddo, const float* P, void* ws, size_t ws_bytes,
                           void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                          int B, int T, int Tp, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, void* stream)
+                          int B, int T, int Tp, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
   if (Dh != D || win != WIN || T > 256 || (ld & 7) || (lddo & 7) || (lddq & 3)) return 1;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)ws) & 15) return 1;
@@ -589,20 +591,20 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   const bf16_t* dd = static_cast<const bf16_t*>(dout);
   bf16_t* w16 = static_cast<bf16_t*>(ws);
   bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
-  if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, st);
-  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, st);
+  if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, seed_dev, st);
+  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, seed_dev, st);
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                           const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int Dh, int win,
-                          uint32_t th, uint32_t sd, float sc, void* stream)
+                          uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
   if (Dh != D || win != WIN || T > 256 || (ld & 7) || (ldo & 3)) return 1;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bf16_t* qq = static_cast<const bf16_t*>(q); const bf16_t* kk = static_cast<const bf16_t*>(k); const bf16_t* vv = static_cast<const bf16_t*>(v);
   bf16_t* oo = static_cast<bf16_t*>(out);
-  if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, st);
-  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, st);
+  if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, seed_dev, st);
+  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, seed_dev, st);
 }

@@ -32,3 +32,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// Launch check shared by every entry point: reports WHICH call failed and why on stderr (the C-ABI
+// itself only returns GT_E_LAUNCH).
+#include <stdio.h>
+static inline int gt_launch_status(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  fprintf(stderr, "[glowtts_hip] %s: HIP error %d (%s)\n", what, (int)e, hipGetErrorString(e));
+  return -4;
+}

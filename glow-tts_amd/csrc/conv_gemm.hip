@@ -43,6 +43,7 @@ struct ConvArgs {
   int R, N, Cin, taps, Tp, Np, Kp;
   int out_f32, relu;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // gate dropout (modules.py:153)
+  const uint32_t* seed_dev;                            // optional device word XOR-ed into drop_seed (graph replay)
 };
 
 template <int BN, bool GATE>
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][XROWS * LDP];
   __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * LDP];
 
+  if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int r = lane & 31, h = lane >> 5;
@@ -302,7 +304,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
                                  void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                                  void* gate_t, void* gate_s, int ldts,
                                  int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                                 int relu, int gate, float drop_p, uint32_t drop_seed, void* stream)
+                                 int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (R < 0 || N <= 0 || Cin <= 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
@@ -318,7 +320,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   a.Tout = static_cast<bf16_t*>(gate_t); a.Sout = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
   a.R = R; a.N = N; a.Cin = Cin; a.taps = taps; a.Tp = Tp > 0 ? Tp : 1; a.Np = Np; a.Kp = Kp;
   a.out_f32 = out_f32; a.relu = relu;
-  a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f;
+  a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f; a.seed_dev = seed_dev;
   if (drop_p > 0.0f) {
     if (drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p);
@@ -335,7 +337,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
     if (Np % 64 || Np < N) return GT_E_INVAL;
     hipLaunchKernelGGL((gt_conv_gemm_kernel<64, false>), dim3(Np / 64, (R + BM - 1) / BM), block, 0, st, a);
   }
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }
 
 extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
@@ -350,7 +352,7 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
   hipLaunchKernelGGL(gt_pack_conv_weights_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream),
                      v, g, static_cast<bf16_t*>(pack_fwd), static_cast<bf16_t*>(pack_dgrad), inv_norm,
                      Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }
 
 extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, void* stream)
@@ -358,5 +360,5 @@ extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs,
   if (!descs_device || n_convs <= 0 || total_rows <= 0) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_pack_conv_weights_multi_kernel, dim3(total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const gt_pack_desc*>(descs_device), n_convs);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }

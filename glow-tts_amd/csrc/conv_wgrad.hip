@@ -167,11 +167,19 @@ __global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
     dbias[co] = accumulate ? dbias[co] + sb : sb;
   }
   // coalesced pass over the partials: consecutive threads = consecutive ci of one (slab, tap) row
+  const size_t sstride = (size_t)taps * Cout * Cin;              // one slab
   for (int i = tid; i < n; i += 256) {
     const int tap = i / Cin, ci = i - tap * Cin;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[(((size_t)k * taps + tap) * Cout + co) * Cin + ci];
-    dws[ci * taps + tap] = s;
+    const float* pp = part + ((size_t)tap * Cout + co) * Cin + ci;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                 // 4 loads in flight per thread, not a dependent chain
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {
+      const float a0 = pp[(size_t)k * sstride], a1 = pp[(size_t)(k + 1) * sstride];
+      const float a2 = pp[(size_t)(k + 2) * sstride], a3 = pp[(size_t)(k + 3) * sstride];
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; k < S; ++k) s0 += pp[(size_t)k * sstride];
+    dws[ci * taps + tap] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (!g) {
@@ -254,7 +262,7 @@ extern "C" int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ld
   if (taps == 5)      hipLaunchKernelGGL(gt_conv_wgrad_kernel<5>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
   else if (taps == 3) hipLaunchKernelGGL(gt_conv_wgrad_kernel<3>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
   else                hipLaunchKernelGGL(gt_conv_wgrad_kernel<1>, grid, dim3(256), 0, st, x, ldx, dy, ldy, part, pb, R, Cin, Cout, slab_rows);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }
 
 extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
@@ -269,7 +277,7 @@ extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, c
   const float* part = static_cast<const float*>(workspace);
   hipLaunchKernelGGL(gt_weightnorm_bwd_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream),
                      part, part + (size_t)S * taps * Cout * Cin, S, v, g, inv_norm, dv, dg, dbias, Cout, Cin, taps, accumulate);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }
 
 extern "C" int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void* stream)
@@ -281,5 +289,5 @@ extern "C" int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (is_f32) hipLaunchKernelGGL(gt_colsum_kernel<true>,  grid, dim3(256), 0, st, Y, ldy, out, R, N, rows_per_block);
   else        hipLaunchKernelGGL(gt_colsum_kernel<false>, grid, dim3(256), 0, st, Y, ldy, out, R, N, rows_per_block);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }

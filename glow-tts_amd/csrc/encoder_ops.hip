@@ -27,10 +27,12 @@ struct LnArgs {
   uint32_t din_thresh, din_seed; float din_scale;
   uint32_t dout_thresh, dout_seed; float dout_scale;
   int relu;
+  const uint32_t* seed_dev;                    // optional device word XOR-ed into both seeds (graph replay)
 };
 
 __global__ __launch_bounds__(256) void gt_layernorm_fwd_kernel(LnArgs p)
 {
+  if (p.seed_dev) { const uint32_t x = *p.seed_dev; p.din_seed ^= x; p.dout_seed ^= x; }
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= p.R) return;
   float s[4]; float sum = 0.f;
@@ -80,6 +82,7 @@ struct LnBwdArgs {
 
 __global__ __launch_bounds__(256) void gt_layernorm_bwd_kernel(LnBwdArgs q)
 {
+  if (q.f.seed_dev) { const uint32_t x = *q.f.seed_dev; q.f.din_seed ^= x; q.f.dout_seed ^= x; }
   const LnArgs& p = q.f;
   __shared__ float sg[4][256], sb[4][256];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -166,8 +169,9 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
-    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -236,8 +240,9 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P, float* __restrict__ dS,
     bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
-    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AT_QT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -316,8 +321,9 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
 __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
     const bf16_t* __restrict__ q, int ld, const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
     const float* __restrict__ dS, const int32_t* __restrict__ lens, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk,
-    int T, int Tp, int H, int D, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+    int T, int Tp, int H, int D, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.z, h = blockIdx.y, j0 = blockIdx.x * AT_QT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict
 }  // namespace
 
 #define GT_ST(s) static_cast<hipStream_t>(s)
-#define GT_RET() return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH
+#define GT_RET() return gt_launch_status(__func__)
 
 static void fill_drop(float p, uint32_t seed, uint32_t& th, uint32_t& sd, float& sc)
 {
@@ -517,13 +523,13 @@ static void fill_drop(float p, uint32_t seed, uint32_t& th, uint32_t& sd, float&
 
 static int fill_ln(LnArgs& p, const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                    float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
-                   float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu)
+                   float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev)
 {
   if ((!a && !y) || !gamma || !beta || !mean || !rstd || R <= 0 || C <= 0 || C > 256) return GT_E_INVAL;
   if (p_in >= 1.f || p_out >= 1.f) return GT_E_INVAL;
   p.a = a; p.y = static_cast<const bf16_t*>(y); p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask;
   p.out_f32 = out_f32; p.out_bf16 = static_cast<bf16_t*>(out_bf16); p.ldo = ldo; p.mean = mean; p.rstd = rstd;
-  p.R = R; p.C = C; p.eps = eps; p.relu = relu;
+  p.R = R; p.C = C; p.eps = eps; p.relu = relu; p.seed_dev = seed_dev;
   fill_drop(p_in, seed_in, p.din_thresh, p.din_seed, p.din_scale);
   fill_drop(p_out, seed_out, p.dout_thresh, p.dout_seed, p.dout_scale);
   return GT_OK;
@@ -531,10 +537,10 @@ static int fill_ln(LnArgs& p, const float* a, const void* y, int ldy, const floa
 
 extern "C" int gt_layernorm_fwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                                 float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
-                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, void* stream)
+                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev, void* stream)
 {
   LnArgs p;
-  const int rc = fill_ln(p, a, y, ldy, gamma, beta, rowmask, out_f32, out_bf16, ldo, mean, rstd, R, C, eps, p_in, seed_in, p_out, seed_out, relu);
+  const int rc = fill_ln(p, a, y, ldy, gamma, beta, rowmask, out_f32, out_bf16, ldo, mean, rstd, R, C, eps, p_in, seed_in, p_out, seed_out, relu, seed_dev);
   if (rc) return rc;
   hipLaunchKernelGGL(gt_layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), p);
   GT_RET();
@@ -542,13 +548,13 @@ extern "C" int gt_layernorm_fwd(const float* a, const void* y, int ldy, const fl
 
 extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                                 const float* mean, const float* rstd, int R, int C, float eps,
-                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu,
+                                float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
                                 const float* dout_f32, const void* dout_bf16, int lddo,
                                 float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream)
 {
   LnBwdArgs q;
   const int rc = fill_ln(q.f, a, y, ldy, gamma, beta, rowmask, nullptr, nullptr, 0, const_cast<float*>(mean), const_cast<float*>(rstd),
-                         R, C, eps, p_in, seed_in, p_out, seed_out, relu);
+                         R, C, eps, p_in, seed_in, p_out, seed_out, relu, seed_dev);
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
@@ -565,7 +571,7 @@ static size_t attn_lds(int T, int D, int win, size_t extra_floats)
 
 extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                            const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
-                           float drop_p, uint32_t drop_seed, void* stream)
+                           float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (!q || !k || !v || !Ek || !Ev || !lens || !out || !P || B <= 0 || T <= 0 || H <= 0) return GT_E_INVAL;
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
@@ -573,7 +579,7 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
     uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
     static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
     if (!no_mfma) {
-      const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, H, D, win, th, sd, sc, stream);
+      const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;                      // handled (or failed loudly) on the MFMA path
     }
   }
@@ -584,7 +590,7 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
   uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
   hipLaunchKernelGGL(gt_attn_fwd_kernel, dim3((T + AT_QT - 1) / AT_QT, H, B), dim3(256), lds, GT_ST(stream),
                      static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
-                     static_cast<bf16_t*>(out), ldo, P, T, Tp, H, D, win, th, sd, sc);
+                     static_cast<bf16_t*>(out), ldo, P, T, Tp, H, D, win, th, sd, sc, seed_dev);
   GT_RET();
 }
 
@@ -599,7 +605,7 @@ extern "C" size_t gt_attn_bwd_workspace_bytes(int B, int T, int H)
 extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                            const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                            void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                           int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream)
+                           int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (!q || !k || !v || !Ek || !Ev || !lens || !dout || !P || !workspace || !dq || !dk || !dv || !dEk || !dEv) return GT_E_INVAL;
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
@@ -610,7 +616,7 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
     static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
     if (!no_mfma) {
       const int rc = gt_attn_bwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, dout, lddo, P, workspace, workspace_bytes, dq, dk, dv, lddq,
-                                           dEk, dEv, B, T, Tp, H, D, win, th, sd, sc, stream);
+                                           dEk, dEv, B, T, Tp, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;
     }
   }
@@ -629,10 +635,10 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
   hipLaunchKernelGGL(gt_attn_bwd_q_kernel, grid, dim3(256), lds1, GT_ST(stream),
                      static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
                      static_cast<const bf16_t*>(dout), lddo, P, dS_ws, static_cast<bf16_t*>(dq), lddq, dEk, dEv,
-                     T, Tp, H, D, win, th, sd, sc);
+                     T, Tp, H, D, win, th, sd, sc, seed_dev);
   hipLaunchKernelGGL(gt_attn_bwd_kv_kernel, grid, dim3(256), lds2, GT_ST(stream),
                      static_cast<const bf16_t*>(q), ld, static_cast<const bf16_t*>(dout), lddo, P, dS_ws, lens,
-                     static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), lddq, T, Tp, H, D, th, sd, sc);
+                     static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), lddq, T, Tp, H, D, th, sd, sc, seed_dev);
   GT_RET();
 }
 

@@ -261,8 +261,10 @@ __global__ __launch_bounds__(256) void gt_rows_add_bf16_kernel(float* __restrict
 __global__ __launch_bounds__(256) void gt_gate_bwd_kernel(const bf16_t* __restrict__ dacts, int ldd, const bf16_t* __restrict__ T,
                                                           const bf16_t* __restrict__ S, int ldts, bf16_t* __restrict__ dpre, int ldp,
                                                           bf16_t* __restrict__ dpre_cond, int R, int half,
-                                                          uint32_t drop_thresh, uint32_t drop_seed, float drop_scale)
+                                                          uint32_t drop_thresh, uint32_t drop_seed, float drop_scale,
+                                                          const uint32_t* __restrict__ seed_dev)
 {
+  if (seed_dev) drop_seed ^= *seed_dev;
   const int idx = blockIdx.x * 256 + threadIdx.x, q4 = half >> 2;
   if (idx >= R * q4) return;
   const int m = idx / q4, c = (idx - m * q4) * 4;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void gt_rows_f32_to_bf16_kernel(const float* _
 }  // namespace
 
 #define GT_ST(s) static_cast<hipStream_t>(s)
-#define GT_RET() return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH
+#define GT_RET() return gt_launch_status(__func__)
 
 extern "C" int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream)
 {
@@ -385,14 +387,14 @@ extern "C" int gt_rows_add_bf16(float* dx, int ldx, const void* add, int lda, in
   GT_RET();
 }
 extern "C" int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void* S, int ldts, void* dpre, int ldp, void* dpre_cond,
-                           int R, int half, float drop_p, uint32_t drop_seed, void* stream)
+                           int R, int half, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (!dacts || !T || !S || !dpre || R <= 0 || (half & 3) || (ldd & 3) || (ldts & 3) || (ldp & 3)) return GT_E_INVAL;
   uint32_t th = 0; float sc = 1.0f;
   if (drop_p > 0.f) { th = (uint32_t)((double)drop_p * 4294967296.0); sc = 1.0f / (1.0f - drop_p); }
   hipLaunchKernelGGL(gt_gate_bwd_kernel, dim3((R * (half / 4) + 255) / 256), dim3(256), 0, GT_ST(stream),
                      static_cast<const bf16_t*>(dacts), ldd, static_cast<const bf16_t*>(T), static_cast<const bf16_t*>(S), ldts,
-                     static_cast<bf16_t*>(dpre), ldp, static_cast<bf16_t*>(dpre_cond), R, half, th, drop_seed, sc);
+                     static_cast<bf16_t*>(dpre), ldp, static_cast<bf16_t*>(dpre_cond), R, half, th, drop_seed, sc, seed_dev);
   GT_RET();
 }
 extern "C" int gt_relu_drop_bwd(const void* d, int ldd, const void* y, int ldy, void* dc, int ldc, int R, int n, float drop_p, void* stream)

@@ -36,6 +36,7 @@
 // Cells outside the reference's band x in [max(0,t_x+y-t_y), min(t_x,y+1)) are computed
 // too (garbage) but never read by in-band cells nor by the backtrack.
 #include <hip/hip_runtime.h>
+#include "common.h"
 #pragma clang fp contract(off)   // bit-exact IEEE adds/compares only
 #include <stdint.h>
 #include "../../include/glowtts_hip.h"
@@ -547,14 +548,14 @@ extern "C" int gt_mas_f32(const float* logp, const float* mask,
     attr_set[k] = true;
   }
   hipLaunchKernelGGL(kerns[k], dim3(B), dim3(W * 64), lds, st, a);
-  if (hipGetLastError() != hipSuccess) return GT_E_LAUNCH;
+  if (gt_launch_status(__func__)) return GT_E_LAUNCH;
 
   if (path) {
     const bool vec = (T_y % 4 == 0) && ((uintptr_t)path % 16 == 0);
     const dim3 grid((unsigned)(((T_y + 3) / 4 + 255) / 256), (unsigned)T_x, (unsigned)B);
     if (vec) hipLaunchKernelGGL(gt_mas_expand_kernel<true>,  grid, dim3(256), 0, st, a.starts, path, path_dtype, T_x, T_y);
     else     hipLaunchKernelGGL(gt_mas_expand_kernel<false>, grid, dim3(256), 0, st, a.starts, path, path_dtype, T_x, T_y);
-    if (hipGetLastError() != hipSuccess) return GT_E_LAUNCH;
+    if (gt_launch_status(__func__)) return GT_E_LAUNCH;
   }
   return GT_OK;
 }
@@ -568,5 +569,5 @@ extern "C" int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int
   if (!mask || !t_x || !t_y) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_mas_lengths_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream),
                      mask, t_x, t_y, T_x, T_y, stride_b, stride_x);
-  return hipGetLastError() == hipSuccess ? GT_OK : GT_E_LAUNCH;
+  return gt_launch_status(__func__);
 }

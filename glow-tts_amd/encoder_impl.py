@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from .flow_impl import _st, conv_param_grads
-from .ops import conv_rows
+from .ops import conv_rows, seed_word
 
 LN_EPS = 1e-4
 
@@ -29,7 +29,8 @@ def _ln_fwd(rc, ln, a, y, p_in, seed_in, p_out, seed_out, relu, want_f32, C):
     rstd = torch.empty(R, dtype=torch.float32, device=dev)
     _lib.check(L.gt_layernorm_fwd(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
                                   _lib.ptr(rc.rowmask), _lib.ptr(out_f32), _lib.ptr(out_bf), C, _lib.ptr(mean), _lib.ptr(rstd),
-                                  R, C, LN_EPS, float(p_in), int(seed_in), float(p_out), int(seed_out), int(relu), _st(dev)),
+                                  R, C, LN_EPS, float(p_in), int(seed_in), float(p_out), int(seed_out), int(relu),
+                                  _lib.ptr(seed_word(dev)) if (p_in > 0 or p_out > 0) else None, _st(dev)),
                "gt_layernorm_fwd")
     return out_f32, out_bf, (a, y, mean, rstd, p_in, seed_in, p_out, seed_out, relu, C)
 
@@ -46,6 +47,7 @@ def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads):
     _lib.check(L.gt_layernorm_bwd(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
                                   _lib.ptr(rc.rowmask), _lib.ptr(mean), _lib.ptr(rstd), R, C, LN_EPS,
                                   float(p_in), int(seed_in), float(p_out), int(seed_out), int(relu),
+                                  _lib.ptr(seed_word(dev)) if (p_in > 0 or p_out > 0) else None,
                                   _lib.ptr(dout_f32), _lib.ptr(dout_bf), 0 if dout_bf is None else dout_bf.stride(0),
                                   _lib.ptr(da), _lib.ptr(dy), C, _lib.ptr(dg), _lib.ptr(db), _st(dev)), "gt_layernorm_bwd")
     grads[ln.gamma] = dg
@@ -69,7 +71,8 @@ def mha_fwd(rc, att, xb, p, seed):
     Ek = att.emb_rel_k.detach().reshape(-1, D).contiguous()
     Ev = att.emb_rel_v.detach().reshape(-1, D).contiguous()
     _lib.check(L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
-                             _lib.ptr(o), C, _lib.ptr(P), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed), _st(dev)),
+                             _lib.ptr(o), C, _lib.ptr(P), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed),
+                             _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_fwd")
     y = conv_rows(o, att.conv_o.pc, rc, bias=att.conv_o.bias)
     return y, (xb, q, k, v, o, P, Ek, Ev, p, seed)
@@ -96,7 +99,8 @@ def mha_bwd(rc, att, saved, dy, grads):
     dEv = torch.zeros_like(Ev)
     _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
                              _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C,
-                             _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed), _st(dev)),
+                             _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed),
+                             _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_bwd")
     grads[att.emb_rel_k] = dEk.view_as(att.emb_rel_k)
     grads[att.emb_rel_v] = dEv.view_as(att.emb_rel_v)

@@ -9,7 +9,7 @@ backward mirrors what autograd derives for the reference modules:
 import torch
 
 from . import _lib
-from .ops import RowsCtx, conv_rows  # noqa: F401
+from .ops import RowsCtx, conv_rows, seed_word  # noqa: F401
 
 _SCRATCH = {}
 
@@ -153,7 +153,8 @@ def wn_bwd(rc, wn, saved, drs, want_dcond=False):
         dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
         dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if (want_dcond and p > 0) else None
         _lib.check(L.gt_gate_bwd(_lib.ptr(dacts), dacts.stride(0), _lib.ptr(ts[i]), _lib.ptr(ss[i]), ts[i].stride(0),
-                                 _lib.ptr(dpre), 2 * H, _lib.ptr(dpre_c), R, H, float(p), int(seed + i), _st(dev)), "gt_gate_bwd")
+                                 _lib.ptr(dpre), 2 * H, _lib.ptr(dpre_c), R, H, float(p), int(seed + i),
+                                 _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)), "gt_gate_bwd")
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre

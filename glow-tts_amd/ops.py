@@ -50,6 +50,23 @@ class _KernelTimer:
 
 KERNEL_TIMER = _KernelTimer()
 
+_SEED = {}
+
+
+def seed_word(device):
+    """Device-resident uint32 mixed into every dropout seed (seed_dev of the C-ABI).  Bumping it (even
+    from inside a captured HIP graph) gives fresh dropout masks without changing any kernel argument."""
+    key = str(device)
+    t = _SEED.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+        _SEED[key] = t
+    return t
+
+
+def bump_seed(device):
+    seed_word(device).add_(0x632BE5AB)           # odd constant: full-period walk over 2^32
+
 
 class RowsCtx:
     """Geometry of one batch in the rows layout: utterance b owns rows [b*Tp, (b+1)*Tp),
@@ -135,7 +152,7 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(addend), 0 if addend is None else addend.stride(0),
                              _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
-                             _lib.current_stream(x.device))
+                             _lib.ptr(seed_word(x.device)) if drop_p > 0 else None, _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
     _lib.check(rc, "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate else out

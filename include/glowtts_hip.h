@@ -108,13 +108,16 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
  *     pre = drop(acc + bias) + cond;  T = tanh(pre[:half]), S = sigmoid(pre[half:]),
  *     Y[m, :half] = T*S (bf16), T and S are saved to gate_t / gate_s ([R, ldts] bf16).
  *   Wp: weights packed by gt_pack_conv_weights ([taps][Np][Kp] bf16, zero padded).
+ * Dropout masks are a counter-based hash of (seed, row, col), replayed by the backward kernels.
+ * seed_dev (here and in every entry point that takes it; may be NULL) is a device uint32 XOR-ed into the
+ * host seed at kernel start: a captured HIP graph then draws fresh masks on every replay by bumping that word.
  * Alignment: all pointers 16 B; N%4, Cin%8, ldx%8, ldy%4, Kp%64 == 0. */
 int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
                       const float* cond, int ldc, const float* rowmask,
                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                       void* gate_t, void* gate_s, int ldts,
                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                      int relu, int gate, float drop_p, uint32_t drop_seed, void* stream);
+                      int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 
 /* Weight preparation for gt_conv_gemm_bf16: w = g*v/||v|| when g != NULL (torch weight_norm,
  * dim 0: modules.py:127,132,141, attentions.py:103) else w = v; v is [Cout, Cin, taps] fp32.
@@ -181,7 +184,7 @@ int gt_coupling_bwd(const float* out, const float* x, const float* dz, const flo
 /* WaveNet gate backward (commons.py:61-68): dpre [R,2*half] bf16 from d(acts), saved T and S;
  * dpre carries the replayed dropout mask, dpre_cond (optional) does not. */
 int gt_gate_bwd(const void* dacts, int ldd, const void* T, const void* S, int ldts, void* dpre, int ldp, void* dpre_cond,
-                int R, int half, float drop_p, uint32_t drop_seed, void* stream);
+                int R, int half, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 
 /* backward of y = rowmask * dropout(relu(c)) given the saved y: dc = (y != 0) ? d/(1-p) : 0 (bf16 rows). */
 int gt_relu_drop_bwd(const void* d, int ldd, const void* y, int ldy, void* dc, int ldc, int R, int n, float drop_p, void* stream);
@@ -197,10 +200,10 @@ int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const floa
  * Dropout masks are counter-based (seed) and replayed by the backward. dgamma/dbeta ACCUMULATE. */
 int gt_layernorm_fwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                      float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
-                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, void* stream);
+                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev, void* stream);
 int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                      const float* mean, const float* rstd, int R, int C, float eps,
-                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu,
+                     float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
                      const float* dout_f32, const void* dout_bf16, int lddo,
                      float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream);
 
@@ -212,12 +215,12 @@ int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma,
  * scratch, 16-byte aligned; dEk/dEv ACCUMULATE.  D = 96, win = 4, T <= 256 run on bf16 MFMA. */
 int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                 const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
-                float drop_p, uint32_t drop_seed, void* stream);
+                float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 size_t gt_attn_bwd_workspace_bytes(int B, int T, int H);
 int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                 const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                 void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, void* stream);
+                int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 
 /* Embedding * scale into rows (models.py:693): fp32 and/or bf16 output, zero halo / padded rows. */
 int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
