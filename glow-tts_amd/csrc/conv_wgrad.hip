@@ -35,19 +35,21 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p0, const bf16_t* p1) 
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// One workgroup: 128 output channels [co0, co0+128) of the dY view (Ncols columns wide; dY column c is
+// output channel co_begin + c of a conv with Cout channels) x 64 input channels x all taps, rows of one slab.
 template <int TAPS>
-__global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
+__device__ __forceinline__ void wgrad_tile(
     const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy,
-    float* __restrict__ part, float* __restrict__ part_bias, int R, int Cin, int Cout, int slab_rows)
+    float* __restrict__ part, float* __restrict__ part_bias, int R, int Cin, int Cout, int slab_rows,
+    int co0, int ci0, int slab, int co_begin, int Ncols)
 {
   __shared__ __attribute__((aligned(16))) bf16_t Ys[2][KB * YP];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][XROWS * XP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64, slab = blockIdx.z;
   const int padl = TAPS >> 1;
   const int mbeg = slab * slab_rows;
   const int mend = min(R, mbeg + slab_rows);
-  const bool do_bias = (blockIdx.y == 0) && part_bias;          // column sums of dY ride along as one more MFMA
+  const bool do_bias = (ci0 == 0) && part_bias;                 // column sums of dY ride along as one more MFMA
 
   f32x16_t acc[TAPS][2], accb;
 #pragma unroll
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
     const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
     const int m = mb + row, co = co0 + c8 * 8;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (m < mend && co < Cout) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
+    if (m < mend && co < Ncols) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
     return v;
   };
   auto ldx1 = [&](int mb, int i) -> uint4 {
@@ -137,30 +139,50 @@ __global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (co < Cout) part[(((size_t)slab * TAPS + t) * Cout + co) * Cin + ci] = acc[t][j][e];
+        if (co < Ncols) part[(((size_t)slab * TAPS + t) * Cout + co_begin + co) * Cin + ci] = acc[t][j][e];
       }
     }
   if (do_bias && r == 0) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (co < Cout) part_bias[(size_t)slab * Cout + co] = accb[e];
+      if (co < Ncols) part_bias[(size_t)slab * Cout + co_begin + co] = accb[e];
     }
   }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 1) void gt_conv_wgrad_kernel(
+    const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy,
+    float* __restrict__ part, float* __restrict__ part_bias, int R, int Cin, int Cout, int slab_rows)
+{
+  wgrad_tile<TAPS>(X, ldx, dY, ldy, part, part_bias, R, Cin, Cout, slab_rows,
+                   blockIdx.x * 128, blockIdx.y * 64, blockIdx.z, 0, Cout);
+}
+
+// Batched form: every workgroup reads its (job, tile) from device tables, so ONE launch per tap count
+// covers the weight gradients of a whole network (the jobs' X / dY rows stay resident until then).
+template <int TAPS>
+__global__ __launch_bounds__(256, 1) void gt_conv_wgrad_batched_kernel(
+    const gt_wgrad_job* __restrict__ jobs, const gt_wgrad_tile* __restrict__ tiles)
+{
+  const gt_wgrad_tile t = tiles[blockIdx.x];
+  const gt_wgrad_job j = jobs[t.job];
+  wgrad_tile<TAPS>(static_cast<const bf16_t*>(j.X), j.ldx, static_cast<const bf16_t*>(j.dY), j.ldy,
+                   j.part, j.part_bias, j.R, j.Cin, j.Cout, j.slab_rows, t.co0, t.ci0, t.slab, j.co_begin, j.co_count);
 }
 
 // Sum the S slab partials and map to the parameter gradient(s).  One workgroup per co.
 //   plain conv:   dw[co][ci][tap] (+)= dW
 //   weight-norm:  w = g v / ||v||  =>  dg = <dW, v>/||v|| ;  dv = g/||v|| (dW - v <dW,v>/||v||^2)
 //   bias:         db[co] (+)= sum of the slab column sums
-__global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
+__device__ __forceinline__ void weightnorm_bwd_row(
     const float* __restrict__ part, const float* __restrict__ part_bias, int S, const float* __restrict__ v,
     const float* __restrict__ g, const float* __restrict__ inv_norm, float* __restrict__ dv, float* __restrict__ dg,
-    float* __restrict__ dbias, int Cout, int Cin, int taps, int accumulate)
+    float* __restrict__ dbias, int Cout, int Cin, int taps, int accumulate, int co, float* dws)
 {
-  extern __shared__ float dws[];               // [Cin*taps] summed dW of this co, natural (ci, tap) order
   __shared__ float red[4];
-  const int co = blockIdx.x, tid = threadIdx.x, n = Cin * taps;
+  const int tid = threadIdx.x, n = Cin * taps;
   if (dbias && tid == 0) {
     float sb = 0.f;
     for (int k = 0; k < S; ++k) sb += part_bias[(size_t)k * Cout + co];
@@ -203,6 +225,30 @@ __global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
     const float val = a * dws[i] - bcoef * v[o];
     dv[o] = accumulate ? dv[o] + val : val;
   }
+}
+
+__global__ __launch_bounds__(256) void gt_weightnorm_bwd_kernel(
+    const float* __restrict__ part, const float* __restrict__ part_bias, int S, const float* __restrict__ v,
+    const float* __restrict__ g, const float* __restrict__ inv_norm, float* __restrict__ dv, float* __restrict__ dg,
+    float* __restrict__ dbias, int Cout, int Cin, int taps, int accumulate)
+{
+  extern __shared__ float dws[];               // [Cin*taps] summed dW of this co, natural (ci, tap) order
+  weightnorm_bwd_row(part, part_bias, S, v, g, inv_norm, dv, dg, dbias, Cout, Cin, taps, accumulate, blockIdx.x, dws);
+}
+
+// Batched form: one workgroup per output channel of ANY conv; the job is found by bisection on row_start.
+__global__ __launch_bounds__(256) void gt_weightnorm_bwd_batched_kernel(const gt_wnb_job* __restrict__ jobs, int n_jobs)
+{
+  extern __shared__ float dws[];
+  const int row = blockIdx.x;
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].row_start <= row) lo = mid; else hi = mid - 1;
+  }
+  const gt_wnb_job j = jobs[lo];
+  weightnorm_bwd_row(j.part, j.part_bias, j.S, j.v, j.g, j.inv_norm, j.dv, j.dg, j.dbias, j.Cout, j.Cin, j.taps,
+                     j.accumulate, row - j.row_start, dws);
 }
 
 // Column sums over rows: out[n] (+)= sum_m Y[m, n] (bias gradients).  bf16 or fp32 input.
@@ -277,6 +323,29 @@ extern "C" int gt_weightnorm_bwd(const void* workspace, int R, const float* v, c
   const float* part = static_cast<const float*>(workspace);
   hipLaunchKernelGGL(gt_weightnorm_bwd_kernel, dim3(Cout), dim3(256), lds, static_cast<hipStream_t>(stream),
                      part, part + (size_t)S * taps * Cout * Cin, S, v, g, inv_norm, dv, dg, dbias, Cout, Cin, taps, accumulate);
+  return gt_launch_status(__func__);
+}
+
+extern "C" int gt_conv_wgrad_batched(const void* jobs_device, const void* tiles_device, int n_tiles5, int n_tiles3,
+                                     int n_tiles1, void* stream)
+{
+  if (!jobs_device || !tiles_device || n_tiles5 < 0 || n_tiles3 < 0 || n_tiles1 < 0) return GT_E_INVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const gt_wgrad_job* jobs = static_cast<const gt_wgrad_job*>(jobs_device);
+  const gt_wgrad_tile* tiles = static_cast<const gt_wgrad_tile*>(tiles_device);
+  if (n_tiles5) hipLaunchKernelGGL(gt_conv_wgrad_batched_kernel<5>, dim3(n_tiles5), dim3(256), 0, st, jobs, tiles);
+  if (n_tiles3) hipLaunchKernelGGL(gt_conv_wgrad_batched_kernel<3>, dim3(n_tiles3), dim3(256), 0, st, jobs, tiles + n_tiles5);
+  if (n_tiles1) hipLaunchKernelGGL(gt_conv_wgrad_batched_kernel<1>, dim3(n_tiles1), dim3(256), 0, st, jobs, tiles + n_tiles5 + n_tiles3);
+  return gt_launch_status(__func__);
+}
+
+extern "C" int gt_weightnorm_bwd_batched(const void* jobs_device, int n_jobs, int total_rows, int max_row_elems, void* stream)
+{
+  if (!jobs_device || n_jobs <= 0 || total_rows <= 0 || max_row_elems <= 0) return GT_E_INVAL;
+  const size_t lds = (size_t)max_row_elems * sizeof(float);
+  if (lds > 60 * 1024) return GT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gt_weightnorm_bwd_batched_kernel, dim3(total_rows), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     static_cast<const gt_wnb_job*>(jobs_device), n_jobs);
   return gt_launch_status(__func__);
 }
 

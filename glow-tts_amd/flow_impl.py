@@ -29,10 +29,19 @@ def _st(dev):
 
 
 # ----------------------------------------------------------------------------- conv parameter grads
-def conv_param_grads(conv, x, dy, R, want_bias=True):
+def conv_param_grads(conv, x, dy, R, want_bias=True, parts=None):
     """Gradients of a ConvP/WNConvP module's parameters from its input rows x (bf16) and output
     gradient rows dy (bf16): wgrad MFMA kernel -> slab partials -> weight-norm backward; bias by
-    column sums.  Returns {param: grad}."""
+    column sums.  Returns {param: grad}.  Inside a `wgrad.WgradQueue` block the work is only recorded
+    (x and dy must then stay untouched until the block ends) and the returned tensors are filled by the
+    queue's batched launches.  parts = [(dy_view, co_begin, co_count), ...] lets the output gradient live
+    in several buffers (res/skip halves of modules.py:166-168); it needs an open queue."""
+    from . import wgrad
+    q = wgrad.active()
+    if q is not None:
+        pl = [(x, dy, 0, conv.pc.Cout)] if parts is None else [(x, d, b, c) for d, b, c in parts]
+        return q.add(conv, R, pl, want_bias)
+    assert parts is None, "split output gradients need an open WgradQueue"
     L = _lib.lib()
     pc = conv.pc
     dev = x.device
@@ -141,12 +150,18 @@ def wn_bwd(rc, wn, saved, drs, want_dcond=False):
     dskip = drs[:, H:]
     dx_next = None          # gradient wrt x_{i+1} pre-mask (= drs[:, :H]) once available
     dcond = None if not want_dcond else torch.zeros(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    from . import wgrad
+    deferred = wgrad.active() is not None
     for i in reversed(range(n)):
         rs = wn.res_skip_layers[i]
         acts = acts_l[i]
         if i < n - 1:
             dacts = conv_rows(drs, rs.pc, rc, dgrad=True)                      # [R,H] = d_rs @ W_rs
-            grads.update(conv_param_grads(rs, acts, drs, R))
+            if deferred:                                                       # d res must outlive this layer
+                dres = drs[:, :H].clone()
+                grads.update(conv_param_grads(rs, acts, None, R, parts=[(dres, 0, H), (dskip, H, H)]))
+            else:
+                grads.update(conv_param_grads(rs, acts, drs, R))
         else:
             dacts = conv_rows(dskip, rs.pc, rc, dgrad=True)
             grads.update(conv_param_grads(rs, acts, dskip, R))

@@ -8,7 +8,7 @@ node whose forward/backward are explicit HIP kernel launch sequences (flow_impl.
 import torch
 from torch import nn
 
-from . import _lib, flow_impl
+from . import _lib, flow_impl, wgrad
 from .attentions import CouplingBlock, _wn_cond
 from .modules import ActNorm, InvConvNear, _RowsFn, _mask_lengths, prepare_all
 from .ops import HALO, RowsCtx
@@ -104,13 +104,14 @@ class _DecoderRunner:
             _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, st), "gt_squeeze_rows_f32")
         dconds = [None] * nb
         cur = drows
-        for b in reversed(range(nb)):
-            an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
-            s1, s2 = saved[b]
-            cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
-            grads.update(g2)
-            cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
-            grads.update(g1)
+        with wgrad.WgradQueue(dev, site=dec):           # data-gradient chain now, ALL weight gradients in one batch after it
+            for b in reversed(range(nb)):
+                an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+                s1, s2 = saved[b]
+                cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
+                grads.update(g2)
+                cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
+                grads.update(g1)
         dx = torch.zeros(B, C, T, dtype=torch.float32, device=dev) if T != T2 * 2 else torch.empty(B, C, T, dtype=torch.float32, device=dev)
         if T == T2 * 2:
             _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(dx), _lib.ptr(rc.lengths), B, C, T, rc.Tp, st), "gt_unsqueeze_rows_f32")

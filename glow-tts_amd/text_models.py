@@ -146,23 +146,25 @@ class _TextEncoderRunner:
         C = te.hidden_channels
         grads = {}
         dxb = None
-        if dx_m is not None:
-            d = rc.to_rows(dx_m.float(), torch.bfloat16)
-            grads.update(conv_param_grads(te.proj_m, xb_final, d, rc.R))
-            dxb = conv_rows(d, te.proj_m.pc, rc, dgrad=True)
-        if not te.mean_only and dx_logs is not None:
-            d = rc.to_rows(dx_logs.float(), torch.bfloat16)
-            grads.update(conv_param_grads(te.proj_s, xb_final, d, rc.R))
-            dxb = conv_rows(d, te.proj_s.pc, rc, dgrad=True, addend=dxb)
-        dx = rc.to_rows(dxo.float()) if dxo is not None else None
-        if dx is None and dxb is None:
+        if dxo is None and dx_m is None and (te.mean_only or dx_logs is None):
             return [None] * len(self.params)
-        if dx is None:
-            dx = torch.zeros(rc.R, C, dtype=torch.float32, device=dev)
-        for i in reversed(range(te.encoder.n_layers)):
-            dx, dxb = encoder_impl.layer_bwd(rc, te.encoder, i, s_layers[i], dx, dxb, grads)
-        if te.prenet:
-            dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
+        from . import wgrad
+        with wgrad.WgradQueue(dev, site=te):
+            if dx_m is not None:
+                d = rc.to_rows(dx_m.float(), torch.bfloat16)
+                grads.update(conv_param_grads(te.proj_m, xb_final, d, rc.R))
+                dxb = conv_rows(d, te.proj_m.pc, rc, dgrad=True)
+            if not te.mean_only and dx_logs is not None:
+                d2 = rc.to_rows(dx_logs.float(), torch.bfloat16)
+                grads.update(conv_param_grads(te.proj_s, xb_final, d2, rc.R))
+                dxb = conv_rows(d2, te.proj_s.pc, rc, dgrad=True, addend=dxb)
+            dx = rc.to_rows(dxo.float()) if dxo is not None else None
+            if dx is None:
+                dx = torch.zeros(rc.R, C, dtype=torch.float32, device=dev)
+            for i in reversed(range(te.encoder.n_layers)):
+                dx, dxb = encoder_impl.layer_bwd(rc, te.encoder, i, s_layers[i], dx, dxb, grads)
+            if te.prenet:
+                dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
         demb = torch.zeros_like(te.emb.weight)
         B, T = self.ids.shape
@@ -190,7 +192,9 @@ class _DurationRunner:
         grads = {}
         dout = torch.zeros(rc.B, rc.Tp, 8, dtype=torch.float32, device=rc.device)
         dout[:, HALO:HALO + rc.T, 0] = dlogw[:, 0].float()
-        encoder_impl.dp_bwd(rc, self.dp, saved, dout.reshape(rc.R, 8), grads)
+        from . import wgrad
+        with wgrad.WgradQueue(rc.device, site=self.dp):
+            encoder_impl.dp_bwd(rc, self.dp, saved, dout.reshape(rc.R, 8), grads)
         return [grads.get(p) for p in self.params]
 
 

@@ -1,0 +1,182 @@
+"""Deferred, batched parameter gradients of the rows-layout convolutions.
+
+The reference gets every conv's weight/bias gradient from autograd, one ATen call per module as the
+backward walks the graph (modules.py:127-171, attentions.py:103-259).  On one MI355X a single conv's
+wgrad is a small GEMM (a few GFLOP) that cannot fill 256 CUs, and its weight-norm backward is one more
+tiny launch.  HBM is plentiful (288 GB), so the backward keeps every layer's input rows and output-gradient
+rows alive, runs only the data-gradient chain, and at the end `WgradQueue.flush()` computes ALL weight
+gradients with one launch per tap count (`gt_conv_wgrad_batched`) and ALL weight-norm Jacobians / bias
+gradients with one more (`gt_weightnorm_bwd_batched`).
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+JOB = np.dtype([("X", "u8"), ("dY", "u8"), ("part", "u8"), ("part_bias", "u8"), ("ldx", "i4"), ("ldy", "i4"), ("R", "i4"),
+                ("Cin", "i4"), ("Cout", "i4"), ("co_begin", "i4"), ("co_count", "i4"), ("slab_rows", "i4")])
+TILE = np.dtype([("job", "i4"), ("co0", "i4"), ("ci0", "i4"), ("slab", "i4")])
+WNB = np.dtype([("part", "u8"), ("part_bias", "u8"), ("v", "u8"), ("g", "u8"), ("inv_norm", "u8"), ("dv", "u8"), ("dg", "u8"),
+                ("dbias", "u8"), ("S", "i4"), ("Cout", "i4"), ("Cin", "i4"), ("taps", "i4"), ("row_start", "i4"),
+                ("accumulate", "i4"), ("pad0_", "i4"), ("pad1_", "i4")])
+assert JOB.itemsize == 64 and TILE.itemsize == 16 and WNB.itemsize == 96
+
+# rows x taps one workgroup reduces over: bigger = fewer slab partials (HBM traffic), smaller = more workgroups
+ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
+MAX_SLABS = 8
+
+_ACTIVE = []            # stack of open queues
+_KEEP = []              # host tables referenced by captured graphs
+_SCRATCH = {}
+
+
+_POOL = []              # pinned staging buffers set aside (outside capture) for use inside a graph capture
+_POOL_N, _POOL_BYTES = 12, 1 << 19
+
+
+def _fill_pool():
+    while len(_POOL) < _POOL_N:
+        _POOL.append(torch.empty(_POOL_BYTES, dtype=torch.uint8).pin_memory())
+
+
+def active():
+    return _ACTIVE[-1] if _ACTIVE else None
+
+
+def _scratch(dev, nbytes):
+    buf = _SCRATCH.get(str(dev))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        _SCRATCH[str(dev)] = buf
+    return buf
+
+
+class WgradQueue:
+    """`with WgradQueue(dev) as q:` — conv_param_grads() inside only records (conv, x, dy) and hands back the
+    (still unwritten) gradient tensors; leaving the block launches the batched kernels that fill them."""
+
+    def __init__(self, device, site=None):
+        self.dev = device
+        self.site = site            # object that owns the cached tables (the runner's module)
+        self.items = []             # (conv, R, parts[(x, dy, co_begin, co_count)], dv, dg, db)
+
+    def __enter__(self):
+        _ACTIVE.append(self)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _ACTIVE.pop()
+        if et is None:
+            self.flush()
+        return False
+
+    def add(self, conv, R, parts, want_bias=True):
+        v = conv.weight_v if conv.weight_norm else conv.weight
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(conv.weight_g) if conv.weight_norm else None
+        db = torch.empty_like(conv.bias) if (want_bias and conv.bias is not None) else None
+        self.items.append((conv, R, parts, dv, dg, db))
+        out = {v: dv}
+        if dg is not None:
+            out[conv.weight_g] = dg
+        if db is not None:
+            out[conv.bias] = db
+        return out
+
+    def _plan(self):
+        """-> (key, job rows, tile rows, wnb rows, counts, scratch bytes)"""
+        jobs, wnbs, tiles = [], [], {5: [], 3: [], 1: []}
+        off = 0
+        row = 0
+        max_n = 1
+        for conv, R, parts, dv, dg, db in self.items:
+            pc = conv.pc
+            taps, Cin, Cout = pc.taps, pc.Cin, pc.Cout
+            S = min(MAX_SLABS, max(1, round(R * taps / ROWTAPS)))
+            slab_rows = -(-(-(-R // S)) // 64) * 64
+            S = -(-R // slab_rows)
+            part_off, off = off, off + S * taps * Cout * Cin * 4
+            pb_off, off = off, off + S * Cout * 4
+            off = (off + 255) & ~255
+            for x, dy, co_begin, co_count in parts:
+                assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.stride(1) == 1 and dy.stride(1) == 1
+                assert x.shape[0] >= R and dy.shape[0] >= R and x.shape[1] >= Cin and dy.shape[1] >= co_count
+                jid = len(jobs)
+                jobs.append((x.data_ptr(), dy.data_ptr(), part_off, pb_off if db is not None else -1, x.stride(0), dy.stride(0),
+                             R, Cin, Cout, co_begin, co_count, slab_rows))
+                tiles[taps].append((R * taps, jid, -(-co_count // 128), -(-Cin // 64), S))
+            v = conv.weight_v if conv.weight_norm else conv.weight
+            wnbs.append((part_off, pb_off, v.data_ptr(), conv.weight_g.data_ptr() if dg is not None else 0,
+                         pc.inv_norm.data_ptr() if dg is not None else 0, dv.data_ptr(), dg.data_ptr() if dg is not None else 0,
+                         db.data_ptr() if db is not None else 0, S, Cout, Cin, taps, row, 0, 0, 0))
+            row += Cout
+            max_n = max(max_n, Cin * taps)
+        return jobs, tiles, wnbs, row, max_n, off
+
+    def flush(self):
+        if not self.items:
+            return
+        L = _lib.lib()
+        dev = self.dev
+        jobs, tiles, wnbs, rows, max_n, nbytes = self._plan()
+        ws = _scratch(dev, nbytes)
+        base = ws.data_ptr()
+        capturing = torch.cuda.is_current_stream_capturing()
+
+        def upload(arr):
+            raw = arr.view(np.uint8).reshape(-1)
+            if capturing:
+                # pinned allocation is illegal while a stream is capturing: take a buffer set aside earlier; the
+                # graph's copy node reads it at every replay, so it is never reused
+                if not _POOL or raw.size > _POOL_BYTES:
+                    raise RuntimeError("wgrad tables: no pinned staging buffer available inside graph capture "
+                                       "(run one eager step first)")
+                host = _POOL.pop()[: raw.size]
+                host.numpy()[:] = raw
+                _KEEP.append(host)
+            else:
+                host = torch.from_numpy(raw).pin_memory()
+            return host.to(dev, non_blocking=True)
+
+        if capturing:
+            cache = {}                                   # tables of a captured step belong to the graph alone
+        else:
+            _fill_pool()
+            cache = getattr(self.site, "_wgrad_tables", None) if self.site is not None else None
+            if cache is None:
+                cache = {}
+                if self.site is not None:
+                    object.__setattr__(self.site, "_wgrad_tables", cache)
+        # tiles depend on shapes only
+        skey = tuple((t, tuple(x[2:] for x in tiles[t]), tuple(j[6:] for j in jobs)) for t in (5, 3, 1))
+        if cache.get("skey") != skey:
+            tl, counts = [], []
+            for taps in (5, 3, 1):
+                n = 0
+                order = sorted(range(len(tiles[taps])), key=lambda i: -tiles[taps][i][0])       # heavy tiles first
+                for i in order:
+                    _, jid, nco, nci, S = tiles[taps][i]
+                    g = np.stack(np.meshgrid(np.arange(nco) * 128, np.arange(nci) * 64, np.arange(S), indexing="ij"), -1).reshape(-1, 3)
+                    t = np.zeros(len(g), dtype=TILE)
+                    t["job"], t["co0"], t["ci0"], t["slab"] = jid, g[:, 0], g[:, 1], g[:, 2]
+                    tl.append(t)
+                    n += len(g)
+                counts.append(n)
+            ta = np.concatenate(tl) if tl else np.zeros(1, dtype=TILE)
+            cache["skey"], cache["tiles"], cache["counts"] = skey, upload(ta), counts
+            cache["pkey"] = None
+        pkey = (base, tuple(j[:4] for j in jobs), tuple(w[2:8] for w in wnbs))
+        if cache.get("pkey") != pkey:
+            ja = np.array([(j[0], j[1], base + j[2], (base + j[3]) if j[3] >= 0 else 0) + j[4:] for j in jobs], dtype=JOB)
+            wa = np.array([(base + w[0], base + w[1]) + w[2:] for w in wnbs], dtype=WNB)
+            cache["pkey"], cache["jobs"], cache["wnb"] = pkey, upload(ja), upload(wa)
+        counts = cache["counts"]
+        st = _lib.current_stream(dev)
+        _lib.check(L.gt_conv_wgrad_batched(_lib.ptr(cache["jobs"]), _lib.ptr(cache["tiles"]), counts[0], counts[1], counts[2], st),
+                   "gt_conv_wgrad_batched")
+        _lib.check(L.gt_weightnorm_bwd_batched(_lib.ptr(cache["wnb"]), len(wnbs), rows, max_n, st), "gt_weightnorm_bwd_batched")
+        if capturing:
+            _KEEP.append(cache)
+        self.items = []

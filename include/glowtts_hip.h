@@ -152,6 +152,28 @@ int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, i
 int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
                       float* dv, float* dg, float* dbias, int Cout, int Cin, int taps, int accumulate, void* stream);
 
+/* Batched forms: the weight gradients of a whole network in one launch per tap count, after the
+ * data-gradient chain has run (every job's X and dY rows stay resident in HBM until then), and ONE
+ * weight-norm backward over all of them.  Tables live in device memory.
+ *   job:  dY column c is output channel co_begin + c (co_count columns) of a conv with Cout channels whose
+ *         partials are part[S][taps][Cout][Cin] (+ part_bias[S][Cout], may be NULL); slab_rows % 64 == 0.
+ *   tile: one workgroup = 128 dY columns from co0 x 64 input channels from ci0 x all taps x rows of `slab`;
+ *         tiles are ordered taps 5, then 3, then 1.
+ *   wnb job: as gt_weightnorm_bwd, rows [row_start, row_start + Cout) of the launch. */
+typedef struct gt_wgrad_job {
+  const void* X; const void* dY; float* part; float* part_bias;
+  int32_t ldx, ldy, R, Cin, Cout, co_begin, co_count, slab_rows;
+} gt_wgrad_job;
+typedef struct gt_wgrad_tile { int32_t job, co0, ci0, slab; } gt_wgrad_tile;
+typedef struct gt_wnb_job {
+  const float* part; const float* part_bias; const float* v; const float* g; const float* inv_norm;
+  float* dv; float* dg; float* dbias;
+  int32_t S, Cout, Cin, taps, row_start, accumulate, pad0_, pad1_;
+} gt_wnb_job;
+int gt_conv_wgrad_batched(const void* jobs_device, const void* tiles_device, int n_tiles5, int n_tiles3,
+                          int n_tiles1, void* stream);
+int gt_weightnorm_bwd_batched(const void* jobs_device, int n_jobs, int total_rows, int max_row_elems, void* stream);
+
 /* out[n] += sum_m Y[m,n]  (bias gradients); Y bf16 (is_f32 == 0) or fp32 rows. */
 int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void* stream);
 
