@@ -8,7 +8,7 @@ arguments and state_dict keys); arithmetic in HIP kernels behind the C-ABI.
 import torch
 from torch import nn
 
-from . import flow_impl
+from . import flow_impl, wgrad
 from .modules import WN, ConvP, WNConvP, _RowsFn, _mask_lengths, prepare_all
 from .ops import RowsCtx
 
@@ -76,7 +76,8 @@ class _CouplingRunner:
         rc, saved = saved_all
         dlogdet = torch.zeros(rc.B, device=dz.device) if dlogdet is None else dlogdet.contiguous().float()
         dzr = rc.to_rows(dz.float())
-        dx, grads, dcond = flow_impl.coupling_bwd(rc, self.cb, saved, dzr, dlogdet, self.has_cond)
+        with wgrad.WgradQueue(dz.device, site=self.cb):
+            dx, grads, dcond = flow_impl.coupling_bwd(rc, self.cb, saved, dzr, dlogdet, self.has_cond)
         out = [rc.from_rows(dx)]
         if self.has_cond:
             out.append(dcond)
@@ -143,7 +144,8 @@ class _MHARunner:
     def backward(self, saved_all, dy, _dp):
         rc, saved = saved_all
         grads = {}
-        dxb = encoder_impl.mha_bwd(rc, self.att, saved, rc.to_rows(dy, torch.bfloat16), grads)
+        with wgrad.WgradQueue(dy.device, site=self.att):
+            dxb = encoder_impl.mha_bwd(rc, self.att, saved, rc.to_rows(dy, torch.bfloat16), grads)
         return [rc.from_rows(dxb, torch.float32) * self.x_mask] + [grads.get(p) for p in self.params]
 
 
@@ -210,7 +212,8 @@ class _EncoderRunner:
         rc, saved = saved_all
         grads = {}
         dx, dxb = rc.to_rows(dout.float() * self.x_mask), None
-        for i in reversed(range(self.enc.n_layers)):
-            dx, dxb = encoder_impl.layer_bwd(rc, self.enc, i, saved[i], dx, dxb, grads)
+        with wgrad.WgradQueue(dout.device, site=self.enc):
+            for i in reversed(range(self.enc.n_layers)):
+                dx, dxb = encoder_impl.layer_bwd(rc, self.enc, i, saved[i], dx, dxb, grads)
         tot = rc.from_rows(dx) + rc.from_rows(dxb, torch.float32)
         return [tot * self.x_mask] + [grads.get(p) for p in self.params]

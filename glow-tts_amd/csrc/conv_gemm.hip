@@ -20,6 +20,7 @@
 // (conflict-free ds_read_b128 for 16 distinct rows), weights and activations double-buffered
 // in LDS with register prefetch (global loads of step i+1 fly under the MFMAs of step i), one
 // barrier per (K-slice, tap) step, 2 workgroups per CU.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/glowtts_hip.h"
 
@@ -44,6 +45,8 @@ struct ConvArgs {
   int out_f32, relu;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // gate dropout (modules.py:153)
   const uint32_t* seed_dev;                            // optional device word XOR-ed into drop_seed (graph replay)
+  int exp_;                                            // EXPERIMENT bits (dev only)
+  int y16;                                             // Y rows allow 16-byte bf16 stores (ldy % 8 == 0, base 16-B aligned)
 };
 
 template <int BN, bool GATE>
@@ -54,8 +57,12 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
   constexpr int MB = BM / (32 * WM);          // 32-row MFMA blocks per wave
   constexpr int WCH = BN / 32;                // weight 16-B chunks per thread per tile
 
-  __shared__ __attribute__((aligned(16))) bf16_t Xs[2][XROWS * LDP];
-  __shared__ __attribute__((aligned(16))) bf16_t Ws[2][BN * LDP];
+  constexpr int XS_HALFS = XROWS * LDP, WS_HALFS = BN * LDP;
+  constexpr int EP = BN + 4;                  // epilogue tile pitch in floats (== 4 mod 64 banks: conflict-free b128 rows)
+  constexpr int MAIN_BYTES = 2 * (XS_HALFS + WS_HALFS) * 2, EPI_BYTES = BM * EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  bf16_t (*Xs)[XS_HALFS] = reinterpret_cast<bf16_t (*)[XS_HALFS]>(smem);
+  bf16_t (*Ws)[WS_HALFS] = reinterpret_cast<bf16_t (*)[WS_HALFS]>(smem + 2 * XS_HALFS * 2);
 
   if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
     const int nxt = it + 1;
     const bool has = nxt < NIT;
     const bool newslice = has && (tap == taps - 1);
-    if (has) { load_W(nxt); if (newslice) load_X(slice + 1); }
+    if (has && !(a.exp_ & 2)) { load_W(nxt); if (newslice) load_X(slice + 1); }
 
     const bf16_t* wsb = &Ws[it & 1][(64 * wn + r) * LDP + 8 * h];
     const bf16_t* xsb = &Xs[slice & 1][(mrow0 + r + tap) * LDP + 8 * h];
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
           acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[bn], bfm[bm], acc[bn][bm], 0, 0, 0);
     }
 
-    if (has) { store_W(nxt & 1); if (newslice) store_X((slice + 1) & 1); }
+    if (has && !(a.exp_ & 2)) { store_W(nxt & 1); if (newslice) store_X((slice + 1) & 1); }
     __syncthreads();
   }
 
@@ -140,98 +147,155 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
 #undef load_X
 #undef store_X
   // ------------------------------------------------------------------ epilogue
-  // Side loads (bias / cond / addend / mask) of one 32-row block are issued as a batch under ONE
-  // uniform branch each, then consumed: a load-and-wait per 4-channel group would serialise ~16
-  // L2 round trips behind the last MFMA.
+  // Phase 1: every wave drops its fp32 accumulators into an LDS tile [128 rows][BN channels] (the main loop's
+  // last barrier has retired all reads of Xs/Ws).  Phase 2: a thread owns (row, 8 consecutive channels) chunks,
+  // so bias / cond / addend loads and all stores are 16-32 B per lane and whole 128-B lines per row — the MFMA
+  // layout itself gives only 8 B per lane with a row stride between lanes.
+  float* es = reinterpret_cast<float*>(smem);
+  if (a.exp_ & 1) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc += acc[i][j][e];
+    if (sacc == 123.456f) static_cast<bf16_t*>(a.Y)[tid] = 1;
+    return;
+  }
+#pragma unroll
+  for (int bm = 0; bm < MB; ++bm)
+#pragma unroll
+    for (int bn = 0; bn < 2; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(&es[(mrow0 + 32 * bm + r) * EP + 64 * wn + 32 * bn + 8 * g + 4 * h]) =
+            make_float4(acc[bn][bm][4 * g], acc[bn][bm][4 * g + 1], acc[bn][bm][4 * g + 2], acc[bn][bm][4 * g + 3]);
+  __syncthreads();
+
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (GATE) {
+    // 64 gate channels per tile; packed columns: [32 tanh | 32 sigmoid] per 64
+    constexpr int NCH = (BM * (BN / 2) / 8) / 256;                   // chunks per thread (4)
+    const int half = a.N >> 1;
 #pragma unroll
-  for (int bm = 0; bm < MB; ++bm) {
-    const int m = m0 + mrow0 + 32 * bm + r;
-    const bool mvalid = m < a.R;
-    const int mm = mvalid ? m : a.R - 1;
-    const float rm = a.rowmask ? a.rowmask[mm] : 1.0f;
-    const int b = a.cond ? (mm / a.Tp) : 0;
-    if (GATE) {
-      const int half = a.N >> 1;
-      const int cb = (n0 >> 1) + 32 * wn + 4 * h;                    // gate channel of group 0 (+ 8g)
-      float4 bt[4] = {z4, z4, z4, z4}, bs[4] = {z4, z4, z4, z4}, ct[4] = {z4, z4, z4, z4}, cs[4] = {z4, z4, z4, z4};
+    for (int j = 0; j < NCH; ++j) {
+      const int q = tid + 256 * j, row = q >> 3, c = (q & 7) * 8;     // gate channel within the tile
+      const int m = m0 + row;
+      if (m >= a.R) continue;
+      const int cg = (n0 >> 1) + c;                                  // global gate channel
+      const float* et = &es[row * EP + (c >> 5) * 64 + (c & 31)];
+      float4 t0 = *reinterpret_cast<const float4*>(et), t1 = *reinterpret_cast<const float4*>(et + 4);
+      float4 s0 = *reinterpret_cast<const float4*>(et + 32), s1 = *reinterpret_cast<const float4*>(et + 36);
+      float4 bt0 = z4, bt1 = z4, bs0 = z4, bs1 = z4, ct0 = z4, ct1 = z4, cs0 = z4, cs1 = z4;
       if (a.bias) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { bt[g] = *reinterpret_cast<const float4*>(a.bias + cb + 8 * g);
-                                      bs[g] = *reinterpret_cast<const float4*>(a.bias + half + cb + 8 * g); }
+        bt0 = *reinterpret_cast<const float4*>(a.bias + cg);        bt1 = *reinterpret_cast<const float4*>(a.bias + cg + 4);
+        bs0 = *reinterpret_cast<const float4*>(a.bias + half + cg); bs1 = *reinterpret_cast<const float4*>(a.bias + half + cg + 4);
       }
       if (a.cond) {
-        const float* cp = a.cond + (size_t)b * a.ldc + cb;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { ct[g] = *reinterpret_cast<const float4*>(cp + 8 * g);
-                                      cs[g] = *reinterpret_cast<const float4*>(cp + half + 8 * g); }
+        const float* cp = a.cond + (size_t)(m / a.Tp) * a.ldc + cg;
+        ct0 = *reinterpret_cast<const float4*>(cp);        ct1 = *reinterpret_cast<const float4*>(cp + 4);
+        cs0 = *reinterpret_cast<const float4*>(cp + half); cs1 = *reinterpret_cast<const float4*>(cp + half + 4);
       }
-      if (!mvalid) continue;
+      const float pt_[8] = {t0.x + bt0.x, t0.y + bt0.y, t0.z + bt0.z, t0.w + bt0.w, t1.x + bt1.x, t1.y + bt1.y, t1.z + bt1.z, t1.w + bt1.w};
+      const float ps_[8] = {s0.x + bs0.x, s0.y + bs0.y, s0.z + bs0.z, s0.w + bs0.w, s1.x + bs1.x, s1.y + bs1.y, s1.z + bs1.z, s1.w + bs1.w};
+      const float ct_[8] = {ct0.x, ct0.y, ct0.z, ct0.w, ct1.x, ct1.y, ct1.z, ct1.w};
+      const float cs_[8] = {cs0.x, cs0.y, cs0.z, cs0.w, cs1.x, cs1.y, cs1.z, cs1.w};
+      float tt[8], ss[8], aa[8];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = cb + 8 * g;
-        const float bt_[4] = {bt[g].x, bt[g].y, bt[g].z, bt[g].w}, bs_[4] = {bs[g].x, bs[g].y, bs[g].z, bs[g].w};
-        const float ct_[4] = {ct[g].x, ct[g].y, ct[g].z, ct[g].w}, cs_[4] = {cs[g].x, cs[g].y, cs[g].z, cs[g].w};
-        float tt[4], ss[4], aa[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float pt = acc[0][bm][4 * g + i] + bt_[i], ps = acc[1][bm][4 * g + i] + bs_[i];
-          if (a.drop_thresh) {                                       // x_in = drop(conv(x))
-            pt = drop_keep(a.drop_seed, m, c + i, a.drop_thresh) ? pt * a.drop_scale : 0.0f;
-            ps = drop_keep(a.drop_seed, m, half + c + i, a.drop_thresh) ? ps * a.drop_scale : 0.0f;
-          }
-          pt += ct_[i]; ps += cs_[i];
-          tt[i] = tanhf_(pt); ss[i] = sigmoidf_(ps); aa[i] = tt[i] * ss[i];
+      for (int i = 0; i < 8; ++i) {
+        float pt = pt_[i], ps = ps_[i];
+        if (a.drop_thresh) {                                         // x_in = drop(conv(x))
+          pt = drop_keep(a.drop_seed, m, cg + i, a.drop_thresh) ? pt * a.drop_scale : 0.0f;
+          ps = drop_keep(a.drop_seed, m, half + cg + i, a.drop_thresh) ? ps * a.drop_scale : 0.0f;
         }
-        *reinterpret_cast<uint2*>(a.Tout + (size_t)m * a.ldts + c) = make_uint2(pack2bf(tt[0], tt[1]), pack2bf(tt[2], tt[3]));
-        *reinterpret_cast<uint2*>(a.Sout + (size_t)m * a.ldts + c) = make_uint2(pack2bf(ss[0], ss[1]), pack2bf(ss[2], ss[3]));
-        *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + c) =
-            make_uint2(pack2bf(aa[0], aa[1]), pack2bf(aa[2], aa[3]));
+        pt += ct_[i]; ps += cs_[i];
+        tt[i] = tanhf_(pt); ss[i] = sigmoidf_(ps); aa[i] = tt[i] * ss[i];
       }
-    } else {
+      *reinterpret_cast<uint4*>(a.Tout + (size_t)m * a.ldts + cg) =
+          make_uint4(pack2bf(tt[0], tt[1]), pack2bf(tt[2], tt[3]), pack2bf(tt[4], tt[5]), pack2bf(tt[6], tt[7]));
+      *reinterpret_cast<uint4*>(a.Sout + (size_t)m * a.ldts + cg) =
+          make_uint4(pack2bf(ss[0], ss[1]), pack2bf(ss[2], ss[3]), pack2bf(ss[4], ss[5]), pack2bf(ss[6], ss[7]));
+      *reinterpret_cast<uint4*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + cg) =
+          make_uint4(pack2bf(aa[0], aa[1]), pack2bf(aa[2], aa[3]), pack2bf(aa[4], aa[5]), pack2bf(aa[6], aa[7]));
+    }
+  } else {
+    constexpr int NCH = (BM * BN / 8) / 256;                         // 8 (BN=128) or 4 (BN=64) chunks per thread
+    constexpr int CPR = BN / 8;                                      // chunks per row
+    // side loads of all chunks first (one exposed latency), then the math and the stores
+    uint4 adq[NCH][2];
+    float rmq[NCH];
 #pragma unroll
-      for (int bn = 0; bn < 2; ++bn) {
-        const int nb = n0 + 64 * wn + 32 * bn + 4 * h;               // channel of group 0 (+ 8g)
-        int nn[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { const int n = nb + 8 * g; nn[g] = n < a.N ? n : a.N - 4; }   // clamped load address
-        float4 bb[4] = {z4, z4, z4, z4}, cc[4] = {z4, z4, z4, z4}, ad[4] = {z4, z4, z4, z4};
-        if (a.bias) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) bb[g] = *reinterpret_cast<const float4*>(a.bias + nn[g]);
-        }
-        if (a.cond) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) cc[g] = *reinterpret_cast<const float4*>(a.cond + (size_t)b * a.ldc + nn[g]);
-        }
+    for (int j = 0; j < NCH; ++j) {
+      const int q = tid + 256 * j, row = q / CPR, c = (q % CPR) * 8;
+      const int m = m0 + row, n = n0 + c;
+      adq[j][0] = make_uint4(0, 0, 0, 0); adq[j][1] = make_uint4(0, 0, 0, 0);
+      rmq[j] = 1.0f;
+      if (m < a.R && n < a.N) {
+        if (a.rowmask) rmq[j] = a.rowmask[m];
         if (a.addend) {
           if (a.out_f32) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ad[g] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.addend) + (size_t)mm * a.ldadd + nn[g]);
+            const float* ap = static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n;
+            adq[j][0] = *reinterpret_cast<const uint4*>(ap);
+            if (n + 4 < a.N) adq[j][1] = *reinterpret_cast<const uint4*>(ap + 4);
           } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(a.addend) + (size_t)mm * a.ldadd + nn[g]);
-              ad[g] = make_float4(bf2f(u.x & 0xffff), bf2f(u.x >> 16), bf2f(u.y & 0xffff), bf2f(u.y >> 16));
-            }
+            const bf16_t* ap = static_cast<const bf16_t*>(a.addend) + (size_t)m * a.ldadd + n;
+            const uint2 lo = *reinterpret_cast<const uint2*>(ap);
+            uint2 hi = make_uint2(0, 0);
+            if (n + 4 < a.N) hi = *reinterpret_cast<const uint2*>(ap + 4);
+            adq[j][0] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
         }
-        if (!mvalid) continue;
+      }
+    }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g;
-          if (n >= a.N) continue;                                    // N % 4 == 0
-          float v[4] = {acc[bn][bm][4 * g] + bb[g].x + cc[g].x, acc[bn][bm][4 * g + 1] + bb[g].y + cc[g].y,
-                        acc[bn][bm][4 * g + 2] + bb[g].z + cc[g].z, acc[bn][bm][4 * g + 3] + bb[g].w + cc[g].w};
-          if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          if (a.drop_thresh) {                                       // dropout after the activation (attentions.py:370)
+    for (int j = 0; j < NCH; ++j) {
+      const int q = tid + 256 * j, row = q / CPR, c = (q % CPR) * 8;
+      const int m = m0 + row, n = n0 + c;
+      if (m >= a.R || n >= a.N) continue;                            // N % 4 == 0
+      const bool full = n + 4 < a.N;                                 // second 4-channel half valid
+      const float* ep = &es[row * EP + c];
+      const float4 e0 = *reinterpret_cast<const float4*>(ep), e1 = *reinterpret_cast<const float4*>(ep + 4);
+      float v[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      const int n1 = full ? n + 4 : n;                               // clamped address of the second half
+      if (a.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n), b1 = *reinterpret_cast<const float4*>(a.bias + n1);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (a.cond) {
+        const float* cp = a.cond + (size_t)(m / a.Tp) * a.ldc;
+        const float4 c0 = *reinterpret_cast<const float4*>(cp + n), c1 = *reinterpret_cast<const float4*>(cp + n1);
+        v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+      }
+      if (a.relu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = drop_keep(a.drop_seed, m, n + i, a.drop_thresh) ? v[i] * a.drop_scale : 0.0f;
-          }
-          v[0] = (v[0] + ad[g].x) * rm; v[1] = (v[1] + ad[g].y) * rm; v[2] = (v[2] + ad[g].z) * rm; v[3] = (v[3] + ad[g].w) * rm;
-          if (a.out_f32) *reinterpret_cast<float4*>(static_cast<float*>(a.Y) + (size_t)m * a.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-          else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        }
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+      }
+      if (a.drop_thresh) {                                           // dropout after the activation (attentions.py:370)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = drop_keep(a.drop_seed, m, n + i, a.drop_thresh) ? v[i] * a.drop_scale : 0.0f;
+      }
+      float ad[8];
+      if (a.out_f32) {
+        ad[0] = __uint_as_float(adq[j][0].x); ad[1] = __uint_as_float(adq[j][0].y); ad[2] = __uint_as_float(adq[j][0].z); ad[3] = __uint_as_float(adq[j][0].w);
+        ad[4] = __uint_as_float(adq[j][1].x); ad[5] = __uint_as_float(adq[j][1].y); ad[6] = __uint_as_float(adq[j][1].z); ad[7] = __uint_as_float(adq[j][1].w);
+      } else {
+        const uint4 u = adq[j][0];
+        ad[0] = bf2f(u.x & 0xffff); ad[1] = bf2f(u.x >> 16); ad[2] = bf2f(u.y & 0xffff); ad[3] = bf2f(u.y >> 16);
+        ad[4] = bf2f(u.z & 0xffff); ad[5] = bf2f(u.z >> 16); ad[6] = bf2f(u.w & 0xffff); ad[7] = bf2f(u.w >> 16);
+      }
+      const float rm = rmq[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (v[i] + ad[i]) * rm;
+      if (a.out_f32) {
+        float* yp = static_cast<float*>(a.Y) + (size_t)m * a.ldy + n;
+        *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+        if (full) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        bf16_t* yp = static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n;
+        const uint2 lo = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])), hi = make_uint2(pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+        if (full && a.y16) *reinterpret_cast<uint4*>(yp) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        else { *reinterpret_cast<uint2*>(yp) = lo; if (full) *reinterpret_cast<uint2*>(yp + 4) = hi; }
       }
     }
   }
@@ -320,6 +384,8 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   a.Tout = static_cast<bf16_t*>(gate_t); a.Sout = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
   a.R = R; a.N = N; a.Cin = Cin; a.taps = taps; a.Tp = Tp > 0 ? Tp : 1; a.Np = Np; a.Kp = Kp;
   a.out_f32 = out_f32; a.relu = relu;
+  a.y16 = !(ldy & 7);
+  { static int ex = -1; if (ex < 0) { const char* e = getenv("GT_CONV_EXP"); ex = e ? atoi(e) : 0; } a.exp_ = ex; }
   a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f; a.seed_dev = seed_dev;
   if (drop_p > 0.0f) {
     if (drop_p >= 1.0f) return GT_E_UNSUPPORTED;
@@ -328,7 +394,8 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
   if (gate) {
-    if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32 || (ldts & 3)) return GT_E_INVAL;
+    if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
+    if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
     hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);
   } else if (Np % 128 == 0) {
     if (Np < N) return GT_E_INVAL;
@@ -345,7 +412,7 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
                                     int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream)
 {
   if (Cout <= 0 || Cin <= 0 || taps < 1 || taps > MAXTAPS) return GT_E_INVAL;
-  if (!v || (!pack_fwd && !pack_dgrad)) return GT_E_INVAL;
+  if (!v || (!pack_fwd && !pack_dgrad && !(g && inv_norm))) return GT_E_INVAL;
   if (pack_fwd && (Np_fwd < Cout || Kp_fwd < Cin)) return GT_E_INVAL;
   if (pack_dgrad && (Np_dgrad < Cin || Kp_dgrad < Cout)) return GT_E_INVAL;
   if (gate && (Cout % 128)) return GT_E_UNSUPPORTED;

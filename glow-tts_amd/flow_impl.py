@@ -41,7 +41,8 @@ def conv_param_grads(conv, x, dy, R, want_bias=True, parts=None):
     if q is not None:
         pl = [(x, dy, 0, conv.pc.Cout)] if parts is None else [(x, d, b, c) for d, b, c in parts]
         return q.add(conv, R, pl, want_bias)
-    assert parts is None, "split output gradients need an open WgradQueue"
+    if parts is not None:                     # immediate mode: gather the pieces into one [R, Cout] buffer
+        dy = torch.cat([d[:, :c] for d, _, c in sorted(parts, key=lambda t: t[1])], dim=1)
     L = _lib.lib()
     pc = conv.pc
     dev = x.device
@@ -108,62 +109,55 @@ def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
 # ----------------------------------------------------------------------------- WN
 def wn_fwd(rc, wn, h0, cond, train, seed):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None.
-    Returns out [R,H] bf16 (= skip sum * mask) and saved activations."""
+    Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
+
+    The gated activations of all layers live side by side in ONE [R, n*H] buffer: the residual 1x1 reads its
+    own window, and output = sum_i skip_i(acts_i) (modules.py:168-170) is a single K = n*H GEMM at the end
+    instead of n read-modify-write passes over an fp32 accumulator."""
     R, H = h0.shape
     dev = h0.device
     n = wn.n_layers
     p = wn.p_dropout if train else 0.0
-    xs, ts, ss, acts_l = [h0], [], [], []
-    skip = torch.zeros(R, H, dtype=torch.float32, device=dev)
+    xs, ts, ss = [h0], [], []
+    acts_all = torch.empty(R, n * H, dtype=torch.bfloat16, device=dev)
     x = h0
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
-        acts, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True,
-                               drop_p=p, seed=seed + i, tag="in_layer_gate_conv")
-        ts.append(t); ss.append(s); acts_l.append(acts)
-        rs = wn.res_skip_layers[i]
+        acts = acts_all[:, i * H:(i + 1) * H]
+        _, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True, out=acts,
+                            drop_p=p, seed=seed + i, tag="in_layer_gate_conv")
+        ts.append(t); ss.append(s)
         if i < n - 1:
+            rs = wn.res_skip_layers[i]
             # rows [0,H) of the weight -> residual, rows [H,2H) -> skip (modules.py:166-168)
-            xn = conv_rows(acts, rs.pc_res, rc, bias=rs.bias[:H], addend=x, mask=True)
-            conv_rows(acts, rs.pc_skip, rc, bias=rs.bias[H:], addend=skip, out=skip)
-            x = xn
+            x = conv_rows(acts, rs.pc_res, rc, bias=rs.bias[:H], addend=x, mask=True)
             xs.append(x)
-        else:
-            conv_rows(acts, rs.pc, rc, bias=rs.bias, addend=skip, out=skip)
-    out = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
-    L = _lib.lib()
-    _lib.check(L.gt_rows_f32_to_bf16(_lib.ptr(skip), H, _lib.ptr(out), H, _lib.ptr(rc.rowmask), R, H, _st(dev)),
-               "gt_rows_f32_to_bf16")
-    return out, (xs, ts, ss, acts_l, p, seed)
+    out = conv_rows(acts_all, wn.pc_skipcat, rc, bias=wn.skip_bias, mask=True)
+    return out, (xs, ts, ss, acts_all, p, seed)
 
 
-def wn_bwd(rc, wn, saved, drs, want_dcond=False):
-    """drs: [R,2H] bf16 work buffer whose columns [H,2H) hold the MASKED gradient of the wn output
-    (= d skip of every layer, since out = skip*mask); columns [0,H) are scratch.
+def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
+    """dskip: [R,H] bf16, the MASKED gradient of the wn output (= d skip of every layer, since out = skip*mask).
     Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond)."""
     L = _lib.lib()
-    xs, ts, ss, acts_l, p, seed = saved
-    R, H = drs.shape[0], drs.shape[1] // 2
-    dev = drs.device
+    xs, ts, ss, acts_all, p, seed = saved
+    R, H = dskip.shape
+    dev = dskip.device
     n = wn.n_layers
     grads = {}
-    dskip = drs[:, H:]
-    dx_next = None          # gradient wrt x_{i+1} pre-mask (= drs[:, :H]) once available
     dcond = None if not want_dcond else torch.zeros(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
-    from . import wgrad
-    deferred = wgrad.active() is not None
+    # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
+    dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
+    dres = None             # gradient arriving at x_{i+1} (masked), i.e. at res_i's output
     for i in reversed(range(n)):
         rs = wn.res_skip_layers[i]
-        acts = acts_l[i]
+        acts = acts_all[:, i * H:(i + 1) * H]
+        via_skip = dacts_skip[:, i * H:(i + 1) * H]
         if i < n - 1:
-            dacts = conv_rows(drs, rs.pc, rc, dgrad=True)                      # [R,H] = d_rs @ W_rs
-            if deferred:                                                       # d res must outlive this layer
-                dres = drs[:, :H].clone()
-                grads.update(conv_param_grads(rs, acts, None, R, parts=[(dres, 0, H), (dskip, H, H)]))
-            else:
-                grads.update(conv_param_grads(rs, acts, drs, R))
+            dacts = conv_rows(dres, rs.pc_res, rc, dgrad=True, addend=via_skip)
+            grads.update(conv_param_grads(rs, acts, None, R, parts=[(dres, 0, H), (dskip, H, H)]))
         else:
-            dacts = conv_rows(dskip, rs.pc, rc, dgrad=True)
+            dacts = via_skip
             grads.update(conv_param_grads(rs, acts, dskip, R))
         dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
         dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if (want_dcond and p > 0) else None
@@ -174,13 +168,9 @@ def wn_bwd(rc, wn, saved, drs, want_dcond=False):
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre
             dcond[:, 2 * H * i:2 * H * (i + 1)] = src.float().reshape(rc.B, rc.Tp, 2 * H).sum(1)
-        # d x_i = dgrad(in_layer) + (residual path) ;  then through the mask of x_i's producer
-        if i > 0:
-            conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=(drs[:, :H] if i < n - 1 else None), mask=True,
-                      out=drs[:, :H])
-        else:
-            dh0 = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=(drs[:, :H] if n > 1 else None), mask=True)
-    return dh0, grads, dcond
+        # d x_i = dgrad(in_layer) + (residual path), then through the mask of x_i's producer
+        dres = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=dres, mask=True)
+    return dres, grads, dcond
 
 
 # ----------------------------------------------------------------------------- coupling block
@@ -208,10 +198,8 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
     _lib.check(L.gt_coupling_bwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dlogdet), _lib.ptr(rc.rowmask),
                                  _lib.ptr(dx), _lib.ptr(dout), R, C, rc.Tp, int(cb.sigmoid_scale), _st(dev)), "gt_coupling_bwd")
     grads = conv_param_grads(cb.end, wn_out, dout, R)
-    H = cb.hidden_channels
-    drs = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
-    conv_rows(dout, cb.end.pc, rc, dgrad=True, mask=True, out=drs[:, H:])         # d(wn out) * mask = d skip
-    dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, drs, want_dcond)
+    dskip = conv_rows(dout, cb.end.pc, rc, dgrad=True, mask=True)                # d(wn out) * mask = d skip
+    dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, dskip, want_dcond)
     grads.update(g2)
     grads.update(conv_param_grads(cb.start, x0_bf16, dh0, R))                    # dh0 is already masked
     dx0 = conv_rows(dh0, cb.start.pc, rc, dgrad=True)

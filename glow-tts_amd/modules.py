@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib, flow_impl
-from .ops import PackedConv, RowsCtx
+from .ops import PackSlice, PackedConv, RowsCtx
 
 
 class ConvP(nn.Module):
@@ -66,33 +66,43 @@ class WNConvP(ConvP):
         del self.weight
         self.weight_g = nn.Parameter(v.reshape(out_channels, -1).norm(dim=1).reshape(out_channels, 1, 1).clone())
         self.weight_v = nn.Parameter(v.clone())
-        self.split_res_skip = split_res_skip
-        self.pc_res = self.pc_skip = None
+        self.split_res_skip = split_res_skip       # res_skip layer of a WN: rows [0,h) residual, [h,2h) skip
+        self.skip_slice = None                     # set by the owning WN: where the skip rows are packed
+        self.pc_res = None
 
     def _ensure_pcs(self):
         dev = self.weight_v.device
-        if self._pc is None or self._pc.fwd.device != dev:
-            self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev)
+        if self._pc is None or self._pc.inv_norm.device != dev:
+            in_wn = self.skip_slice is not None
+            self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev, norm_only=in_wn)
             if self.split_res_skip:
-                h = self.out_channels // 2
-                self.pc_res = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
-                self.pc_skip = PackedConv(h, self.in_channels, self.kernel_size, False, device=dev)
+                self.pc_res = PackedConv(self.out_channels // 2, self.in_channels, self.kernel_size, False, device=dev)
 
     def _pack_entries(self):
-        out = [(self.weight_v, self.weight_g, self._pc)]
+        out = [(self.weight_v, self.weight_g, self._pc)]                 # inv_norm (+ images unless norm_only)
+        h = self.out_channels // 2 if self.split_res_skip else 0
         if self.split_res_skip:
-            h = self.out_channels // 2
-            out += [(self.weight_v[:h], self.weight_g[:h], self.pc_res), (self.weight_v[h:], self.weight_g[h:], self.pc_skip)]
+            out.append((self.weight_v[:h], self.weight_g[:h], self.pc_res))
+        if self.skip_slice is not None:
+            out.append((self.weight_v[h:], self.weight_g[h:], self.skip_slice()))
         return out
 
     def prepare(self):
         self._ensure_pcs()
-        self._pc.pack(self.weight_v, self.weight_g)
-        if self.split_res_skip:
-            h = self.out_channels // 2
-            self.pc_res.pack(self.weight_v[:h], self.weight_g[:h])
-            self.pc_skip.pack(self.weight_v[h:], self.weight_g[h:])
+        for v, g, pc in self._pack_entries():
+            _pack_one(pc, v, g)
         return self
+
+
+def _pack_one(pc, v, g):
+    """Single-conv packing (tests / tools; training packs everything in one launch through _PackPlan)."""
+    L = _lib.lib()
+    v = v.detach().contiguous().float()
+    gg = None if g is None else g.detach().reshape(-1).contiguous().float()
+    _lib.check(L.gt_pack_conv_weights(_lib.ptr(v), _lib.ptr(gg), _lib.ptr(pc.fwd), _lib.ptr(pc.dgrad), _lib.ptr(pc.inv_norm),
+                                      pc.Cout, pc.Cin, pc.taps, max(pc.Np_f, pc.Cout), max(pc.Kp_f, pc.Cin),
+                                      max(pc.Np_d, pc.Cin), max(pc.Kp_d, pc.Cout), int(pc.gate),
+                                      _lib.current_stream(v.device)), "gt_pack_conv_weights")
 
 
 class _PackPlan:
@@ -117,7 +127,9 @@ class _PackPlan:
         row = 0
         for d, (v, g, pc) in zip(arr, entries):
             d.v, d.g = v.data_ptr(), (g.data_ptr() if g is not None else None)
-            d.pack_fwd, d.pack_dgrad, d.inv_norm = pc.fwd.data_ptr(), pc.dgrad.data_ptr(), pc.inv_norm.data_ptr()
+            d.pack_fwd = pc.fwd.data_ptr() if pc.fwd is not None else None
+            d.pack_dgrad = pc.dgrad.data_ptr() if pc.dgrad is not None else None
+            d.inv_norm = pc.inv_norm.data_ptr() if pc.inv_norm is not None else None
             d.Cout, d.Cin, d.taps = pc.Cout, pc.Cin, pc.taps
             d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, int(pc.gate), row
             row += pc.Cout
@@ -234,6 +246,25 @@ class WN(nn.Module):
             last = i == n_layers - 1
             self.res_skip_layers.append(WNConvP(hidden_channels, hidden_channels if last else 2 * hidden_channels, 1,
                                                 split_res_skip=not last))
+        # output = sum_i skip_i(acts_i) (modules.py:168-170) is ONE GEMM over the K-concatenated gated activations:
+        # every layer's skip rows are packed into a window of pc_skipcat ([H, n_layers*H])
+        self._pc_skipcat = None
+        self.skip_bias = None
+        for i, rs in enumerate(self.res_skip_layers):
+            rs.skip_slice = (lambda i=i: PackSlice(self.pc_skipcat, i * self.hidden_channels, self.hidden_channels, self.hidden_channels))
+
+    @property
+    def pc_skipcat(self):
+        dev = self.in_layers[0].weight_v.device
+        if self._pc_skipcat is None or self._pc_skipcat.fwd.device != dev:
+            self._pc_skipcat = PackedConv(self.hidden_channels, self.n_layers * self.hidden_channels, 1, False, device=dev)
+        return self._pc_skipcat
+
+    def _refresh_padded(self):
+        """Bias of the concatenated skip GEMM = sum of the layers' skip biases (once per optimizer step)."""
+        H = self.hidden_channels
+        with torch.no_grad():
+            self.skip_bias = torch.stack([rs.bias[-H:] for rs in self.res_skip_layers]).sum(0)
 
 
 class ConvReluNorm(nn.Module):

@@ -99,18 +99,37 @@ class RowsCtx:
         return x.to(dtype or xr.dtype).contiguous()
 
 
+class PackSlice:
+    """Pack destination that is a window of a bigger packed image: rows [k0, k0+Cin) of the reduction axis of
+    a K-concatenated GEMM (`parent`), same attribute names as PackedConv for the pack descriptors."""
+
+    def __init__(self, parent, k0, Cout, Cin):
+        assert parent.taps == 1 and not parent.gate
+        self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, 1, False
+        self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
+        self.fwd = parent.fwd[k0:]                                  # Pf[co][k0 + ci]
+        self.dgrad = parent.dgrad[k0 * parent.Kp_d:]                # Pd[k0 + ci][co]
+        self.inv_norm = None
+
+
 class PackedConv:
     """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing."""
 
-    def __init__(self, Cout, Cin, taps, gate=False, device="cuda"):
+    def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False):
+        """norm_only: only the per-row 1/||v|| is wanted (the weight itself is packed elsewhere, e.g. into the
+        K-concatenated skip GEMM of a WN): no bf16 images."""
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, taps, gate
+        self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
+        self.fwd = self.dgrad = None
+        self.Kp_f = self.Np_f = self.Kp_d = self.Np_d = 0
+        if norm_only:
+            return
         self.Kp_f = _round_up(Cin, 64)
         self.Np_f = Cout if gate else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
         self.Kp_d = _round_up(Cout, 64)
         self.Np_d = _round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64)
         self.fwd = torch.zeros(taps * self.Np_f * self.Kp_f, dtype=torch.int16, device=device)
         self.dgrad = torch.zeros(taps * self.Np_d * self.Kp_d, dtype=torch.int16, device=device)
-        self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
 
     def pack(self, v, g=None):
         """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""

@@ -7,12 +7,13 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--")
 out_csv = sys.argv[sys.argv.index("--csv") + 1] if "--csv" in sys.argv else None
 
 rows = []
-f = glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
+dbs = glob.glob(d + "/*.db")
+f = [] if dbs else glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
 if f:
     for r in csv.DictReader(open(f[0])):
         rows.append((r["Name"], int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"])))
 else:
-    db = glob.glob(d + "/**/*.db", recursive=True)[0]
+    db = dbs[0]
     c = sqlite3.connect(db)
     for name, calls, tot in c.execute("select name, count(*), sum(duration) from kernels group by name order by 3 desc"):
         rows.append((name, calls, float(tot), float(tot) / calls))
