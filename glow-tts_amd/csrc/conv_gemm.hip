@@ -44,9 +44,11 @@ struct ConvArgs {
   int R, N, Cin, taps, Tp, Np, Kp;
   int out_f32, relu;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // gate dropout (modules.py:153)
+  uint32_t gb_thresh;                                  // gatebwd: dropout threshold replayed on the gradient
   const uint32_t* seed_dev;                            // optional device word XOR-ed into drop_seed (graph replay)
   int exp_;                                            // EXPERIMENT bits (dev only)
   int y16;                                             // Y rows allow 16-byte bf16 stores (ldy % 8 == 0, base 16-B aligned)
+  int gatebwd;                                         // epilogue = WaveNet-gate backward: Tout/Sout are the SAVED tanh/sigmoid, Y = d pre [R, 2N]
 };
 
 template <int BN, bool GATE>
@@ -223,16 +225,21 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
     constexpr int NCH = (BM * BN / 8) / 256;                         // 8 (BN=128) or 4 (BN=64) chunks per thread
     constexpr int CPR = BN / 8;                                      // chunks per row
     // side loads of all chunks first (one exposed latency), then the math and the stores
-    uint4 adq[NCH][2];
+    uint4 adq[NCH][2], tsq[NCH][2];
     float rmq[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int q = tid + 256 * j, row = q / CPR, c = (q % CPR) * 8;
       const int m = m0 + row, n = n0 + c;
       adq[j][0] = make_uint4(0, 0, 0, 0); adq[j][1] = make_uint4(0, 0, 0, 0);
+      tsq[j][0] = make_uint4(0, 0, 0, 0); tsq[j][1] = make_uint4(0, 0, 0, 0);
       rmq[j] = 1.0f;
       if (m < a.R && n < a.N) {
         if (a.rowmask) rmq[j] = a.rowmask[m];
+        if (a.gatebwd) {
+          tsq[j][0] = *reinterpret_cast<const uint4*>(a.Tout + (size_t)m * a.ldts + n);
+          tsq[j][1] = *reinterpret_cast<const uint4*>(a.Sout + (size_t)m * a.ldts + n);
+        }
         if (a.addend) {
           if (a.out_f32) {
             const float* ap = static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n;
@@ -287,7 +294,24 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
       const float rm = rmq[j];
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = (v[i] + ad[i]) * rm;
-      if (a.out_f32) {
+      if (a.gatebwd) {
+        // v = d acts.  d pre_t = d*S*(1-T^2), d pre_s = d*T*S*(1-S), times the replayed dropout mask of the conv
+        // output (modules.py:153-156 backward); natural [tanh half | sigmoid half] order, N % 8 == 0.
+        const uint32_t tw[4] = {tsq[j][0].x, tsq[j][0].y, tsq[j][0].z, tsq[j][0].w}, sw[4] = {tsq[j][1].x, tsq[j][1].y, tsq[j][1].z, tsq[j][1].w};
+        float gt[8], gs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float t = bf2f((tw[i >> 1] >> (16 * (i & 1))) & 0xffff), sg = bf2f((sw[i >> 1] >> (16 * (i & 1))) & 0xffff);
+          gt[i] = v[i] * sg * (1.0f - t * t); gs[i] = v[i] * t * sg * (1.0f - sg);
+          if (a.gb_thresh) {
+            gt[i] = drop_keep(a.drop_seed, m, n + i, a.gb_thresh) ? gt[i] * a.drop_scale : 0.0f;
+            gs[i] = drop_keep(a.drop_seed, m, a.N + n + i, a.gb_thresh) ? gs[i] * a.drop_scale : 0.0f;
+          }
+        }
+        bf16_t* yp = static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n;
+        *reinterpret_cast<uint4*>(yp) = make_uint4(pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3]), pack2bf(gt[4], gt[5]), pack2bf(gt[6], gt[7]));
+        *reinterpret_cast<uint4*>(yp + a.N) = make_uint4(pack2bf(gs[0], gs[1]), pack2bf(gs[2], gs[3]), pack2bf(gs[4], gs[5]), pack2bf(gs[6], gs[7]));
+      } else if (a.out_f32) {
         float* yp = static_cast<float*>(a.Y) + (size_t)m * a.ldy + n;
         *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
         if (full) *reinterpret_cast<float4*>(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -387,13 +411,19 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   a.y16 = !(ldy & 7);
   { static int ex = -1; if (ex < 0) { const char* e = getenv("GT_CONV_EXP"); ex = e ? atoi(e) : 0; } a.exp_ = ex; }
   a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f; a.seed_dev = seed_dev;
+  a.gatebwd = (gate == 2); a.gb_thresh = 0;
   if (drop_p > 0.0f) {
     if (drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p);
   }
+  if (a.gatebwd) {                            // the dropout belongs to the gate's forward: replay it on the gradient only
+    if (!gate_t || !gate_s || out_f32 || relu || (N & 7) || (ldts & 7) || (ldy & 7)) return GT_E_INVAL;
+    if (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15) return GT_E_ALIGN;
+    a.gb_thresh = a.drop_thresh; a.drop_thresh = 0;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
-  if (gate) {
+  if (gate == 1) {
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
     if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
     hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);

@@ -153,17 +153,25 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
         rs = wn.res_skip_layers[i]
         acts = acts_all[:, i * H:(i + 1) * H]
         via_skip = dacts_skip[:, i * H:(i + 1) * H]
-        if i < n - 1:
+        dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if (want_dcond and p > 0) else None
+        fused = i < n - 1 and dpre_c is None
+        if fused:
+            # d acts = d res @ W_res + (skip path), pushed straight through the gate in the GEMM's epilogue
+            dpre = conv_rows(dres, rs.pc_res, rc, dgrad=True, addend=via_skip, gate=2, gate_t=ts[i], gate_s=ss[i],
+                             drop_p=p, seed=seed + i)
+        elif i < n - 1:
             dacts = conv_rows(dres, rs.pc_res, rc, dgrad=True, addend=via_skip)
-            grads.update(conv_param_grads(rs, acts, None, R, parts=[(dres, 0, H), (dskip, H, H)]))
         else:
             dacts = via_skip
+        if i < n - 1:
+            grads.update(conv_param_grads(rs, acts, None, R, parts=[(dres, 0, H), (dskip, H, H)]))
+        else:
             grads.update(conv_param_grads(rs, acts, dskip, R))
-        dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
-        dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if (want_dcond and p > 0) else None
-        _lib.check(L.gt_gate_bwd(_lib.ptr(dacts), dacts.stride(0), _lib.ptr(ts[i]), _lib.ptr(ss[i]), ts[i].stride(0),
-                                 _lib.ptr(dpre), 2 * H, _lib.ptr(dpre_c), R, H, float(p), int(seed + i),
-                                 _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)), "gt_gate_bwd")
+        if not fused:
+            dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
+            _lib.check(L.gt_gate_bwd(_lib.ptr(dacts), dacts.stride(0), _lib.ptr(ts[i]), _lib.ptr(ss[i]), ts[i].stride(0),
+                                     _lib.ptr(dpre), 2 * H, _lib.ptr(dpre_c), R, H, float(p), int(seed + i),
+                                     _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)), "gt_gate_bwd")
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre

@@ -155,11 +155,11 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
         N, Cin, Np, Kp, W = pc.Cin, pc.Cout, pc.Np_d, pc.Kp_d, pc.dgrad
     else:
         N, Cin, Np, Kp, W = pc.Cout, pc.Cin, pc.Np_f, pc.Kp_f, pc.fwd
-    n_out = N // 2 if gate else N
+    n_out = N // 2 if gate is True or gate == 1 else (2 * N if gate == 2 else N)
     if out is None:
         out = torch.empty(R, n_out, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     out_f32 = out.dtype == torch.float32
-    if gate:
+    if gate == 1:
         if gate_t is None:
             gate_t = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
             gate_s = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
@@ -174,4 +174,4 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(seed_word(x.device)) if drop_p > 0 else None, _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
     _lib.check(rc, "gt_conv_gemm_bf16")
-    return (out, gate_t, gate_s) if gate else out
+    return (out, gate_t, gate_s) if gate == 1 else out

@@ -104,9 +104,12 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
  *   Y[m,n] = epi( sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci] + bias[n] + cond[m/Tp][n] )
  *   epi: optional relu, optional dropout (drop_p, counter-based on (m,n)), optional + addend[m,n],
  *        optional * rowmask[m]; output bf16 or fp32.
- *   gate != 0 (WaveNet gate, commons.py:61-68; N = 2*half, packed with the gate interleave):
+ *   gate == 1 (WaveNet gate, commons.py:61-68; N = 2*half, packed with the gate interleave):
  *     pre = drop(acc + bias) + cond;  T = tanh(pre[:half]), S = sigmoid(pre[half:]),
- *     Y[m, :half] = T*S (bf16), T and S are saved to gate_t / gate_s ([R, ldts] bf16).
+ *     Y[m, :half] = T*S (bf16), T and S are saved to gate_t / gate_s ([R, ldts] bf16; ldts%8, ldy%8 == 0).
+ *   gate == 2 (backward of that gate fused behind a data-gradient GEMM): d = acc + addend is d(T*S);
+ *     gate_t / gate_s are the SAVED T / S (read-only); Y is [R, 2N] bf16: Y[m, n] = d*S*(1-T^2), Y[m, N+n] =
+ *     d*T*S*(1-S), both times the forward's dropout mask (drop_p / drop_seed as given to the forward call).
  *   Wp: weights packed by gt_pack_conv_weights ([taps][Np][Kp] bf16, zero padded).
  * Dropout masks are a counter-based hash of (seed, row, col), replayed by the backward kernels.
  * seed_dev (here and in every entry point that takes it; may be NULL) is a device uint32 XOR-ed into the

@@ -118,3 +118,42 @@ def test_conv_gate_dropout_statistics(built):
     dropped = (t1.float() == 0) & (t0.float().abs() > 1e-3)      # tanh(0) = 0 where the pre-activation was dropped
     frac = dropped.float().mean().item()
     assert 0.2 < frac < 0.3, frac
+
+
+def test_gate_backward_epilogue_replays_forward_dropout(built):
+    """gate == 2 (gate backward fused behind a dgrad GEMM): against the standalone gt_gate_bwd on the same
+    d acts, and the dropout mask it replays is exactly the one the forward gate conv drew (same seed):
+    with zero bias a dropped pre-activation gives T == 0 / S == 0.5 in the forward and a zero gradient here."""
+    from glow_tts_amd import _lib, ops
+    B, T, H, k, p, seed = 2, 96, 192, 5, 0.3, 1234
+    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=11)
+    g = torch.Generator().manual_seed(5)
+    R = ctx.R
+    xr = ctx.to_rows(x.to(torch.bfloat16))
+    pc_in = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
+    _, t, s = ops.conv_rows(xr, pc_in, ctx, gate=True, drop_p=p, seed=seed)                 # no bias: dropped -> pre == 0
+    valid = ctx.rowmask.bool()
+    keep_t, keep_s = (t.float() != 0)[valid], (s.float() != 0.5)[valid]
+    assert abs(keep_t.float().mean().item() - (1 - p)) < 0.02 and abs(keep_s.float().mean().item() - (1 - p)) < 0.02
+    # d acts = dres @ W_res + via_skip
+    wres = (torch.randn(H, H, 1, generator=g) / H ** 0.5).to(dev())
+    pc_res = ops.PackedConv(H, H, 1).pack(wres)
+    dres = (torch.randn(R, H, generator=g).to(dev()) * ctx.rowmask[:, None]).to(torch.bfloat16)
+    via = (torch.randn(R, H, generator=g).to(dev()) * ctx.rowmask[:, None]).to(torch.bfloat16)
+    fused = ops.conv_rows(dres, pc_res, ctx, dgrad=True, addend=via, gate=2, gate_t=t, gate_s=s, drop_p=p, seed=seed)
+    dacts = ops.conv_rows(dres, pc_res, ctx, dgrad=True, addend=via)
+    want = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev())
+    L = _lib.lib()
+    _lib.check(L.gt_gate_bwd(_lib.ptr(dacts), H, _lib.ptr(t), _lib.ptr(s), H, _lib.ptr(want), 2 * H, None, R, H, float(p), seed,
+                             _lib.ptr(ops.seed_word(dev())), _lib.current_stream(dev())), "gt_gate_bwd")
+    torch.cuda.synchronize()
+    assert fused.shape == (R, 2 * H)
+    scale = want.float().abs().max().item()
+    assert torch.allclose(fused.float()[valid], want.float()[valid], atol=2e-2 * scale, rtol=0)   # d acts is bf16-rounded in `want`
+    nz_t, nz_s = (fused[:, :H].float() != 0)[valid], (fused[:, H:].float() != 0)[valid]
+    # a kept element can still be zero only if d acts or a saturated gate factor is zero: compare on the forward's dropped set
+    assert not (nz_t & ~keep_t).any()
+    assert (nz_t | ~keep_t).float().mean().item() > 0.98
+    # sigmoid half: d pre_s = d*T*S*(1-S) also vanishes where T was dropped, and a KEPT pre-activation below 2^-8
+    # rounds to S == 0.5 in bf16: compare where T survived and allow those few
+    assert (nz_s & ~keep_s).float().mean().item() < 0.01 and (~nz_s & keep_s & keep_t).float().mean().item() < 0.02
