@@ -31,6 +31,7 @@ PROTOTYPES = {
                                   c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_weightnorm_bwd_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gt_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "gt_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -11,6 +11,7 @@ from torch import nn
 from . import _lib, flow_impl, wgrad
 from .attentions import CouplingBlock, _wn_cond
 from .modules import ActNorm, InvConvNear, _RowsFn, _mask_lengths, prepare_all
+from . import ops
 from .ops import HALO, RowsCtx
 
 
@@ -74,7 +75,7 @@ class _DecoderRunner:
         rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
         _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, st), "gt_squeeze_rows_f32")
-        logdet = torch.zeros(B, dtype=torch.float32, device=dev)
+        logdet = ops.zeros_small(B, torch.float32, dev)
         saved = []
         cur = rows
         for b in range(nb):
@@ -94,7 +95,7 @@ class _DecoderRunner:
         dev = rc.device
         st = _lib.current_stream(dev)
         T2 = T // 2
-        dlogdet = torch.zeros(B, device=dev) if dlogdet is None else dlogdet.contiguous().float()
+        dlogdet = ops.zeros_small(B, torch.float32, dev) if dlogdet is None else dlogdet.contiguous().float()
         grads = {}
         drows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         if dz is None:

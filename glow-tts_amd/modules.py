@@ -169,6 +169,7 @@ class _RowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, n_out, *tensors):
         outs, saved = runner.forward(*tensors)
+        ctx.set_materialize_grads(False)          # runners take None for an unused output's gradient (no zero fills)
         ctx.runner, ctx.saved, ctx.n_in = runner, saved, len(tensors)
         ctx.mark_non_differentiable(*[o for o in outs[n_out:]])
         return tuple(outs)

@@ -68,6 +68,46 @@ def bump_seed(device):
     seed_word(device).add_(0x632BE5AB)           # odd constant: full-period walk over 2^32
 
 
+# ---- per-step arena of small zero-initialised accumulators --------------------------------------------
+# The backward needs ~150 tiny zeroed buffers per step (atomicAdd targets: LayerNorm gamma/beta, ActNorm
+# logs/bias, InvConv dW, relative-position embeddings ...): one fill of the arena at step start instead
+# of one fill launch each.  Opt-in (train.Trainer): outside a step `zeros_small` is plain torch.zeros.
+_ARENA = {}
+ARENA_BYTES = 1 << 20
+
+
+def arena_begin(device):
+    """Zero the arena and hand out slices of it until the next arena_begin (call once per training step,
+    after the previous step's optimizer has consumed its gradients)."""
+    key = str(device)
+    a = _ARENA.get(key)
+    if a is None:
+        a = {"buf": torch.zeros(ARENA_BYTES, dtype=torch.uint8, device=device), "off": 0, "on": True}
+        _ARENA[key] = a
+    else:
+        a["buf"].zero_()
+    a["off"], a["on"] = 0, True
+
+
+def arena_end(device):
+    a = _ARENA.get(str(device))
+    if a is not None:
+        a["on"] = False
+
+
+def zeros_small(shape, dtype, device):
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    a = _ARENA.get(str(device))
+    nbytes = (n * torch.empty(0, dtype=dtype).element_size() + 255) & ~255
+    if a is None or not a["on"] or nbytes > 65536 or a["off"] + nbytes > ARENA_BYTES:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    off = a["off"]
+    a["off"] = off + nbytes
+    return a["buf"][off:off + nbytes].view(dtype)[:n].view(shape)
+
+
 class RowsCtx:
     """Geometry of one batch in the rows layout: utterance b owns rows [b*Tp, (b+1)*Tp),
     frame t is row b*Tp + HALO + t; rowmask is 1 on valid frames."""

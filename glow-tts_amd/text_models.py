@@ -12,7 +12,7 @@ import math
 import torch
 from torch import nn
 
-from . import _lib, encoder_impl
+from . import _lib, encoder_impl, ops
 from . import monotonic_align
 from .attentions import Encoder
 from .modules import ConvP, ConvReluNorm, LayerNorm, _RowsFn, prepare_all
@@ -252,7 +252,7 @@ class _MleLossFn(torch.autograd.Function):
         dev = z.device
         zc, mc = z.detach().float().contiguous(), m.detach().float().contiguous()
         lc = None if logs is None else logs.detach().float().contiguous()
-        acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        acc = ops.zeros_small(2, torch.float32, dev)
         _lib.check(L.gt_mle_sums(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(acc), zc.numel(), _lib.current_stream(dev)), "gt_mle_sums")
         denom = (mask.sum() * z.shape[1]).to(torch.float32)                 # sum(ones_like(z) * mask)
         loss = (acc[0] + 0.5 * acc[1] - logdet.sum()) / denom + 0.5 * math.log(2 * math.pi)

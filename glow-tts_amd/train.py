@@ -50,47 +50,135 @@ def synth_batch(B, Tx_max, Ty_max, rank, device, n_vocab=148, blank=False):
     return ids.to(device), t_x.to(device), y.to(device), t_y.to(device)
 
 
+def one_cycle(step, total_steps, max_lr, pct_start=0.3, div_factor=25.0, final_div_factor=1e4,
+              base_momentum=0.85, max_momentum=0.95):
+    """(lr, beta1) of torch.optim.lr_scheduler.OneCycleLR with its defaults (cosine, two phases, momentum
+    cycled inversely to the LR) — the schedule of reference train_ms_emo_lang_pitch.py:161,314."""
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+    initial, min_lr = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    end1 = float(pct_start * total_steps) - 1.0
+    end2 = float(total_steps) - 1.0
+    step = min(float(step), end2)
+    if step <= end1:
+        pct = step / end1 if end1 > 0 else 1.0
+        return cos(initial, max_lr, pct), cos(max_momentum, base_momentum, pct)
+    pct = (step - end1) / (end2 - end1)
+    return cos(max_lr, min_lr, pct), cos(base_momentum, max_momentum, pct)
+
+
 class GradBuckets:
-    """Flat gradient buckets + asynchronous all-reduce (mean) on a communication stream."""
+    """All gradients in ONE flat fp32 buffer + asynchronous all-reduce (mean) of large slices of it on a
+    communication stream.  Every parameter gets `_gt_flat_grad = (buffer, offset)`: the deferred weight-gradient
+    kernels (wgrad.WgradQueue) then write their results straight into the buffer, the others are copied in by
+    `gather()` (one multi-tensor copy); the optimizer and the collectives only ever see the flat buffer."""
+    ALIGN = 64          # floats: every parameter starts on a 256-byte boundary
 
     def __init__(self, params, world, bucket_mb=64):
         self.world = world
         self.params = [p for p in params if p.requires_grad]
-        self.buckets, cur, cur_n = [], [], 0
-        cap = bucket_mb * (1 << 20) // 4
-        for p in reversed(self.params):                      # roughly the order gradients become ready
-            cur.append(p); cur_n += p.numel()
-            if cur_n >= cap:
-                self.buckets.append(cur); cur, cur_n = [], 0
-        if cur:
-            self.buckets.append(cur)
         dev = self.params[0].device
-        self.flat = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=dev) for b in self.buckets]
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        cap = max(self.ALIGN, int(bucket_mb * (1 << 20) / 4) // self.ALIGN * self.ALIGN)
+        self.buckets = [(s, min(s + cap, self.total)) for s in range(0, self.total, cap)]
+        for p, o in zip(self.params, self.offsets):
+            p._gt_flat_grad = (self.flat, o)
         self.on_gpu = dev.type == "cuda"
         self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.on_gpu) else None
+        self.active = [True] * len(self.params)
+
+    def view(self, i):
+        p, o = self.params[i], self.offsets[i]
+        return self.flat[o:o + p.numel()].view_as(p)
+
+    def gather(self):
+        """Make every p.grad the parameter's slice of the flat buffer (copy only what is not there already)."""
+        dsts, srcs = [], []
+        for i, p in enumerate(self.params):
+            g = p.grad
+            self.active[i] = g is not None
+            if g is None:
+                continue
+            v = self.view(i)
+            if g.data_ptr() != v.data_ptr():
+                dsts.append(v); srcs.append(g)
+            p.grad = v
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+
+    def active_runs(self):
+        """[(start, end)] float ranges of the flat buffer covering runs of parameters that have a gradient
+        (torch optimizers skip parameters whose grad is None; so does the flat AdamW)."""
+        runs, start = [], None
+        for i, a in enumerate(self.active):
+            if a and start is None:
+                start = self.offsets[i]
+            if not a and start is not None:
+                runs.append((start, self.offsets[i])); start = None
+        if start is not None:
+            runs.append((start, self.total))
+        return runs
 
     def reduce_all(self):
-        """Pack every bucket and all-reduce it; bucket i+1 is packed while bucket i is on the wire."""
+        """gather(), then all-reduce (mean) the flat buffer slice by slice on the communication stream."""
+        self.gather()
         if self.world == 1:
             return
-        cur = torch.cuda.current_stream() if self.on_gpu else None
-        for b, flat in zip(self.buckets, self.flat):
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
-            views = list(torch.split(flat, [p.numel() for p in b]))
-            torch._foreach_copy_([v.view_as(g) for v, g in zip(views, grads)], grads)
-            if self.on_gpu:
-                self.comm.wait_stream(cur)
-                with torch.cuda.stream(self.comm):
-                    dist.all_reduce(flat, op=dist.ReduceOp.AVG)       # RCCL over xGMI
-            else:                                                       # gloo (CPU tests): SUM then scale
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat.mul_(1.0 / self.world)
         if self.on_gpu:
+            cur = torch.cuda.current_stream()
+            self.comm.wait_stream(cur)
+            with torch.cuda.stream(self.comm):
+                for s, e in self.buckets:
+                    dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG)       # RCCL over xGMI
             cur.wait_stream(self.comm)
-        for b, flat in zip(self.buckets, self.flat):
-            views = torch.split(flat, [p.numel() for p in b])
-            for p, v in zip(b, views):
-                p.grad = v.view_as(p)
+        else:                                                                   # gloo (CPU tests): SUM then scale
+            for s, e in self.buckets:
+                dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / self.world)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics on flat buffers through gt_adamw_flat (one HBM pass, gradient norm included).
+    Parameters are re-pointed at slices of one flat fp32 buffer laid out like the GradBuckets buffer.
+    Parameters whose grad is None are skipped like torch does; the bias-correction step count is global (torch
+    keeps one per parameter, which only differs for a parameter that gets gradients in some steps and not others)."""
+
+    def __init__(self, gb, lr, betas, eps, weight_decay=0.01):
+        self.gb = gb
+        dev = gb.flat.device
+        self.flat_p = torch.zeros_like(gb.flat)
+        with torch.no_grad():
+            for p, o in zip(gb.params, gb.offsets):
+                self.flat_p[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view_as(p)
+        self.m = torch.zeros_like(gb.flat)
+        self.v = torch.zeros_like(gb.flat)
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0], dtype=torch.float32, device=dev)
+        self._host = torch.empty(2, dtype=torch.float32).pin_memory()
+        self.gnorm_sq = None
+
+    def set_schedule(self, lr, beta1):
+        """Host-side schedule update (outside a captured graph: the graph's kernels read it from device memory)."""
+        self._host[0], self._host[1] = lr, beta1
+        self.hyper[:2].copy_(self._host, non_blocking=True)
+
+    def step(self):
+        from . import _lib, ops
+        L = _lib.lib()
+        dev = self.flat_p.device
+        self.hyper[5:6].add_(1.0)
+        self.gnorm_sq = ops.zeros_small(1, torch.float32, dev)
+        st = _lib.current_stream(dev)
+        for s, e in self.gb.active_runs():
+            _lib.check(L.gt_adamw_flat(self.flat_p.data_ptr() + 4 * s, self.gb.flat.data_ptr() + 4 * s, self.m.data_ptr() + 4 * s,
+                                       self.v.data_ptr() + 4 * s, e - s, _lib.ptr(self.hyper), _lib.ptr(self.gnorm_sq), st),
+                       "gt_adamw_flat")
+        return self.gnorm_sq
 
 
 class Trainer:
@@ -101,12 +189,15 @@ class Trainer:
     buffers (`step` copies into them) and dropout masks still change every replay because every
     dropout kernel mixes the device-resident seed word (ops.seed_word) that the graph itself bumps."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False):
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None):
+        """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
+        None keeps lr / betas constant."""
         self.model = model
         self.world = world
         self.graph_mode = bool(graph) and world == 1
-        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, betas=betas, eps=eps, fused=True, capturable=self.graph_mode)
         self.buckets = GradBuckets(list(model.parameters()), world)
+        self.opt = FlatAdamW(self.buckets, lr, betas, eps)
+        self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
         self._graph = None
         self._static = None
@@ -116,17 +207,18 @@ class Trainer:
         from . import ops
         m = self.model
         ops.bump_seed(ids.device)
-        self.opt.zero_grad(set_to_none=True)
+        ops.arena_begin(ids.device)              # one fill for all the small zeroed accumulators of this step
+        for p in self.buckets.params:
+            p.grad = None
         (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y)
         l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
         loss = l_mle + torch.sum(l_length)
         loss.backward()
         self.buckets.reduce_all()
-        grads = [p.grad for p in m.parameters() if p.grad is not None]
-        # reference commons.clip_grad_value_(params, None): total grad norm, no clipping (one device
-        # reduction instead of ~1.8k .item() syncs)
-        self.grad_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
-        self.opt.step()
+        # reference commons.clip_grad_value_(params, None): total grad norm, no clipping — the sum of squares
+        # falls out of the optimizer's own pass over the gradients (no ~1.8k .item() syncs)
+        self.grad_norm = torch.sqrt(self.opt.step())
+        ops.arena_end(ids.device)
         return loss.detach(), l_mle.detach()
 
     def _capture(self, ids, t_x, y, t_y):
@@ -140,10 +232,15 @@ class Trainer:
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
+        # created on, and work they launched on another stream would stay outside the captured graph
+        with torch.cuda.graph(self._graph, stream=side):
             self._out = self._step_impl(*self._static)
 
     def step(self, ids, t_x, y, t_y):
+        if self.total_steps:
+            self.opt.set_schedule(*one_cycle(self.n_steps, self.total_steps, self.max_lr))
+        self.n_steps += 1
         if not self.graph_mode:
             return self._step_impl(ids, t_x, y, t_y)
         if self._graph is None:

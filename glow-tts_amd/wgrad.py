@@ -53,6 +53,16 @@ def _scratch(dev, nbytes):
     return buf
 
 
+def _grad_out(param):
+    """Where a parameter's gradient is written: its slice of the trainer's flat gradient buffer when there is
+    one (train.GradBuckets sets `_gt_flat_grad`; a fresh view, so autograd can adopt it without a copy)."""
+    fg = getattr(param, "_gt_flat_grad", None)
+    if fg is None:
+        return torch.empty_like(param)
+    buf, off = fg
+    return buf[off:off + param.numel()].view_as(param)
+
+
 class WgradQueue:
     """`with WgradQueue(dev) as q:` — conv_param_grads() inside only records (conv, x, dy) and hands back the
     (still unwritten) gradient tensors; leaving the block launches the batched kernels that fill them."""
@@ -74,9 +84,9 @@ class WgradQueue:
 
     def add(self, conv, R, parts, want_bias=True):
         v = conv.weight_v if conv.weight_norm else conv.weight
-        dv = torch.empty_like(v)
-        dg = torch.empty_like(conv.weight_g) if conv.weight_norm else None
-        db = torch.empty_like(conv.bias) if (want_bias and conv.bias is not None) else None
+        dv = _grad_out(v)
+        dg = _grad_out(conv.weight_g) if conv.weight_norm else None
+        db = _grad_out(conv.bias) if (want_bias and conv.bias is not None) else None
         self.items.append((conv, R, parts, dv, dg, db))
         out = {v: dv}
         if dg is not None:

@@ -268,6 +268,14 @@ int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, 
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
                size_t n, void* stream);
 
+/* AdamW over flat fp32 buffers (parameters, gradients, both moments are slices of four buffers of n floats,
+ * n % 4 == 0, 16-B aligned) — replaces torch.optim.AdamW.step + commons.clip_grad_value_(params, None)
+ * (train_ms_emo_lang_pitch.py:311-312, commons.py:320-336).  hyper (device) = {lr, beta1, beta2, eps,
+ * weight_decay, step} with step >= 1 already counting this update; *gnorm_sq (optional, device, caller zeroes
+ * it) += sum g^2. */
+int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
+                  float* gnorm_sq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

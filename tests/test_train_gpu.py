@@ -1,0 +1,88 @@
+"""GPU tests of the training step plumbing: flat AdamW (gt_adamw_flat) against torch.optim.AdamW, the
+OneCycleLR restatement against torch's scheduler, and the graph-captured step against the eager one."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_flat_adamw_matches_torch(built):
+    from glow_tts_amd import ops, train
+    torch.manual_seed(0)
+    shapes = [(7, 5), (3,), (11, 2, 3), (1,), (64, 33), (192, 192, 5)]
+    ref = [torch.nn.Parameter(torch.randn(s, device=dev())) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    lr, betas, eps = 2e-3, (0.9, 0.98), 1e-9
+    opt_ref = torch.optim.AdamW(ref, lr=lr, betas=betas, eps=eps)
+    gb = train.GradBuckets(mine, world=1)
+    opt = train.FlatAdamW(gb, lr, betas, eps)
+    for it in range(4):
+        gs = [torch.randn(s, device=dev()) * (it + 1) for s in shapes]
+        skip = 2            # a parameter that never gets a gradient is left untouched (torch skips grad-None parameters too;
+                            # the step count of the bias correction is global here, per parameter in torch)
+        for i, (p, q, g) in enumerate(zip(ref, mine, gs)):
+            p.grad = None if i == skip else g.clone()
+            q.grad = None if i == skip else g.clone()
+        opt_ref.step()
+        ops.arena_begin(dev())
+        gb.reduce_all()
+        gn = torch.sqrt(opt.step()).item()
+        ops.arena_end(dev())
+        want_gn = math.sqrt(sum(g.double().pow(2).sum().item() for i, g in enumerate(gs) if i != skip))
+        assert abs(gn - want_gn) <= 1e-4 * want_gn
+        for p, q in zip(ref, mine):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (it, (p - q).abs().max().item())
+
+
+def test_one_cycle_matches_torch_scheduler():
+    from glow_tts_amd import train
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=2e-4, betas=(0.9, 0.98))
+    total = 57
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, total_steps=total)
+    for step in range(total):
+        lr, b1 = train.one_cycle(step, total, 2e-4)
+        assert abs(lr - opt.param_groups[0]["lr"]) <= 1e-9 + 1e-6 * lr, step
+        assert abs(b1 - opt.param_groups[0]["betas"][0]) <= 1e-6, step
+        opt.step()
+        if step < total - 1:
+            sch.step()
+
+
+def test_graph_step_matches_eager_step(built):
+    """Same model, same batch, dropout off: the captured-graph step and the eager step give the same losses
+    and the same parameters after two updates (the graph only removes launch gaps)."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():                                     # the zero-initialised convs would hide most of the path
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0                            # the prenet's dropout is a hard-coded 0.5 (models.py:674)
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    t1, t2 = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+    for _ in range(2):
+        l1, _ = t1.step(*batch)
+    # the graph trainer runs 3 warm-up steps + the capture step before its first replay: compare after equal counts
+    m3 = train.build_model(cfg, device=dev())
+    m3.load_state_dict(m2.state_dict())
+    m3.encoder.pre.p_dropout = 0.0
+    t3 = train.Trainer(m3, graph=False)
+    l2, _ = t2.step(*batch)            # 3 warm-ups + capture (capture does not execute) + 1 replay = 4 updates
+    for _ in range(4):
+        l3, _ = t3.step(*batch)
+    torch.cuda.synchronize()
+    assert math.isfinite(l1.item()) and abs(l2.item() - l3.item()) <= 2e-2 * max(1.0, abs(l3.item())), (l2.item(), l3.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m2.parameters(), m3.parameters()))
+    assert worst < 5e-3, worst
