@@ -137,7 +137,7 @@ def main():
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     tr = train.Trainer(model, world=world, graph=use_graph)
     ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
     valid_frames = int(t_y.sum().item())
@@ -189,7 +189,8 @@ def main():
             "config": {"workload": wl["desc"], "batch_per_gpu": wl["B"], "T_x": wl["T_x"], "T_y": wl["T_y"],
                        "valid_frames_per_gpu_step": valid_frames, "padded_frames_per_gpu_step": padded_frames,
                        "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
-                       "launch": "one HIP graph per step" if use_graph else "eager launches",
+                       "launch": (("one HIP graph per step" if world == 1 else "two HIP graphs per step (fwd+bwd | optimizer), RCCL all-reduce between them")
+                                  if tr.graph_mode else "eager launches"),
                        "sub_graph": "upstream-equivalent live sub-graph of configs/base.json (one WN per coupling block, "
                                     "deterministic DurationPredictor) — SURVEY F1/F2/F4",
                        "final_loss": float(loss)},

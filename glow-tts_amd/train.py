@@ -127,6 +127,9 @@ class GradBuckets:
     def reduce_all(self):
         """gather(), then all-reduce (mean) the flat buffer slice by slice on the communication stream."""
         self.gather()
+        self.allreduce()
+
+    def allreduce(self):
         if self.world == 1:
             return
         if self.on_gpu:
@@ -184,26 +187,30 @@ class FlatAdamW:
 class Trainer:
     """zero_grad -> forward -> loss -> backward -> all-reduce -> grad-norm -> AdamW step.
 
-    graph=True captures the whole step (forward, MAS, backward, optimizer: ~1.5 k kernel launches) into
-    ONE HIP graph after three eager warm-up steps and replays it; the batch then lives in static
-    buffers (`step` copies into them) and dropout masks still change every replay because every
-    dropout kernel mixes the device-resident seed word (ops.seed_word) that the graph itself bumps."""
+    graph=True captures the step (forward, MAS, backward, optimizer: ~1 k kernel launches) into HIP graphs after
+    three eager warm-up steps and replays them; the batch then lives in static buffers (`step` copies into them)
+    and dropout masks still change every replay because every dropout kernel mixes the device-resident seed word
+    (ops.seed_word) that the graph itself bumps.  One process alone: ONE graph.  Data-parallel (world > 1): two
+    graphs — forward/backward/gather and the optimizer — with the RCCL all-reduce of the flat gradient buffer
+    launched between them (collectives stay outside the captured region)."""
 
-    def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None):
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
+                 split_graph=None):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
-        None keeps lr / betas constant."""
+        None keeps lr / betas constant.  split_graph forces the two-graph form (default: world > 1)."""
         self.model = model
         self.world = world
-        self.graph_mode = bool(graph) and world == 1
+        self.graph_mode = bool(graph)
+        self.split = (world > 1) if split_graph is None else bool(split_graph)
         self.buckets = GradBuckets(list(model.parameters()), world)
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
-        self._graph = None
+        self._graphs = None
         self._static = None
         self._out = None
 
-    def _step_impl(self, ids, t_x, y, t_y):
+    def _fwd_bwd(self, ids, t_x, y, t_y):
         from . import ops
         m = self.model
         ops.bump_seed(ids.device)
@@ -214,12 +221,21 @@ class Trainer:
         l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
         loss = l_mle + torch.sum(l_length)
         loss.backward()
-        self.buckets.reduce_all()
+        self.buckets.gather()
+        return loss.detach(), l_mle.detach()
+
+    def _optim(self, device):
+        from . import ops
         # reference commons.clip_grad_value_(params, None): total grad norm, no clipping — the sum of squares
         # falls out of the optimizer's own pass over the gradients (no ~1.8k .item() syncs)
         self.grad_norm = torch.sqrt(self.opt.step())
-        ops.arena_end(ids.device)
-        return loss.detach(), l_mle.detach()
+        ops.arena_end(device)
+
+    def _step_impl(self, ids, t_x, y, t_y):
+        out = self._fwd_bwd(ids, t_x, y, t_y)
+        self.buckets.allreduce()
+        self._optim(ids.device)
+        return out
 
     def _capture(self, ids, t_x, y, t_y):
         self._static = [t.clone() for t in (ids, t_x, y, t_y)]
@@ -231,11 +247,20 @@ class Trainer:
                 self._step_impl(*self._static)
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and work they launched on another stream would stay outside the captured graph
-        with torch.cuda.graph(self._graph, stream=side):
-            self._out = self._step_impl(*self._static)
+        g1 = torch.cuda.CUDAGraph()
+        if not self.split:
+            with torch.cuda.graph(g1, stream=side):
+                self._out = self._step_impl(*self._static)
+            self._graphs = (g1,)
+        else:
+            with torch.cuda.graph(g1, stream=side):
+                self._out = self._fwd_bwd(*self._static)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side, pool=g1.pool()):
+                self._optim(ids.device)
+            self._graphs = (g1, g2)
 
     def step(self, ids, t_x, y, t_y):
         if self.total_steps:
@@ -243,11 +268,20 @@ class Trainer:
         self.n_steps += 1
         if not self.graph_mode:
             return self._step_impl(ids, t_x, y, t_y)
-        if self._graph is None:
-            self._capture(ids, t_x, y, t_y)
+        if self._graphs is None:
+            try:
+                self._capture(ids, t_x, y, t_y)
+            except Exception as e:                   # e.g. a collective that refuses capture: keep training, eagerly
+                import warnings
+                warnings.warn(f"HIP graph capture of the training step failed ({e!r}); continuing with eager launches")
+                self.graph_mode, self._graphs = False, None
+                return self._step_impl(ids, t_x, y, t_y)
         else:
             for dst, src in zip(self._static, (ids, t_x, y, t_y)):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
-        self._graph.replay()
+        self._graphs[0].replay()
+        if len(self._graphs) > 1:
+            self.buckets.allreduce()                 # RCCL all-reduce of the flat gradient buffer, between the graphs
+            self._graphs[1].replay()
         return self._out

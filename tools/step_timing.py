@@ -7,7 +7,7 @@ from glow_tts_amd import train
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", 32))
 model = train.build_model(device=dev).train()
-tr = train.Trainer(model, graph=bool(int(os.environ.get("GRAPH", "0"))))
+tr = train.Trainer(model, graph=bool(int(os.environ.get("GRAPH", "0"))), split_graph=bool(int(os.environ.get("SPLIT", "0"))))
 ids, t_x, y, t_y = train.synth_batch(B, 150, 800, 0, dev)
 for i in range(3):
     loss, mle = tr.step(ids, t_x, y, t_y)
