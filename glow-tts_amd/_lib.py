@@ -25,6 +25,11 @@ PROTOTYPES = {
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+    "gt_conv_gemm2_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+    "gt_conv_gemm2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

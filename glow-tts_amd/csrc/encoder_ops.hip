@@ -80,15 +80,19 @@ struct LnBwdArgs {
   int rows_per_block;
 };
 
-__global__ __launch_bounds__(256) void gt_layernorm_bwd_kernel(LnBwdArgs q)
+// 8 waves, one row per wave at a time; gamma/beta partials are folded in LDS so that each channel gets ONE
+// atomic per workgroup (same-address float atomics serialise at L2, ~50 ns each: 32 rows per workgroup keeps both
+// the atomic chain and the per-wave row loop short).
+constexpr int LNB_WAVES = 8;
+__global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdArgs q)
 {
   if (q.f.seed_dev) { const uint32_t x = *q.f.seed_dev; q.f.din_seed ^= x; q.f.dout_seed ^= x; }
   const LnArgs& p = q.f;
-  __shared__ float sg[4][256], sb[4][256];
+  __shared__ float sg[LNB_WAVES][256], sb[LNB_WAVES][256];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float accg[4] = {0, 0, 0, 0}, accb[4] = {0, 0, 0, 0};
   const int m0 = blockIdx.x * q.rows_per_block, m1 = min(p.R, m0 + q.rows_per_block);
-  for (int m = m0 + w; m < m1; m += 4) {
+  for (int m = m0 + w; m < m1; m += LNB_WAVES) {
     const float mean = p.mean[m], rstd = p.rstd[m];
     const float rm = p.rowmask ? p.rowmask[m] : 1.0f;
     float xh[4], dn[4]; bool keep_in[4];
@@ -132,8 +136,11 @@ __global__ __launch_bounds__(256) void gt_layernorm_bwd_kernel(LnBwdArgs q)
   __syncthreads();
   const int c = threadIdx.x;
   if (c < p.C) {
-    atomicAdd(q.dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-    atomicAdd(q.dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_WAVES; ++i) { tg += sg[i][c]; tb += sb[i][c]; }
+    atomicAdd(q.dgamma + c, tg);
+    atomicAdd(q.dbeta + c, tb);
   }
 }
 
@@ -558,8 +565,8 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
-  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 16;
-  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 15) / 16), dim3(256), 0, GT_ST(stream), q);
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 32;
+  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 31) / 32), dim3(64 * LNB_WAVES), 0, GT_ST(stream), q);
   GT_RET();
 }
 

@@ -60,7 +60,7 @@ extern "C" int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_
   if ((n & 3) || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return GT_E_ALIGN;
   const size_t n4 = n >> 2;
   size_t blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;          // 16 workgroups per CU, grid-stride beyond
+  if (blocks > 256 * 4) blocks = 256 * 4;            // 4 workgroups per CU, grid-stride beyond (one same-address atomic each)
   hipLaunchKernelGGL(gt_adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      p, g, m, v, n4, hyper, gnorm_sq);
   return gt_launch_status(__func__);

@@ -101,7 +101,7 @@ def _pack_one(pc, v, g):
     gg = None if g is None else g.detach().reshape(-1).contiguous().float()
     _lib.check(L.gt_pack_conv_weights(_lib.ptr(v), _lib.ptr(gg), _lib.ptr(pc.fwd), _lib.ptr(pc.dgrad), _lib.ptr(pc.inv_norm),
                                       pc.Cout, pc.Cin, pc.taps, max(pc.Np_f, pc.Cout), max(pc.Kp_f, pc.Cin),
-                                      max(pc.Np_d, pc.Cin), max(pc.Kp_d, pc.Cout), int(pc.gate),
+                                      max(pc.Np_d, pc.Cin), max(pc.Kp_d, pc.Cout), pc.flags,
                                       _lib.current_stream(v.device)), "gt_pack_conv_weights")
 
 
@@ -131,7 +131,7 @@ class _PackPlan:
             d.pack_dgrad = pc.dgrad.data_ptr() if pc.dgrad is not None else None
             d.inv_norm = pc.inv_norm.data_ptr() if pc.inv_norm is not None else None
             d.Cout, d.Cin, d.taps = pc.Cout, pc.Cin, pc.taps
-            d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, int(pc.gate), row
+            d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, pc.flags, row
             row += pc.Cout
         self.rows = row
         dev = entries[0][0].device

@@ -3,6 +3,8 @@
 PyTorch is used here only for device memory, streams and trivial index plumbing (building the
 row mask); all arithmetic of the hot path happens in libglowtts_hip.so.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -139,6 +141,12 @@ class RowsCtx:
         return x.to(dtype or xr.dtype).contiguous()
 
 
+def _use_gemm2():
+    """The LDS-DMA ring kernel (conv_gemm2.hip) is opt-in: on the cfg2 shapes it ties with the register-staged kernel
+    (both are bound by the L2 -> LDS fill of the weight tiles), so the simpler one is the default."""
+    return os.environ.get("GT_CONV2", "0") == "1"
+
+
 class PackSlice:
     """Pack destination that is a window of a bigger packed image: rows [k0, k0+Cin) of the reduction axis of
     a K-concatenated GEMM (`parent`), same attribute names as PackedConv for the pack descriptors."""
@@ -147,13 +155,21 @@ class PackSlice:
         assert parent.taps == 1 and not parent.gate
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, 1, False
         self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
-        self.fwd = parent.fwd[k0:]                                  # Pf[co][k0 + ci]
-        self.dgrad = parent.dgrad[k0 * parent.Kp_d:]                # Pd[k0 + ci][co]
+        self.frag_f, self.frag_d = parent.frag_f, parent.frag_d
+        # forward image Pf[co][k0 + ci] / data-gradient image Pd[k0 + ci][co]; fragment order: whole (k/16) resp. (n/32) steps
+        assert k0 % 32 == 0
+        self.fwd = parent.fwd[(k0 // 16) * 512:] if parent.frag_f else parent.fwd[k0:]
+        self.dgrad = parent.dgrad[(k0 // 32) * (parent.Kp_d // 16) * 512:] if parent.frag_d else parent.dgrad[k0 * parent.Kp_d:]
         self.inv_norm = None
+
+    @property
+    def flags(self):
+        return 2 * int(self.frag_f) + 4 * int(self.frag_d)
 
 
 class PackedConv:
-    """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing."""
+    """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing.  Shapes the second
+    generation kernel takes (gt_conv_gemm2_supported) are packed in MFMA-fragment order, the rest row-major."""
 
     def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False):
         """norm_only: only the per-row 1/||v|| is wanted (the weight itself is packed elsewhere, e.g. into the
@@ -162,14 +178,23 @@ class PackedConv:
         self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
         self.fwd = self.dgrad = None
         self.Kp_f = self.Np_f = self.Kp_d = self.Np_d = 0
+        self.frag_f = self.frag_d = False
         if norm_only:
             return
+        L = _lib.lib()
+        if _use_gemm2():
+            self.frag_f = bool(L.gt_conv_gemm2_supported(Cout, Cin, taps, int(gate)))
+            self.frag_d = bool(L.gt_conv_gemm2_supported(Cin, Cout, taps, 0))
         self.Kp_f = _round_up(Cin, 64)
-        self.Np_f = Cout if gate else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
+        self.Np_f = Cout if (gate or self.frag_f) else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
         self.Kp_d = _round_up(Cout, 64)
-        self.Np_d = _round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64)
+        self.Np_d = Cin if self.frag_d else (_round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64))
         self.fwd = torch.zeros(taps * self.Np_f * self.Kp_f, dtype=torch.int16, device=device)
         self.dgrad = torch.zeros(taps * self.Np_d * self.Kp_d, dtype=torch.int16, device=device)
+
+    @property
+    def flags(self):
+        return int(bool(self.gate)) + 2 * int(self.frag_f) + 4 * int(self.frag_d)
 
     def pack(self, v, g=None):
         """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""
@@ -179,7 +204,7 @@ class PackedConv:
         gg = None if g is None else g.detach().reshape(-1).contiguous().float()
         _lib.check(L.gt_pack_conv_weights(_lib.ptr(v), _lib.ptr(gg), _lib.ptr(self.fwd), _lib.ptr(self.dgrad),
                                           _lib.ptr(self.inv_norm), self.Cout, self.Cin, self.taps,
-                                          self.Np_f, self.Kp_f, self.Np_d, self.Kp_d, int(self.gate),
+                                          self.Np_f, self.Kp_f, self.Np_d, self.Kp_d, self.flags,
                                           _lib.current_stream(v.device)), "gt_pack_conv_weights")
         return self
 
@@ -203,8 +228,9 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
         if gate_t is None:
             gate_t = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
             gate_s = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
+    fn = L.gt_conv_gemm2_bf16 if (pc.frag_d if dgrad else pc.frag_f) else L.gt_conv_gemm_bf16
     _ev = KERNEL_TIMER.start(tag)
-    rc = L.gt_conv_gemm_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
+    rc = fn(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
                              _lib.ptr(cond), 0 if cond is None else cond.stride(0),
                              _lib.ptr(ctx.rowmask) if mask else None,
                              _lib.ptr(out), out.stride(0), int(out_f32),
@@ -213,5 +239,5 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
                              _lib.ptr(seed_word(x.device)) if drop_p > 0 else None, _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
-    _lib.check(rc, "gt_conv_gemm_bf16")
+    _lib.check(rc, "gt_conv_gemm2_bf16" if fn is L.gt_conv_gemm2_bf16 else "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate == 1 else out

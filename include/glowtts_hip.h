@@ -122,11 +122,26 @@ int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 
+/* Second-generation implicit GEMM (LDS-DMA rings for both operands, 128x192 / 128x96 / 64x192 / 64x96 tiles): same
+ * arguments and semantics as gt_conv_gemm_bf16, for shapes gt_conv_gemm2_supported() accepts (Cin % 64 == 0,
+ * N % 96 == 0, gate == 1 needs N % 192 == 0; Np == N, Kp == Cin).  Wp must be packed in MFMA-fragment order
+ * (gt_pack_conv_weights flag 2 for the forward image, 4 for the data-gradient image). */
+int gt_conv_gemm2_supported(int N, int Cin, int taps, int gate);
+int gt_conv_gemm2_bf16(const void* X, int ldx, const void* Wp, const float* bias,
+                       const float* cond, int ldc, const float* rowmask,
+                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,
+                       void* gate_t, void* gate_s, int ldts,
+                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
+                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
+
 /* Weight preparation for gt_conv_gemm_bf16: w = g*v/||v|| when g != NULL (torch weight_norm,
  * dim 0: modules.py:127,132,141, attentions.py:103) else w = v; v is [Cout, Cin, taps] fp32.
  * Writes bf16 pack_fwd [taps][Np_fwd][Kp_fwd] and/or pack_dgrad [taps][Np_dgrad][Kp_dgrad]
- * (roles swapped, taps flipped) and inv_norm[Cout] = 1/||v|| (optional).  Padding entries are
- * not touched: zero the buffers once. */
+ * (roles swapped, taps flipped) and inv_norm[Cout] = 1/||v|| (optional; pack pointers may both be NULL when only
+ * the norms are wanted).  Padding entries are not touched: zero the buffers once.
+ * `gate` is a bit set: 1 = WaveNet-gate row interleave of the forward image ([32 tanh | 32 sigmoid] per 64 rows),
+ * 2 = forward image in MFMA-fragment order [tap][n/32][k/16][lane = n%32 + 32*((k%16)/8)][k%8] for gt_conv_gemm2_bf16,
+ * 4 = the same for the data-gradient image (Np, Kp multiples of 32 / 16 then). */
 int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
                          float* inv_norm, int Cout, int Cin, int taps,
                          int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
