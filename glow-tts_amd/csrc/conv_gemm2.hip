@@ -270,8 +270,8 @@ extern "C" int gt_conv_gemm2_bf16(const void* X, int ldx, const void* Wp, const 
   // tile choice: the largest tile that still gives ~one workgroup per CU; small problems take 64-row tiles
   const int rt128 = (R + 127) / 128, rt64 = (R + 63) / 64;
   const bool n192 = (N % 192) == 0;
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("GT_CONV2_TILE"); force = e ? atoi(e) : 0; }
+  const char* fe = getenv("GT_CONV2_TILE");                        // dev/test override of the tile choice
+  const int force = fe ? atoi(fe) : 0;
   int pick = 0;                                                    // 1: 128x192, 2: 128x96, 3: 64x192, 4: 64x96
   if (force >= 1 && force <= 4 && (n192 || force == 2 || force == 4)) pick = force;
   else if (n192 && rt128 * (N / 192) >= 160) pick = 1;

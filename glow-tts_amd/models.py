@@ -5,6 +5,8 @@ The forward signature, return values and state_dict keys (`flows.{3k}.logs`, `fl
 `flows.{3k+2}.start.weight_v`, ...) are the reference's; the whole block chain runs as ONE autograd
 node whose forward/backward are explicit HIP kernel launch sequences (flow_impl.py).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -105,14 +107,19 @@ class _DecoderRunner:
             _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, st), "gt_squeeze_rows_f32")
         dconds = [None] * nb
         cur = drows
-        with wgrad.WgradQueue(dev, site=dec):           # data-gradient chain now, ALL weight gradients in one batch after it
-            for b in reversed(range(nb)):
-                an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
-                s1, s2 = saved[b]
-                cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
-                grads.update(g2)
-                cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
-                grads.update(g1)
+        # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
+        # side stream, beside the rest of the chain)
+        chunk = int(os.environ.get("GT_WGRAD_CHUNK", "12"))
+        for b1 in range(nb, 0, -chunk):
+            b0 = max(0, b1 - chunk)
+            with wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else dec):
+                for b in reversed(range(b0, b1)):
+                    an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+                    s1, s2 = saved[b]
+                    cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
+                    grads.update(g2)
+                    cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
+                    grads.update(g1)
         dx = torch.zeros(B, C, T, dtype=torch.float32, device=dev) if T != T2 * 2 else torch.empty(B, C, T, dtype=torch.float32, device=dev)
         if T == T2 * 2:
             _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(dx), _lib.ptr(rc.lengths), B, C, T, rc.Tp, st), "gt_unsqueeze_rows_f32")

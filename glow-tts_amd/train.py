@@ -98,6 +98,8 @@ class GradBuckets:
 
     def gather(self):
         """Make every p.grad the parameter's slice of the flat buffer (copy only what is not there already)."""
+        from . import wgrad
+        wgrad.join(self.flat.device)             # weight gradients flushed on the side stream land first
         dsts, srcs = [], []
         for i, p in enumerate(self.params):
             g = p.grad
@@ -204,6 +206,8 @@ class Trainer:
         self.split = (world > 1) if split_graph is None else bool(split_graph)
         self.buckets = GradBuckets(list(model.parameters()), world)
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
+        from . import wgrad
+        wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "1") != "0"      # weight-gradient batches on a side stream
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
         self._graphs = None

@@ -27,18 +27,40 @@ assert JOB.itemsize == 64 and TILE.itemsize == 16 and WNB.itemsize == 96
 ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
 MAX_SLABS = 8
 
+# ASYNC (set by train.Trainer): flush() launches on a side stream, so the batched weight-gradient kernels of the
+# decoder overlap with whatever the backward does next (the rest of the data-gradient chain, the text encoder's
+# backward: mostly small kernels that leave CUs idle); join() makes the current stream wait for them and must run
+# before anything reads the gradients (train.GradBuckets.gather does).
+ASYNC = False
+_SIDE = {}
+_PENDING = set()
 _ACTIVE = []            # stack of open queues
 _KEEP = []              # host tables referenced by captured graphs
 _SCRATCH = {}
 
 
 _POOL = []              # pinned staging buffers set aside (outside capture) for use inside a graph capture
-_POOL_N, _POOL_BYTES = 12, 1 << 19
+_POOL_N, _POOL_BYTES = 64, 1 << 18
 
 
 def _fill_pool():
     while len(_POOL) < _POOL_N:
         _POOL.append(torch.empty(_POOL_BYTES, dtype=torch.uint8).pin_memory())
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+def join(dev):
+    """Current stream waits for every asynchronously flushed queue of this device."""
+    key = str(dev)
+    if key in _PENDING:
+        torch.cuda.current_stream(dev).wait_stream(_SIDE[key])
+        _PENDING.discard(key)
 
 
 def active():
@@ -48,6 +70,8 @@ def active():
 def _scratch(dev, nbytes):
     buf = _SCRATCH.get(str(dev))
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and buf.is_cuda:
+            buf.record_stream(torch.cuda.current_stream(dev))       # kernels of an earlier flush may still read it
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _SCRATCH[str(dev)] = buf
     return buf
@@ -128,6 +152,23 @@ class WgradQueue:
     def flush(self):
         if not self.items:
             return
+        dev = self.dev
+        if ASYNC and dev.type == "cuda":
+            cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(cur)
+            for conv, R, parts, dv, dg, db in self.items:          # these outlive the backward node on the side stream
+                for x, dy, _, _ in parts:
+                    x.record_stream(side); dy.record_stream(side)
+                for t in (dv, dg, db):
+                    if t is not None:
+                        t.record_stream(side)
+            with torch.cuda.stream(side):
+                self._flush()
+            _PENDING.add(str(dev))
+        else:
+            self._flush()
+
+    def _flush(self):
         L = _lib.lib()
         dev = self.dev
         jobs, tiles, wnbs, rows, max_n, nbytes = self._plan()

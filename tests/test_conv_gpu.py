@@ -157,3 +157,51 @@ def test_gate_backward_epilogue_replays_forward_dropout(built):
     # sigmoid half: d pre_s = d*T*S*(1-S) also vanishes where T was dropped, and a KEPT pre-activation below 2^-8
     # rounds to S == 0.5 in bf16: compare where T survived and allow those few
     assert (nz_s & ~keep_s).float().mean().item() < 0.01 and (~nz_s & keep_s & keep_t).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("Cin,Cout,k,tile", [(192, 384, 5, 0), (384, 192, 5, 0), (192, 192, 1, 0), (768, 192, 1, 0), (192, 768, 3, 0),
+                                             (192, 384, 5, 2), (192, 384, 1, 3), (192, 192, 3, 4)])
+def test_conv_gemm2_ring_kernel_matches_torch(built, monkeypatch, Cin, Cout, k, tile):
+    """The opt-in LDS-DMA ring kernel (gt_conv_gemm2_bf16, fragment-ordered weights) against torch conv1d, forward and
+    data gradient, on every tile shape (GT_CONV2_TILE 1..4; 0 = the kernel's own choice), ragged lengths."""
+    from glow_tts_amd import ops
+    monkeypatch.setenv("GT_CONV2", "1")
+    if tile:
+        monkeypatch.setenv("GT_CONV2_TILE", str(tile))
+    B, T = 3, 150
+    ctx, x, w, b = make(B, T, Cin, Cout, k, seed=Cin + Cout + k, lens=[150, 97, 1])
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    pc = ops.PackedConv(Cout, Cin, k).pack(wb.float())
+    assert pc.frag_f and pc.frag_d
+    xr = ctx.to_rows(xb)
+    y = ops.conv_rows(xr, pc, ctx, bias=b, out_f32=True)
+    want = ref_conv(xb, wb, b, k // 2)
+    scale = want.abs().max().item()
+    got = ctx.from_rows(y)
+    assert torch.allclose(got, want, atol=2e-3 * scale, rtol=0), (got - want).abs().max().item() / scale
+    # data gradient: conv of dY with the dgrad image == autograd's input gradient
+    g = torch.Generator().manual_seed(1)
+    dy = (torch.randn(B, Cout, T, generator=g).to(dev()) * ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)).to(torch.bfloat16)
+    xx = xb.float().requires_grad_(True)
+    F.conv1d(xx, wb.float(), None, padding=k // 2).backward(dy.float())
+    dx = ctx.from_rows(ops.conv_rows(ctx.to_rows(dy), pc, ctx, dgrad=True, out_f32=True))
+    valid = ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1).bool().expand_as(dx)
+    s2 = xx.grad.abs().max().item()
+    assert torch.allclose(dx[valid], xx.grad[valid], atol=2e-3 * s2, rtol=0), (dx - xx.grad)[valid].abs().max().item() / s2
+
+
+def test_conv_gemm2_gate_matches_first_generation(built, monkeypatch):
+    """Gate epilogue of the ring kernel == the first-generation kernel on the same operands (same dropout seed)."""
+    from glow_tts_amd import ops
+    B, T, H, k = 2, 96, 192, 5
+    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=3)
+    xr = ctx.to_rows(x.to(torch.bfloat16))
+    pc1 = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
+    a1, t1, s1 = ops.conv_rows(xr, pc1, ctx, bias=b, gate=True, drop_p=0.1, seed=77)
+    monkeypatch.setenv("GT_CONV2", "1")
+    pc2 = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
+    assert pc2.frag_f and not pc1.frag_f
+    a2, t2, s2 = ops.conv_rows(xr, pc2, ctx, bias=b, gate=True, drop_p=0.1, seed=77)
+    valid = ctx.rowmask.bool()
+    for u, v in ((a1, a2), (t1, t2), (s1, s2)):
+        assert torch.allclose(u.float()[valid], v.float()[valid], atol=1e-2, rtol=0)
