@@ -24,11 +24,11 @@ PROTOTYPES = {
     "gt_conv_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p]),
     "gt_conv_gemm2_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p]),
     "gt_conv_gemm2_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -38,16 +38,16 @@ PROTOTYPES = {
     "gt_weightnorm_bwd_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "gt_colsum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_flow_scalars": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gt_actnorm_invconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_actnorm_invconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "gt_coupling_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_coupling_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gt_coupling_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                c_int, c_int, c_int, c_int, c_void_p]),
+                                c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gt_gate_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_relu_drop_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
@@ -59,13 +59,13 @@ PROTOTYPES = {
                                  c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+                            c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gt_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
-    "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                            c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
+    "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "gt_logp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_prior_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_prior_expand_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

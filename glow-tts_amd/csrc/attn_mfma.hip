@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
-    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+    int T, int Tp, const int32_t* row0, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -58,15 +58,19 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int len = lens[b];
-  const size_t rbase = (size_t)b * Tp + HALO;
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  // rows this utterance owns behind rbase (frames + trailing halo): in the ragged layout frame indices past them belong
+  // to the NEXT utterance — reads are clamped onto the (zero) trailing halo row, stores are dropped
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
 
   // ---- stage K, V (zero rows >= T), Ek, Ev^T
   for (int i = tid; i < TPAD * (D / 8); i += 256) {
     const int j = i / (D / 8), c8 = i - j * (D / 8);
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
     if (j < T) {
-      kk = *reinterpret_cast<const uint4*>(k + (rbase + j) * ld + h * D + c8 * 8);
-      vv = *reinterpret_cast<const uint4*>(v + (rbase + j) * ld + h * D + c8 * 8);
+      kk = *reinterpret_cast<const uint4*>(k + RW(j) * ld + h * D + c8 * 8);
+      vv = *reinterpret_cast<const uint4*>(v + RW(j) * ld + h * D + c8 * 8);
     }
     *reinterpret_cast<uint4*>(Ks + j * KP + c8 * 8) = kk;
     *reinterpret_cast<uint4*>(Vs + j * VP + c8 * 8) = vv;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
   bf16x8_t qf[6];
 #pragma unroll
   for (int ks = 0; ks < 6; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8_t*>(q + (rbase + ic) * ld + h * D + ks * 16 + 8 * hh);
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(q + RW(ic) * ld + h * D + ks * 16 + 8 * hh);
 
   // ---- QE = Ek Q^T  (rows r' < 9 used)
   {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
       o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfp, o[dt], 0, 0, 0);
     }
   }
-  if (i < T) {
+  if (i < T && i <= nv1) {
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_kernel(
 
 template <int NT>
 int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
-               bf16_t* out, int ldo, float* P, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
+               bf16_t* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
 {
   constexpr int TPAD = NT * 32;
   const size_t lds = (size_t)TPAD * KP * 2 + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 4 * 32 * NW * 4 + 4 * 32 * 16 * 2;
@@ -229,7 +233,7 @@ int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
     attr = true;
   }
   hipLaunchKernelGGL(gt_attn_fwd_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds, st,
-                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, H, th, sd, sc, seed_dev);
+                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, row0, H, th, sd, sc, seed_dev);
   return gt_launch_status(__func__);
 }
 
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
     const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
     bf16_t* __restrict__ dST, bf16_t* __restrict__ PdT, int TI,
     bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
-    int T, int Tp, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+    int T, int Tp, const int32_t* row0, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -269,14 +273,18 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int len = lens[b];
-  const size_t rbase = (size_t)b * Tp + HALO;
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  // rows this utterance owns behind rbase (frames + trailing halo): in the ragged layout frame indices past them belong
+  // to the NEXT utterance — reads are clamped onto the (zero) trailing halo row, stores are dropped
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
 
   for (int i = tid; i < TPAD * (D / 8); i += NTH) {
     const int j = i / (D / 8), c8 = i - j * (D / 8);
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
     if (j < T) {
-      kk = *reinterpret_cast<const uint4*>(k + (rbase + j) * ld + h * D + c8 * 8);
-      vv = *reinterpret_cast<const uint4*>(v + (rbase + j) * ld + h * D + c8 * 8);
+      kk = *reinterpret_cast<const uint4*>(k + RW(j) * ld + h * D + c8 * 8);
+      vv = *reinterpret_cast<const uint4*>(v + RW(j) * ld + h * D + c8 * 8);
     }
     *reinterpret_cast<uint4*>(Ks + j * VP + c8 * 8) = kk;
     *reinterpret_cast<uint4*>(Vs + j * KP + c8 * 8) = vv;
@@ -308,8 +316,8 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
       const int rr = c / (D / 8), c8 = c - rr * (D / 8);
       uint4 qq = make_uint4(0, 0, 0, 0), dd = qq;
       if (i0 + rr < T) {
-        qq = *reinterpret_cast<const uint4*>(q + (rbase + i0 + rr) * ld + h * D + c8 * 8);
-        dd = *reinterpret_cast<const uint4*>(dout + (rbase + i0 + rr) * lddo + h * D + c8 * 8);
+        qq = *reinterpret_cast<const uint4*>(q + RW(i0 + rr) * ld + h * D + c8 * 8);
+        dd = *reinterpret_cast<const uint4*>(dout + RW(i0 + rr) * lddo + h * D + c8 * 8);
       }
       *reinterpret_cast<uint4*>(Qw + rr * VP + c8 * 8) = qq;
       *reinterpret_cast<uint4*>(dOw + rr * VP + c8 * 8) = dd;
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
     bf16x8_t dof[6];
 #pragma unroll
     for (int ks = 0; ks < 6; ++ks)
-      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dout + (rbase + ic) * lddo + h * D + ks * 16 + 8 * hh);
+      dof[ks] = *reinterpret_cast<const bf16x8_t*>(dout + RW(ic) * lddo + h * D + ks * 16 + 8 * hh);
     {
       f32x16_t acc;
 #pragma unroll
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfp, o[dt], 0, 0, 0);
       }
     }
-    if (i < T) {
+    if (i < T && i <= nv1) {
 #pragma unroll
       for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -484,7 +492,7 @@ template <int NT>
 __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
     const bf16_t* __restrict__ q, int ld, const bf16_t* __restrict__ dout, int lddo,
     const bf16_t* __restrict__ dST, const bf16_t* __restrict__ PdT, int TI,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk, int T, int Tp, int H)
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk, int T, int Tp, const int32_t* row0, int H)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TPAD = NT * 32;
@@ -493,13 +501,17 @@ __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
   const int b = blockIdx.z, h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const size_t rbase = (size_t)b * Tp + HALO;
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  // rows this utterance owns behind rbase (frames + trailing halo): in the ragged layout frame indices past them belong
+  // to the NEXT utterance — reads are clamped onto the (zero) trailing halo row, stores are dropped
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
   for (int i = tid; i < TPAD * (D / 8); i += 256) {
     const int j = i / (D / 8), c8 = i - j * (D / 8);
     uint4 qq = make_uint4(0, 0, 0, 0), dd = qq;
     if (j < T) {
-      qq = *reinterpret_cast<const uint4*>(q + (rbase + j) * ld + h * D + c8 * 8);
-      dd = *reinterpret_cast<const uint4*>(dout + (rbase + j) * lddo + h * D + c8 * 8);
+      qq = *reinterpret_cast<const uint4*>(q + RW(j) * ld + h * D + c8 * 8);
+      dd = *reinterpret_cast<const uint4*>(dout + RW(j) * lddo + h * D + c8 * 8);
     }
     *reinterpret_cast<uint4*>(Qs + j * VP + c8 * 8) = qq;
     *reinterpret_cast<uint4*>(dOs + j * VP + c8 * 8) = dd;
@@ -529,15 +541,15 @@ __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
       av[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag8(da, da + 4 * VP), bpd, av[dt], 0, 0, 0);
     }
   }
-  if (j < T) {
+  if (j < T && j <= nv1) {
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = 32 * dt + 8 * g + 4 * hh;
-        *reinterpret_cast<uint2*>(dk + (rbase + j) * lddk + h * D + d) =
+        *reinterpret_cast<uint2*>(dk + RW(j) * lddk + h * D + d) =
             make_uint2(pack2bf(ak[dt][4 * g], ak[dt][4 * g + 1]), pack2bf(ak[dt][4 * g + 2], ak[dt][4 * g + 3]));
-        *reinterpret_cast<uint2*>(dv + (rbase + j) * lddk + h * D + d) =
+        *reinterpret_cast<uint2*>(dv + RW(j) * lddk + h * D + d) =
             make_uint2(pack2bf(av[dt][4 * g], av[dt][4 * g + 1]), pack2bf(av[dt][4 * g + 2], av[dt][4 * g + 3]));
       }
   }
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
 template <int NT, int WV>
 int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
                const bf16_t* dout, int lddo, const float* P, bf16_t* ws, bf16_t* dq, bf16_t* dk, bf16_t* dv, int lddq,
-               float* dEk, float* dEv, int B, int T, int Tp, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
+               float* dEk, float* dEv, int B, int T, int Tp, const int32_t* row0, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
 {
   constexpr int TPAD = NT * 32;
   constexpr int WBN = 32 * 16 + 2 * 16 * BTP + 2 * 32 * VP;
@@ -564,9 +576,9 @@ int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   }
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return 1;
   hipLaunchKernelGGL((gt_attn_bwd_q_mfma_kernel<NT, WV>), dim3((T + 32 * WV - 1) / (32 * WV), H, B), dim3(64 * WV), lds1, st,
-                     q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, H, th, sd, sc, seed_dev);
+                     q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, row0, H, th, sd, sc, seed_dev);
   hipLaunchKernelGGL(gt_attn_bwd_kv_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds2, st,
-                     q, ld, dout, lddo, dST, PdT, TI, dk, dv, lddq, T, Tp, H);
+                     q, ld, dout, lddo, dST, PdT, TI, dk, dv, lddq, T, Tp, row0, H);
   return gt_launch_status(__func__);
 }
 
@@ -581,7 +593,7 @@ size_t gt_attn_bwd_mfma_ws_bytes(int B, int T, int H)
 int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                           const int32_t* lens, const void* dout, int lddo, const float* P, void* ws, size_t ws_bytes,
                           void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                          int B, int T, int Tp, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
+                          int B, int T, int Tp, const int32_t* row0, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
   if (Dh != D || win != WIN || T > 256 || (ld & 7) || (lddo & 7) || (lddq & 3)) return 1;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)ws) & 15) return 1;
@@ -591,13 +603,13 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   const bf16_t* dd = static_cast<const bf16_t*>(dout);
   bf16_t* w16 = static_cast<bf16_t*>(ws);
   bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
-  if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, seed_dev, st);
-  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, H, th, sd, sc, seed_dev, st);
+  if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
-                          const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int Dh, int win,
+                          const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, int Dh, int win,
                           uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
   if (Dh != D || win != WIN || T > 256 || (ld & 7) || (ldo & 3)) return 1;
@@ -605,6 +617,6 @@ int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bf16_t* qq = static_cast<const bf16_t*>(q); const bf16_t* kk = static_cast<const bf16_t*>(k); const bf16_t* vv = static_cast<const bf16_t*>(v);
   bf16_t* oo = static_cast<bf16_t*>(out);
-  if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, seed_dev, st);
-  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, H, th, sd, sc, seed_dev, st);
+  if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }

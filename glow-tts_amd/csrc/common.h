@@ -33,6 +33,19 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Rows layout geometry.  Uniform: utterance b owns rows [b*Tp, (b+1)*Tp).  Ragged (row0 != NULL, device int32
+// [B+1]): utterance b owns rows [row0[b], row0[b+1]) = its frames + 2*HALO (the last one also owns the rows that
+// round R up), so padded frames cost nothing; Tp is then only an upper bound on rows per utterance (grid sizing).
+__device__ __forceinline__ int gt_row_base(const int32_t* row0, int b, int Tp) { return row0 ? row0[b] : b * Tp; }
+__device__ __forceinline__ int gt_row_count(const int32_t* row0, int b, int Tp) { return row0 ? row0[b + 1] - row0[b] : Tp; }
+__device__ __forceinline__ int gt_row_batch(const int32_t* row0, int B, int m, int Tp)
+{
+  if (!row0) return m / Tp;
+  int lo = 0, hi = B - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (row0[mid] <= m) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+
 // Launch check shared by every entry point: reports WHICH call failed and why on stderr (the C-ABI
 // itself only returns GT_E_LAUNCH).
 #include <stdio.h>

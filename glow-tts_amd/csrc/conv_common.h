@@ -14,6 +14,7 @@ struct ConvArgs {
   const void* addend; int ldadd;              // same dtype as Y, or null
   bf16_t* Tout; bf16_t* Sout; int ldts;       // gate: saved tanh / sigmoid halves
   int R, N, Cin, taps, Tp, Np, Kp;
+  const int32_t* row0; int B;                 // ragged rows layout (NULL: uniform Tp rows per utterance): cond row = batch of m
   int out_f32, relu;
   uint32_t drop_thresh, drop_seed; float drop_scale;   // gate dropout (modules.py:153)
   uint32_t gb_thresh;                                  // gatebwd: dropout threshold replayed on the gradient
@@ -51,7 +52,7 @@ __device__ __forceinline__ void epilogue_gate(const ConvArgs& a, const float* es
       bs0 = *reinterpret_cast<const float4*>(a.bias + half + cg); bs1 = *reinterpret_cast<const float4*>(a.bias + half + cg + 4);
     }
     if (a.cond) {
-      const float* cp = a.cond + (size_t)(m / a.Tp) * a.ldc + cg;
+      const float* cp = a.cond + (size_t)gt_row_batch(a.row0, a.B, m, a.Tp) * a.ldc + cg;
       ct0 = *reinterpret_cast<const float4*>(cp);        ct1 = *reinterpret_cast<const float4*>(cp + 4);
       cs0 = *reinterpret_cast<const float4*>(cp + half); cs1 = *reinterpret_cast<const float4*>(cp + half + 4);
     }
@@ -131,7 +132,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, const float* e
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
     if (a.cond) {
-      const float* cp = a.cond + (size_t)(m / a.Tp) * a.ldc;
+      const float* cp = a.cond + (size_t)gt_row_batch(a.row0, a.B, m, a.Tp) * a.ldc;
       const float4 c0 = *reinterpret_cast<const float4*>(cp + n), c1 = *reinterpret_cast<const float4*>(cp + n1);
       v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
     }

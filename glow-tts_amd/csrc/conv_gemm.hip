@@ -241,7 +241,8 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
                                  void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                                  void* gate_t, void* gate_s, int ldts,
                                  int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                                 int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
+                                 int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
+                                 const int32_t* row0, int B, void* stream)
 {
   if (R < 0 || N <= 0 || Cin <= 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
@@ -250,12 +251,13 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if ((N & 3) || (Cin & 7) || (ldx & 7) || (ldy & 3) || (Kp % BK) || Kp < Cin) return GT_E_ALIGN;
   if (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15) return GT_E_ALIGN;
   if (addend && (ldadd & 3)) return GT_E_ALIGN;
-  if (cond && Tp <= 0) return GT_E_INVAL;
+  if (cond && (Tp <= 0 || (row0 && B <= 0))) return GT_E_INVAL;
   ConvArgs a;
   a.X = static_cast<const bf16_t*>(X); a.ldx = ldx; a.W = static_cast<const bf16_t*>(Wp); a.bias = bias;
   a.cond = cond; a.ldc = ldc; a.rowmask = rowmask; a.Y = Y; a.ldy = ldy; a.addend = addend; a.ldadd = ldadd;
   a.Tout = static_cast<bf16_t*>(gate_t); a.Sout = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
   a.R = R; a.N = N; a.Cin = Cin; a.taps = taps; a.Tp = Tp > 0 ? Tp : 1; a.Np = Np; a.Kp = Kp;
+  a.row0 = row0; a.B = B;
   a.out_f32 = out_f32; a.relu = relu;
   a.y16 = !(ldy & 7);
   { static int ex = -1; if (ex < 0) { const char* e = getenv("GT_CONV_EXP"); ex = e ? atoi(e) : 0; } a.exp_ = ex; }

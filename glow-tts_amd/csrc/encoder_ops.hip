@@ -154,11 +154,11 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
 constexpr int AT_QT = 16;
 constexpr int AT_MAXD = 96;
 
-__device__ __forceinline__ void at_stage(bf16_t* dst, const bf16_t* src, int ld, size_t rbase, int h, int T, int D, int KP, int tid)
+__device__ __forceinline__ void at_stage(bf16_t* dst, const bf16_t* src, int ld, size_t rbase, int h, int T, int D, int KP, int tid, int nv1)
 {
   for (int i = tid; i < T * (D / 2); i += 256) {
     const int j = i / (D / 2), c2 = i - j * (D / 2);
-    *reinterpret_cast<uint32_t*>(dst + (size_t)j * KP + 2 * c2) = *reinterpret_cast<const uint32_t*>(src + (rbase + j) * ld + h * D + 2 * c2);
+    *reinterpret_cast<uint32_t*>(dst + (size_t)j * KP + 2 * c2) = *reinterpret_cast<const uint32_t*>(src + (rbase + (j < nv1 ? j : nv1)) * ld + h * D + 2 * c2);
   }
 }
 __device__ __forceinline__ float at_dot(const float* qv, const bf16_t* row, int D)
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
-    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+    int T, int Tp, const int32_t* row0, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,8 +188,10 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
   float* Qs = Es + 2 * NW * D;                           // [4 waves][D]
   float* Ps = Qs + 4 * D;                                // [AT_QT][T]
   const int len = lens[b];
-  const size_t rbase = (size_t)b * Tp + HALO;
-  at_stage(St, k, ld, rbase, h, T, D, KP, tid);
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;          // ragged layout: last own row behind rbase (attn_mfma.hip)
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
+  at_stage(St, k, ld, rbase, h, T, D, KP, tid, nv1);
   for (int i = tid; i < NW * D; i += 256) { Es[i] = Ek[i]; Es[NW * D + i] = Ev[i]; }
   __syncthreads();
   const float inv_sqrt = rsqrtf((float)D);
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
     const int i = i0 + ii;
     if (i >= T) break;                                   // wave-uniform
     float* pv = Ps + (size_t)ii * T;
-    for (int c = lane; c < D; c += 64) qv[c] = bf2f(q[(rbase + i) * ld + h * D + c]);
+    for (int c = lane; c < D; c += 64) qv[c] = bf2f(q[RW(i) * ld + h * D + c]);
     __builtin_amdgcn_wave_barrier();
     float mx = -3.0e38f;
     for (int j = lane; j < T; j += 64) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  at_stage(St, v, ld, rbase, h, T, D, KP, tid);
+  at_stage(St, v, ld, rbase, h, T, D, KP, tid, nv1);
   __syncthreads();
   for (int ii = w; ii < AT_QT; ii += 4) {
     const int i = i0 + ii;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256) void gt_attn_fwd_kernel(
       float acc = 0.f;
       for (int j = 0; j < T; ++j) acc += pv[j] * bf2f(St[(size_t)j * KP + c]);
       for (int rel = 0; rel <= 2 * win; ++rel) { const int j = i + rel - win; if (j >= 0 && j < T) acc += pv[j] * Es[NW * D + rel * D + c]; }
-      out[(rbase + i) * ldo + h * D + c] = f2bf(acc);
+      if (i <= nv1) out[(rbase + i) * ldo + h * D + c] = f2bf(acc);
     }
   }
 }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
     const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P, float* __restrict__ dS,
     bf16_t* __restrict__ dq, int lddq, float* __restrict__ dEk, float* __restrict__ dEv,
-    int T, int Tp, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+    int T, int Tp, const int32_t* row0, int H, int D, int win, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -260,8 +262,10 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
   float* Qs = Acc + 2 * NW * D;                          // [AT_QT][2*D]: q row and dO row
   float* Ps = Qs + AT_QT * 2 * D;                        // [AT_QT][T]
   const int len = lens[b];
-  const size_t rbase = (size_t)b * Tp + HALO;
-  at_stage(St, v, ld, rbase, h, T, D, KP, tid);
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;          // ragged layout: last own row behind rbase (attn_mfma.hip)
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
+  at_stage(St, v, ld, rbase, h, T, D, KP, tid, nv1);
   for (int i = tid; i < NW * D; i += 256) { Es[i] = Ek[i]; Es[NW * D + i] = Ev[i]; Acc[i] = 0.f; Acc[NW * D + i] = 0.f; }
   __syncthreads();
   const float inv_sqrt = rsqrtf((float)D);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
     if (i >= T) break;
     float* qv = Qs + ii * 2 * D; float* dov = qv + D;
     float* pv = Ps + (size_t)ii * T;
-    for (int c = lane; c < D; c += 64) { qv[c] = bf2f(q[(rbase + i) * ld + h * D + c]); dov[c] = bf2f(dout[(rbase + i) * lddo + h * D + c]); }
+    for (int c = lane; c < D; c += 64) { qv[c] = bf2f(q[RW(i) * ld + h * D + c]); dov[c] = bf2f(dout[(rbase + i) * lddo + h * D + c]); }
     __builtin_amdgcn_wave_barrier();
     const float* prow = P + (((size_t)b * H + h) * T + i) * T;
     // dPd_j = dO.V_j + [band] dO.Ev[rel];  dP_j = dropout'(dPd_j);  Dsum = sum_j dP_j P_j
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  at_stage(St, k, ld, rbase, h, T, D, KP, tid);
+  at_stage(St, k, ld, rbase, h, T, D, KP, tid, nv1);
   __syncthreads();
   for (int ii = w; ii < AT_QT; ii += 4) {
     const int i = i0 + ii;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
           if (pd != 0.f && i < len) atomicAdd(Acc + NW * D + rel * D + c, pd * dov[c]);
         }
       }
-      dq[(rbase + i) * lddq + h * D + c] = f2bf(acc);
+      if (i <= nv1) dq[(rbase + i) * lddq + h * D + c] = f2bf(acc);
     }
   }
   __syncthreads();
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
 __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
     const bf16_t* __restrict__ q, int ld, const bf16_t* __restrict__ dout, int lddo, const float* __restrict__ P,
     const float* __restrict__ dS, const int32_t* __restrict__ lens, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int lddk,
-    int T, int Tp, int H, int D, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+    int T, int Tp, const int32_t* row0, int H, int D, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
 {
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -337,9 +341,11 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
   const int KP = D + 2;
   bf16_t* St = reinterpret_cast<bf16_t*>(smem);          // [T][KP] q rows, then dO rows
   float* Cs = reinterpret_cast<float*>(St + (size_t)T * KP + (((size_t)T * KP) & 1));   // [AT_QT][2*T] dS column | pd column
-  const size_t rbase = (size_t)b * Tp + HALO;
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;          // ragged layout: last own row behind rbase (attn_mfma.hip)
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
   const int len = lens[b];
-  at_stage(St, q, ld, rbase, h, T, D, KP, tid);
+  at_stage(St, q, ld, rbase, h, T, D, KP, tid, nv1);
   for (int jj = w; jj < AT_QT; jj += 4) {
     const int j = j0 + jj;
     if (j >= T) break;
@@ -360,11 +366,11 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
     for (int c = lane; c < D; c += 64) {
       float ak = 0.f;
       for (int i = 0; i < T; ++i) ak += dsc[i] * bf2f(St[(size_t)i * KP + c]);
-      dk[(rbase + j) * lddk + h * D + c] = f2bf(ak);
+      if (j <= nv1) dk[(rbase + j) * lddk + h * D + c] = f2bf(ak);
     }
   }
   __syncthreads();
-  at_stage(St, dout, lddo, rbase, h, T, D, KP, tid);
+  at_stage(St, dout, lddo, rbase, h, T, D, KP, tid, nv1);
   __syncthreads();
   for (int jj = w; jj < AT_QT; jj += 4) {
     const int j = j0 + jj;
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
     for (int c = lane; c < D; c += 64) {
       float av = 0.f;
       for (int i = 0; i < T; ++i) av += pdc[i] * bf2f(St[(size_t)i * KP + c]);
-      dv[(rbase + j) * lddk + h * D + c] = f2bf(av);
+      if (j <= nv1) dv[(rbase + j) * lddk + h * D + c] = f2bf(av);
     }
   }
 }
@@ -382,11 +388,12 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
 // rows[b*Tp+HALO+t, :] = emb[ids[b,t], :] * scale * (t < len[b]);  fp32 + bf16 copies; halos zero.
 __global__ __launch_bounds__(256) void gt_embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
                                                                const int32_t* __restrict__ lens, float* __restrict__ out_f32,
-                                                               bf16_t* __restrict__ out_bf16, int B, int T, int Tp, int C, float scale)
+                                                               bf16_t* __restrict__ out_bf16, int B, int T, int Tp, int C, float scale,
+                                                               const int32_t* __restrict__ row0, int R)
 {
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (m >= B * Tp) return;
-  const int b = m / Tp, t = m - b * Tp - HALO;
+  if (m >= R) return;
+  const int b = gt_row_batch(row0, B, m, Tp), t = m - gt_row_base(row0, b, Tp) - HALO;
   const bool valid = t >= 0 && t < T && t < lens[b];
   const int64_t id = valid ? ids[(size_t)b * T + t] : 0;
   for (int c = lane; c < C; c += 64) {
@@ -397,11 +404,12 @@ __global__ __launch_bounds__(256) void gt_embedding_fwd_kernel(const int64_t* __
 }
 __global__ __launch_bounds__(256) void gt_embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                                const int32_t* __restrict__ lens, float* __restrict__ demb,
-                                                               int B, int T, int Tp, int C, float scale)
+                                                               int B, int T, int Tp, int C, float scale,
+                                                               const int32_t* __restrict__ row0, int R)
 {
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (m >= B * Tp) return;
-  const int b = m / Tp, t = m - b * Tp - HALO;
+  if (m >= R) return;
+  const int b = gt_row_batch(row0, B, m, Tp), t = m - gt_row_base(row0, b, Tp) - HALO;
   if (t < 0 || t >= T || t >= lens[b]) return;
   const int64_t id = ids[(size_t)b * T + t];
   for (int c = lane; c < C; c += 64) atomicAdd(demb + (size_t)id * C + c, dx[(size_t)m * C + c] * scale);
@@ -577,7 +585,7 @@ static size_t attn_lds(int T, int D, int win, size_t extra_floats)
 }
 
 extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
-                           const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
+                           const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, int D, int win,
                            float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (!q || !k || !v || !Ek || !Ev || !lens || !out || !P || B <= 0 || T <= 0 || H <= 0) return GT_E_INVAL;
@@ -586,7 +594,7 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
     uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
     static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
     if (!no_mfma) {
-      const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, H, D, win, th, sd, sc, seed_dev, stream);
+      const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, row0, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;                      // handled (or failed loudly) on the MFMA path
     }
   }
@@ -597,7 +605,7 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
   uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
   hipLaunchKernelGGL(gt_attn_fwd_kernel, dim3((T + AT_QT - 1) / AT_QT, H, B), dim3(256), lds, GT_ST(stream),
                      static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
-                     static_cast<bf16_t*>(out), ldo, P, T, Tp, H, D, win, th, sd, sc, seed_dev);
+                     static_cast<bf16_t*>(out), ldo, P, T, Tp, row0, H, D, win, th, sd, sc, seed_dev);
   GT_RET();
 }
 
@@ -612,7 +620,7 @@ extern "C" size_t gt_attn_bwd_workspace_bytes(int B, int T, int H)
 extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                            const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                            void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                           int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
+                           int B, int T, int Tp, const int32_t* row0, int H, int D, int win, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream)
 {
   if (!q || !k || !v || !Ek || !Ev || !lens || !dout || !P || !workspace || !dq || !dk || !dv || !dEk || !dEv) return GT_E_INVAL;
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
@@ -623,7 +631,7 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
     static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
     if (!no_mfma) {
       const int rc = gt_attn_bwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, dout, lddo, P, workspace, workspace_bytes, dq, dk, dv, lddq,
-                                           dEk, dEv, B, T, Tp, H, D, win, th, sd, sc, seed_dev, stream);
+                                           dEk, dEv, B, T, Tp, row0, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;
     }
   }
@@ -642,26 +650,28 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
   hipLaunchKernelGGL(gt_attn_bwd_q_kernel, grid, dim3(256), lds1, GT_ST(stream),
                      static_cast<const bf16_t*>(q), static_cast<const bf16_t*>(k), static_cast<const bf16_t*>(v), ld, Ek, Ev, lens,
                      static_cast<const bf16_t*>(dout), lddo, P, dS_ws, static_cast<bf16_t*>(dq), lddq, dEk, dEv,
-                     T, Tp, H, D, win, th, sd, sc, seed_dev);
+                     T, Tp, row0, H, D, win, th, sd, sc, seed_dev);
   hipLaunchKernelGGL(gt_attn_bwd_kv_kernel, grid, dim3(256), lds2, GT_ST(stream),
                      static_cast<const bf16_t*>(q), ld, static_cast<const bf16_t*>(dout), lddo, P, dS_ws, lens,
-                     static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), lddq, T, Tp, H, D, th, sd, sc, seed_dev);
+                     static_cast<bf16_t*>(dk), static_cast<bf16_t*>(dv), lddq, T, Tp, row0, H, D, th, sd, sc, seed_dev);
   GT_RET();
 }
 
 extern "C" int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
-                                int B, int T, int Tp, int C, float scale, void* stream)
+                                int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream)
 {
-  if (!ids || !emb || !lens || (!out_f32 && !out_bf16) || B <= 0 || T <= 0 || C <= 0) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_embedding_fwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, GT_ST(stream), ids, emb, lens, out_f32,
-                     static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale);
+  if (!ids || !emb || !lens || (!out_f32 && !out_bf16) || B <= 0 || T <= 0 || C <= 0 || R <= 0) return GT_E_INVAL;
+  if (!row0 && R != B * Tp) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_embedding_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, emb, lens, out_f32,
+                     static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale, row0, R);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
-                                int B, int T, int Tp, int C, float scale, void* stream)
+                                int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream)
 {
-  if (!ids || !dx || !lens || !demb || B <= 0 || T <= 0 || C <= 0) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_embedding_bwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, GT_ST(stream), ids, dx, lens, demb, B, T, Tp, C, scale);
+  if (!ids || !dx || !lens || !demb || B <= 0 || T <= 0 || C <= 0 || R <= 0) return GT_E_INVAL;
+  if (!row0 && R != B * Tp) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_embedding_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, dx, lens, demb, B, T, Tp, C, scale, row0, R);
   GT_RET();
 }
 

@@ -14,11 +14,14 @@ constexpr int HALO = GT_HALO;
 // ------------------------------------------------------------------ squeeze: [B,C,Ty] -> rows [R,2C]
 // rows[b*Tp + HALO + t', p*C + c] = y[b, c, 2t'+p] * (t' < len[b]);  halo / padded rows = 0.
 __global__ __launch_bounds__(256) void gt_squeeze_rows_kernel(const float* __restrict__ y, float* __restrict__ rows,
-                                                              const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp)
+                                                              const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp,
+                                                              const int32_t* __restrict__ row0)
 {
   __shared__ float tile[32][2 * 80 + 1];          // [t'][p*C+c], C <= 80
   const int b = blockIdx.y, tp0 = blockIdx.x * 32;                 // tp0 indexes rows of the utterance (incl. halo)
-  const int len = len_sq[b], T2 = Tp - 2 * HALO;
+  const int base = gt_row_base(row0, b, Tp), nrows = gt_row_count(row0, b, Tp);
+  if (tp0 >= nrows) return;
+  const int len = len_sq[b], T2 = Ty / 2;
   // load: for each channel, 64 consecutive frames (= 32 squeezed frames x 2 phases)
   for (int i = threadIdx.x; i < C * 64; i += 256) {
     const int c = i >> 6, f = i & 63;
@@ -31,22 +34,24 @@ __global__ __launch_bounds__(256) void gt_squeeze_rows_kernel(const float* __res
   const int C2 = 2 * C;
   for (int i = threadIdx.x; i < 32 * C2; i += 256) {
     const int rr = i / C2, ch = i - rr * C2;
-    if (tp0 + rr < Tp) rows[((size_t)b * Tp + tp0 + rr) * C2 + ch] = tile[rr][ch];
+    if (tp0 + rr < nrows) rows[((size_t)base + tp0 + rr) * C2 + ch] = tile[rr][ch];
   }
 }
 
 // unsqueeze: rows [R,2C] -> [B,C,Ty] with y[b,c,2t'+p] = rows[...]*mask; frames >= 2*len (and a
 // trailing odd frame) are written as 0.  Also the backward of squeeze (and vice versa).
 __global__ __launch_bounds__(256) void gt_unsqueeze_rows_kernel(const float* __restrict__ rows, float* __restrict__ y,
-                                                                const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp)
+                                                                const int32_t* __restrict__ len_sq, int B, int C, int Ty, int Tp,
+                                                                const int32_t* __restrict__ row0)
 {
   __shared__ float tile[32][2 * 80 + 1];
   const int b = blockIdx.y, t0 = blockIdx.x * 32;                  // squeezed frame base (no halo offset)
-  const int len = len_sq[b], C2 = 2 * C, T2 = Tp - 2 * HALO;
+  const int base = gt_row_base(row0, b, Tp);
+  const int len = len_sq[b], C2 = 2 * C, T2 = Ty / 2;
   for (int i = threadIdx.x; i < 32 * C2; i += 256) {
     const int rr = i / C2, ch = i - rr * C2;
     const int tq = t0 + rr;
-    tile[rr][ch] = (tq < len && tq < T2) ? rows[((size_t)b * Tp + HALO + tq) * C2 + ch] : 0.f;
+    tile[rr][ch] = (tq < len && tq < T2) ? rows[((size_t)base + HALO + tq) * C2 + ch] : 0.f;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C * 64; i += 256) {
@@ -204,16 +209,18 @@ __global__ void gt_flow_logdet_bwd_kernel(const float* __restrict__ scal, const 
 // serialise: guide G12).
 __global__ __launch_bounds__(256) void gt_coupling_fwd_kernel(const float* __restrict__ out, const float* __restrict__ x,
                                                               float* __restrict__ z, const float* __restrict__ rowmask,
-                                                              float* __restrict__ logdet, int R, int C, int Tp, int sigmoid_scale)
+                                                              float* __restrict__ logdet, int R, int C, int Tp, int sigmoid_scale,
+                                                              const int32_t* __restrict__ row0)
 {
   __shared__ float red[4];
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6, half = C >> 1;
+  const int base = gt_row_base(row0, b, Tp), nrows = gt_row_count(row0, b, Tp);
   const int t0 = blockIdx.x * 64 + w * 16;
   float s = 0.f;
   for (int tt = 0; tt < 16; ++tt) {
     const int t = t0 + tt;
-    if (t >= Tp) break;
-    const int m = b * Tp + t;
+    if (t >= nrows) break;
+    const int m = base + t;
     const float rm = rowmask[m];
     for (int c = lane; c < half; c += 64) {
       const float mm = out[(size_t)m * C + c];
@@ -236,7 +243,8 @@ __global__ __launch_bounds__(256) void gt_coupling_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void gt_coupling_bwd_kernel(const float* __restrict__ out, const float* __restrict__ x,
                                                               const float* __restrict__ dz, const float* __restrict__ dlogdet,
                                                               const float* __restrict__ rowmask, float* __restrict__ dx,
-                                                              bf16_t* __restrict__ dout_bf16, int R, int C, int Tp, int sigmoid_scale)
+                                                              bf16_t* __restrict__ dout_bf16, int R, int C, int Tp, int sigmoid_scale,
+                                                              const int32_t* __restrict__ row0, int B)
 {
   const int idx = blockIdx.x * 256 + threadIdx.x, half = C >> 1;
   if (idx >= R * half) return;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256) void gt_coupling_bwd_kernel(const float* __res
   const float e = __expf(lg), x1 = x[(size_t)m * C + half + c];
   const float dz1 = dz[(size_t)m * C + half + c] * rm;
   const float d_m = dz1;
-  const float d_lg = (dz1 * e * x1 + dlogdet[m / Tp] * rm) * dl_draw;
+  const float d_lg = (dz1 * e * x1 + dlogdet[gt_row_batch(row0, B, m, Tp)] * rm) * dl_draw;
   dx[(size_t)m * C + c] = dz[(size_t)m * C + c];
   dx[(size_t)m * C + half + c] = dz1 * e;
   dout_bf16[(size_t)m * C + c] = f2bf(d_m);
@@ -329,16 +337,18 @@ __global__ __launch_bounds__(256) void gt_rows_f32_to_bf16_kernel(const float* _
 #define GT_ST(s) static_cast<hipStream_t>(s)
 #define GT_RET() return gt_launch_status(__func__)
 
-extern "C" int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream)
+extern "C" int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp,
+                                   const int32_t* row0, void* stream)
 {
   if (!y || !rows || !len_sq || B <= 0 || C <= 0 || C > 80 || Ty <= 0 || Tp <= 2 * HALO) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_squeeze_rows_kernel, dim3((Tp + 31) / 32, B), dim3(256), 0, GT_ST(stream), y, rows, len_sq, B, C, Ty, Tp);
+  hipLaunchKernelGGL(gt_squeeze_rows_kernel, dim3((Tp + 31) / 32, B), dim3(256), 0, GT_ST(stream), y, rows, len_sq, B, C, Ty, Tp, row0);
   GT_RET();
 }
-extern "C" int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream)
+extern "C" int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp,
+                                     const int32_t* row0, void* stream)
 {
   if (!y || !rows || !len_sq || B <= 0 || C <= 0 || C > 80 || Ty <= 0 || Tp <= 2 * HALO) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_unsqueeze_rows_kernel, dim3((Ty / 2 + 1 + 31) / 32, B), dim3(256), 0, GT_ST(stream), rows, y, len_sq, B, C, Ty, Tp);
+  hipLaunchKernelGGL(gt_unsqueeze_rows_kernel, dim3((Ty / 2 + 1 + 31) / 32, B), dim3(256), 0, GT_ST(stream), rows, y, len_sq, B, C, Ty, Tp, row0);
   GT_RET();
 }
 extern "C" int gt_flow_scalars(const float* logs, int C, const float* W, float* scal, void* stream)
@@ -376,19 +386,20 @@ extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx
   GT_RET();
 }
 extern "C" int gt_coupling_fwd(const float* out, const float* x, float* z, const float* rowmask, float* logdet,
-                               int R, int C, int Tp, int sigmoid_scale, void* stream)
+                               int B, int R, int C, int Tp, const int32_t* row0, int sigmoid_scale, void* stream)
 {
-  if (!out || !x || !z || !rowmask || !logdet || R <= 0 || (C & 1)) return GT_E_INVAL;
-  if (Tp <= 0 || R % Tp) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_coupling_fwd_kernel, dim3((Tp + 63) / 64, R / Tp), dim3(256), 0, GT_ST(stream), out, x, z, rowmask, logdet, R, C, Tp, sigmoid_scale);
+  if (!out || !x || !z || !rowmask || !logdet || R <= 0 || B <= 0 || (C & 1)) return GT_E_INVAL;
+  if (Tp <= 0 || (!row0 && R != B * Tp)) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_coupling_fwd_kernel, dim3((Tp + 63) / 64, B), dim3(256), 0, GT_ST(stream), out, x, z, rowmask, logdet, R, C, Tp, sigmoid_scale, row0);
   GT_RET();
 }
 extern "C" int gt_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const float* rowmask,
-                               float* dx, void* dout_bf16, int R, int C, int Tp, int sigmoid_scale, void* stream)
+                               float* dx, void* dout_bf16, int B, int R, int C, int Tp, const int32_t* row0, int sigmoid_scale,
+                               void* stream)
 {
-  if (!out || !x || !dz || !dlogdet || !rowmask || !dx || !dout_bf16 || R <= 0 || (C & 1)) return GT_E_INVAL;
+  if (!out || !x || !dz || !dlogdet || !rowmask || !dx || !dout_bf16 || R <= 0 || B <= 0 || Tp <= 0 || (C & 1)) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_coupling_bwd_kernel, dim3((R * (C / 2) + 255) / 256), dim3(256), 0, GT_ST(stream),
-                     out, x, dz, dlogdet, rowmask, dx, static_cast<bf16_t*>(dout_bf16), R, C, Tp, sigmoid_scale);
+                     out, x, dz, dlogdet, rowmask, dx, static_cast<bf16_t*>(dout_bf16), R, C, Tp, sigmoid_scale, row0, B);
   GT_RET();
 }
 extern "C" int gt_rows_add_bf16(float* dx, int ldx, const void* add, int lda, int R, int n, void* stream)

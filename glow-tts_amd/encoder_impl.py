@@ -71,7 +71,7 @@ def mha_fwd(rc, att, xb, p, seed):
     Ek = att.emb_rel_k.detach().reshape(-1, D).contiguous()
     Ev = att.emb_rel_v.detach().reshape(-1, D).contiguous()
     _lib.check(L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
-                             _lib.ptr(o), C, _lib.ptr(P), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed),
+                             _lib.ptr(o), C, _lib.ptr(P), rc.B, rc.T, rc.Tp, _lib.ptr(rc.row0), H, D, att.window_size, float(p), int(seed),
                              _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_fwd")
     y = conv_rows(o, att.conv_o.pc, rc, bias=att.conv_o.bias)
@@ -99,7 +99,7 @@ def mha_bwd(rc, att, saved, dy, grads):
     dEv = zeros_small(Ev.shape, Ev.dtype, dev)
     _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
                              _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C,
-                             _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, H, D, att.window_size, float(p), int(seed),
+                             _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, _lib.ptr(rc.row0), H, D, att.window_size, float(p), int(seed),
                              _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_bwd")
     grads[att.emb_rel_k] = dEk.view_as(att.emb_rel_k)

@@ -175,7 +175,7 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre
-            dcond[:, 2 * H * i:2 * H * (i + 1)] = src.float().reshape(rc.B, rc.Tp, 2 * H).sum(1)
+            dcond[:, 2 * H * i:2 * H * (i + 1)] = rc.batch_sum(src.float())
         # d x_i = dgrad(in_layer) + (residual path), then through the mask of x_i's producer
         dres = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=dres, mask=True)
     return dres, grads, dcond
@@ -192,7 +192,7 @@ def coupling_fwd(rc, cb, x, x0_bf16, cond, logdet, train, seed):
     out = conv_rows(wn_out, cb.end.pc, rc, bias=cb.end.bias, out_f32=True)      # [R,C] = [m | logs]
     z = torch.empty_like(x)
     _lib.check(L.gt_coupling_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(z), _lib.ptr(rc.rowmask), _lib.ptr(logdet),
-                                 R, C, rc.Tp, int(cb.sigmoid_scale), _st(dev)), "gt_coupling_fwd")
+                                 rc.B, R, C, rc.Tp, _lib.ptr(rc.row0), int(cb.sigmoid_scale), _st(dev)), "gt_coupling_fwd")
     return z, (x, x0_bf16, h0, wn_out, wn_saved, out)
 
 
@@ -204,7 +204,8 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
     dx = torch.empty_like(x)
     dout = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
     _lib.check(L.gt_coupling_bwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(dz), _lib.ptr(dlogdet), _lib.ptr(rc.rowmask),
-                                 _lib.ptr(dx), _lib.ptr(dout), R, C, rc.Tp, int(cb.sigmoid_scale), _st(dev)), "gt_coupling_bwd")
+                                 _lib.ptr(dx), _lib.ptr(dout), rc.B, R, C, rc.Tp, _lib.ptr(rc.row0), int(cb.sigmoid_scale), _st(dev)),
+               "gt_coupling_bwd")
     grads = conv_param_grads(cb.end, wn_out, dout, R)
     dskip = conv_rows(dout, cb.end.pc, rc, dgrad=True, mask=True)                # d(wn out) * mask = d skip
     dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, dskip, want_dcond)

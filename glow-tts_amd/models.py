@@ -72,11 +72,11 @@ class _DecoderRunner:
         dev = x.device
         T2 = T // 2
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)          # mask[:, :, 1::2] (commons.py:348)
-        rc = RowsCtx(len_sq, T2)
+        rc = ops.make_ctx(len_sq, T2, "y", div=2)
         xin = x.detach().float().contiguous()
         rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
-        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, st), "gt_squeeze_rows_f32")
+        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         logdet = ops.zeros_small(B, torch.float32, dev)
         saved = []
         cur = rows
@@ -86,7 +86,7 @@ class _DecoderRunner:
             cur, s2 = flow_impl.coupling_fwd(rc, cb, y1, x0, conds[b], logdet, self.train, self.seed + 16 * b)
             saved.append((s1, s2))
         z = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
-        _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(z), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, st), "gt_unsqueeze_rows_f32")
+        _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(z), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
         return (z.to(x.dtype), logdet), (rc, saved, (B, C, T))
 
     def backward(self, saved_all, dz, dlogdet):
@@ -104,7 +104,7 @@ class _DecoderRunner:
             drows.zero_()
         else:
             dzc = dz.float().contiguous()
-            _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, st), "gt_squeeze_rows_f32")
+            _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         dconds = [None] * nb
         cur = drows
         # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
@@ -122,10 +122,10 @@ class _DecoderRunner:
                     grads.update(g1)
         dx = torch.zeros(B, C, T, dtype=torch.float32, device=dev) if T != T2 * 2 else torch.empty(B, C, T, dtype=torch.float32, device=dev)
         if T == T2 * 2:
-            _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(dx), _lib.ptr(rc.lengths), B, C, T, rc.Tp, st), "gt_unsqueeze_rows_f32")
+            _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(dx), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
         else:
             tmp = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
-            _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(tmp), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, st), "gt_unsqueeze_rows_f32")
+            _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(tmp), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
             dx[:, :, :T2 * 2] = tmp
         out = [dx]
         if self.has_cond:

@@ -110,35 +110,127 @@ def zeros_small(shape, dtype, device):
     return a["buf"][off:off + nbytes].view(dtype)[:n].view(shape)
 
 
-class RowsCtx:
-    """Geometry of one batch in the rows layout: utterance b owns rows [b*Tp, (b+1)*Tp),
-    frame t is row b*Tp + HALO + t; rowmask is 1 on valid frames."""
+_PREBUILT = {}          # "x" / "y" -> ragged RowsCtx the next forward must use (train.Trainer, around capture / replay)
+_HOST_LENGTHS = {}      # "x" / "y" -> list of ints for the batch in flight (set by FlowGenerator.forward)
+RAGGED = False          # train.Trainer turns it on: utterances are packed back to back (see RowsCtx)
+ROW_ROUND = 128         # ragged R is rounded up to this (row tiles of the GEMMs)
 
-    def __init__(self, lengths, T):
+
+class RowsCtx:
+    """Geometry of one batch in the rows layout; rowmask is 1 on valid frames.
+
+    uniform (default): utterance b owns rows [b*Tp, (b+1)*Tp), Tp = T + 2*HALO, frame t is row b*Tp + HALO + t.
+    ragged  (lengths_host given): utterance b owns rows [row0[b], row0[b+1]) = its OWN frames + 2*HALO, back to
+    back — padded frames (30 % of an LJSpeech-shaped batch) cost no GEMM, no elementwise and no HBM work.  R is
+    rounded up to `round_to` (the last utterance owns the extra, masked rows) so that a captured HIP graph can be
+    replayed for every batch of the same rounded size; Tp = the largest row count of one utterance (grid sizing).
+    The host needs the lengths (the data loader has them; no device sync)."""
+
+    def __init__(self, lengths, T, lengths_host=None, round_to=None):
         _lib.require_cuda(lengths)
         self.device = lengths.device
         self.B = int(lengths.shape[0])
         self.T = int(T)
-        self.Tp = self.T + 2 * HALO
-        self.R = self.B * self.Tp
         self.lengths = lengths.to(torch.int32)
-        t = torch.arange(self.Tp, device=self.device) - HALO
-        self.rowmask2d = ((t[None, :] >= 0) & (t[None, :] < self.lengths[:, None])).to(torch.float32)
-        self.rowmask = self.rowmask2d.reshape(-1).contiguous()
+        self.ragged = lengths_host is not None
+        if not self.ragged:
+            self.Tp = self.T + 2 * HALO
+            self.R = self.B * self.Tp
+            self.row0 = None
+            t = torch.arange(self.Tp, device=self.device) - HALO
+            self.rowmask2d = ((t[None, :] >= 0) & (t[None, :] < self.lengths[:, None])).to(torch.float32)
+            self.rowmask = self.rowmask2d.reshape(-1).contiguous()
+            return
+        assert len(lengths_host) == self.B
+        rnd = self.rnd = int(round_to or ROW_ROUND)
+        starts, self.R = self.row_starts(lengths_host, self.T, rnd)  # the last utterance owns the rounding rows
+        # Tp only sizes grids: the upper bound keeps a captured graph valid for any batch with the same R
+        self.Tp = self.T + 2 * HALO + rnd - 1
+        self.rowmask2d = None
+        assert not torch.cuda.is_current_stream_capturing(), \
+            "a ragged RowsCtx is built outside graph capture (train.Trainer prebuilds and refreshes it)"
+        self.lengths = self.lengths.clone()                         # own storage: refresh() rewrites it in place
+        self.row0 = torch.empty(self.B + 1, dtype=torch.int32, device=self.device)
+        self.rowbatch = torch.empty(self.R, dtype=torch.int64, device=self.device)
+        self.rowframe = torch.empty(self.R, dtype=torch.int32, device=self.device)
+        self.rowmask = torch.empty(self.R, dtype=torch.float32, device=self.device)
+        self._fill(starts)
+
+    def _fill(self, starts):
+        """row0 (host list) -> device row0, row -> utterance, row -> frame, rowmask; all in place."""
+        self.row0.copy_(torch.tensor(starts, dtype=torch.int32).pin_memory(), non_blocking=True)
+        m = torch.arange(self.R, device=self.device, dtype=torch.int32)
+        self.rowbatch.copy_(torch.searchsorted(self.row0[1:].contiguous(), m, right=True).clamp_(max=self.B - 1))
+        self.rowframe.copy_(m - self.row0[:-1][self.rowbatch] - HALO)
+        self.rowmask.copy_(((self.rowframe >= 0) & (self.rowframe < self.lengths[self.rowbatch])).to(torch.float32))
+
+    def batch_sum(self, rows):
+        """[R, C] -> [B, C]: sum over the rows of each utterance."""
+        if not self.ragged:
+            return rows.reshape(self.B, self.Tp, rows.shape[1]).sum(1)
+        out = torch.zeros(self.B, rows.shape[1], dtype=rows.dtype, device=rows.device)
+        return out.index_add_(0, self.rowbatch.long(), rows)
+
+    @staticmethod
+    def row_starts(lengths_host, T, rnd):
+        """(starts [B+1] with starts[B] = R rounded up, R) of the ragged layout for these lengths."""
+        starts = [0]
+        for v in lengths_host:
+            starts.append(starts[-1] + max(0, min(int(v), T)) + 2 * HALO)
+        R = -(-starts[-1] // rnd) * rnd
+        starts[-1] = R
+        return starts, R
+
+    def refresh(self, lengths, lengths_host):
+        """New batch of the same rounded size (a captured graph that reads this context is about to be replayed):
+        stream-ordered, in-place update of everything the graph's kernels read.  False if the size differs."""
+        starts, R = self.row_starts(lengths_host, self.T, self.rnd)
+        if R != self.R:
+            return False
+        self.lengths.copy_(lengths.to(torch.int32))
+        self._fill(starts)
+        return True
+
+    def mask_bt(self):
+        """[B, T] 1/0 mask of valid frames."""
+        return (torch.arange(self.T, device=self.device)[None, :] < self.lengths[:, None]).to(torch.float32)
 
     def to_rows(self, x, dtype=None):
-        """[B, C, T] -> [R, C] (test/boundary helper; zero halos)."""
+        """[B, C, T] -> [R, C] (test/boundary helper; zero halos and padding)."""
         B, C, T = x.shape
         assert B == self.B and T == self.T
-        out = torch.zeros(self.B, self.Tp, C, device=x.device, dtype=dtype or x.dtype)
-        out[:, HALO:HALO + T] = x.transpose(1, 2).to(out.dtype)
-        return out.reshape(self.R, C)
+        if not self.ragged:
+            out = torch.zeros(self.B, self.Tp, C, device=x.device, dtype=dtype or x.dtype)
+            out[:, HALO:HALO + T] = x.transpose(1, 2).to(out.dtype)
+            return out.reshape(self.R, C)
+        xt = x.transpose(1, 2).to(dtype or x.dtype)                                  # [B, T, C]
+        inside = (self.rowframe >= 0) & (self.rowframe < T)
+        idx = self.rowbatch.long() * T + self.rowframe.clamp(0, T - 1).long()
+        return (xt.reshape(B * T, C)[idx] * inside[:, None].to(xt.dtype)).contiguous()
 
     def from_rows(self, xr, dtype=None):
-        """[R, C] -> [B, C, T]."""
+        """[R, C] -> [B, C, T] (frames that have no row — past an utterance's length — come back as zero)."""
         C = xr.shape[1]
-        x = xr.reshape(self.B, self.Tp, C)[:, HALO:HALO + self.T].transpose(1, 2)
-        return x.to(dtype or xr.dtype).contiguous()
+        if not self.ragged:
+            x = xr.reshape(self.B, self.Tp, C)[:, HALO:HALO + self.T].transpose(1, 2)
+            return x.to(dtype or xr.dtype).contiguous()
+        t = torch.arange(self.T, device=self.device)
+        rows = (self.row0[:-1].long()[:, None] + HALO + t[None, :]).clamp_(max=self.R - 1)   # [B, T]
+        out = xr[rows.reshape(-1)].reshape(self.B, self.T, C) * self.mask_bt()[:, :, None].to(xr.dtype)
+        return out.transpose(1, 2).to(dtype or xr.dtype).contiguous()
+
+
+def make_ctx(lengths, T, which, div=1):
+    """RowsCtx for the text side (which = "x") or the mel side ("y", div = n_sqz): ragged when ops.RAGGED is on and
+    the host knows the lengths of the batch in flight (FlowGenerator.forward / train.Trainer put them in), else uniform."""
+    pre = _PREBUILT.get(which)
+    if pre is not None:                                     # the captured-graph path: context built (and refreshed) outside
+        assert pre.T == int(T) and pre.B == int(lengths.shape[0]), "prebuilt rows context does not fit this batch"
+        return pre
+    lh = _HOST_LENGTHS.get(which) if RAGGED else None
+    if lh is None:
+        return RowsCtx(lengths, T)
+    return RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh])
 
 
 def _use_gemm2():
@@ -237,7 +329,8 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(addend), 0 if addend is None else addend.stride(0),
                              _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
-                             _lib.ptr(seed_word(x.device)) if drop_p > 0 else None, _lib.current_stream(x.device))
+                             _lib.ptr(seed_word(x.device)) if drop_p > 0 else None,
+                             _lib.ptr(ctx.row0) if cond is not None else None, ctx.B, _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
     _lib.check(rc, "gt_conv_gemm2_bf16" if fn is L.gt_conv_gemm2_bf16 else "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate == 1 else out

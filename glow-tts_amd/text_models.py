@@ -114,12 +114,12 @@ class _TextEncoderRunner:
         B, T = self.ids.shape
         dev = self.ids.device
         C = te.hidden_channels
-        rc = RowsCtx(self.lengths.to(torch.int32), T)
+        rc = ops.make_ctx(self.lengths.to(torch.int32), T, "x")
         x = torch.empty(rc.R, C, dtype=torch.float32, device=dev)
         xb = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
         emb = te.emb.weight.detach()
         _lib.check(L.gt_embedding_fwd(_lib.ptr(self.ids), _lib.ptr(emb), _lib.ptr(rc.lengths), _lib.ptr(x), _lib.ptr(xb),
-                                      B, T, rc.Tp, C, math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_fwd")
+                                      B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C, math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_fwd")
         s_pre = None
         if te.prenet:
             x, xb, s_pre = encoder_impl.crn_fwd(rc, te.pre, x, xb, self.train, self.seed)
@@ -168,7 +168,7 @@ class _TextEncoderRunner:
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
         demb = torch.zeros_like(te.emb.weight)
         B, T = self.ids.shape
-        _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, C,
+        _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C,
                                       math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_bwd")
         grads[te.emb.weight] = demb
         return [grads.get(p) for p in self.params]
@@ -184,17 +184,18 @@ class _DurationRunner:
     def forward(self, *_):
         out, saved = encoder_impl.dp_fwd(self.rc, self.dp, self.xb, self.train, self.seed)
         rc = self.rc
-        logw = out.reshape(rc.B, rc.Tp, 8)[:, HALO:HALO + rc.T, 0].unsqueeze(1).contiguous()      # [b,1,t]
+        logw = rc.from_rows(out)[:, :1].contiguous()                                              # [b,1,t]
         return (logw,), saved
 
     def backward(self, saved, dlogw):
         rc = self.rc
         grads = {}
-        dout = torch.zeros(rc.B, rc.Tp, 8, dtype=torch.float32, device=rc.device)
-        dout[:, HALO:HALO + rc.T, 0] = dlogw[:, 0].float()
+        d8 = torch.zeros(rc.B, 8, rc.T, dtype=torch.float32, device=rc.device)
+        d8[:, 0] = dlogw[:, 0].float()
+        dout = rc.to_rows(d8)
         from . import wgrad
         with wgrad.WgradQueue(rc.device, site=self.dp):
-            encoder_impl.dp_bwd(rc, self.dp, saved, dout.reshape(rc.R, 8), grads)
+            encoder_impl.dp_bwd(rc, self.dp, saved, dout, grads)
         return [grads.get(p) for p in self.params]
 
 
@@ -313,10 +314,18 @@ class FlowGenerator(nn.Module):
         y_lengths = torch.div(y_lengths, self.n_sqz, rounding_mode="floor") * self.n_sqz
         return y, y_lengths, y_max_length
 
-    def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None):
+    def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None,
+                lengths_host=None):
+        """lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (ops.RAGGED) size its buffers
+        without a device sync (the data loader has them); without it they are read back from the device."""
         assert g is None and emo is None and pitch is None and energy is None and l is None, "cfg 4/5 conditioning: next round"
         self.prepare()
         self._step += 1
+        if ops.RAGGED:
+            lh = lengths_host if lengths_host is not None else (x_lengths.tolist(), y_lengths.tolist())
+            ops._HOST_LENGTHS["x"], ops._HOST_LENGTHS["y"] = list(lh[0]), list(lh[1])
+        else:
+            ops._HOST_LENGTHS.clear()
         xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)

@@ -194,7 +194,13 @@ class Trainer:
     and dropout masks still change every replay because every dropout kernel mixes the device-resident seed word
     (ops.seed_word) that the graph itself bumps.  One process alone: ONE graph.  Data-parallel (world > 1): two
     graphs — forward/backward/gather and the optimizer — with the RCCL all-reduce of the flat gradient buffer
-    launched between them (collectives stay outside the captured region)."""
+    launched between them (collectives stay outside the captured region).
+
+    Rows layout: ragged (ops.RAGGED, GT_RAGGED=0 turns it off) — every utterance owns exactly its own frames, so the
+    ~30 % of padded frames of an LJSpeech-shaped batch cost nothing.  The row count is rounded (128 eager, 512 under
+    graphs) and one graph is captured per distinct (text rows, mel rows) pair; a replay only refreshes the per-utterance
+    row offsets on the device.  `step(..., lengths_host=(x_lengths, y_lengths))` takes the lengths as Python ints (the
+    data loader has them); without it they are read back from the device (one sync per step)."""
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None):
@@ -210,18 +216,19 @@ class Trainer:
         wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "1") != "0"      # weight-gradient batches on a side stream
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
-        self._graphs = None
-        self._static = None
-        self._out = None
+        self._captured = {}                       # (text rows, mel rows) -> (graphs, static inputs, outputs, row contexts)
+        from . import ops
+        ops.RAGGED = os.environ.get("GT_RAGGED", "1") != "0"
+        ops.ROW_ROUND = 512 if self.graph_mode else 128
 
-    def _fwd_bwd(self, ids, t_x, y, t_y):
+    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None):
         from . import ops
         m = self.model
         ops.bump_seed(ids.device)
         ops.arena_begin(ids.device)              # one fill for all the small zeroed accumulators of this step
         for p in self.buckets.params:
             p.grad = None
-        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y)
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host)
         l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
         loss = l_mle + torch.sum(l_length)
         loss.backward()
@@ -235,20 +242,34 @@ class Trainer:
         self.grad_norm = torch.sqrt(self.opt.step())
         ops.arena_end(device)
 
-    def _step_impl(self, ids, t_x, y, t_y):
-        out = self._fwd_bwd(ids, t_x, y, t_y)
+    def _step_impl(self, ids, t_x, y, t_y, lengths_host=None):
+        out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host)
         self.buckets.allreduce()
         self._optim(ids.device)
         return out
 
-    def _capture(self, ids, t_x, y, t_y):
-        self._static = [t.clone() for t in (ids, t_x, y, t_y)]
+    def _capture(self, ids, t_x, y, t_y, lh):
+        from . import ops
+        static = [t.clone() for t in (ids, t_x, y, t_y)]
+        ctxs = {}
+        if ops.RAGGED:                               # row contexts live outside the graph; replays refresh them in place
+            ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0])
+            ctxs["y"] = ops.RowsCtx((static[3] // 2).to(torch.int32), y.shape[2] // 2, lengths_host=[int(v) // 2 for v in lh[1]])
+        ops._PREBUILT.update(ctxs)
+        try:
+            return self._capture_with(static, lh, ctxs)
+        finally:
+            ops._PREBUILT.clear()
+
+    def _capture_with(self, static, lh, ctxs):
+        from . import ops
+        ids = static[0]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(3):                       # warm-up: one-time attribute calls, scratch growth, optimizer state
-                self._step_impl(*self._static)
+                self._step_impl(*static, lengths_host=lh)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
@@ -256,36 +277,54 @@ class Trainer:
         g1 = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(g1, stream=side):
-                self._out = self._step_impl(*self._static)
-            self._graphs = (g1,)
+                out = self._step_impl(*static, lengths_host=lh)
+            graphs = (g1,)
         else:
             with torch.cuda.graph(g1, stream=side):
-                self._out = self._fwd_bwd(*self._static)
+                out = self._fwd_bwd(*static, lengths_host=lh)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, stream=side, pool=g1.pool()):
                 self._optim(ids.device)
-            self._graphs = (g1, g2)
+            graphs = (g1, g2)
+        return graphs, static, out, ctxs
 
-    def step(self, ids, t_x, y, t_y):
+    def _rows_key(self, ids, y, lh):
+        from . import ops
+        if not ops.RAGGED:
+            return (0, 0)
+        _, rx = ops.RowsCtx.row_starts(lh[0], ids.shape[1], ops.ROW_ROUND)
+        _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], y.shape[2] // 2, ops.ROW_ROUND)
+        return (rx, ry)
+
+    def step(self, ids, t_x, y, t_y, lengths_host=None):
+        from . import ops
         if self.total_steps:
             self.opt.set_schedule(*one_cycle(self.n_steps, self.total_steps, self.max_lr))
         self.n_steps += 1
+        lh = lengths_host
+        if ops.RAGGED and lh is None:
+            lh = (t_x.tolist(), t_y.tolist())        # device sync: pass lengths_host to avoid it
         if not self.graph_mode:
-            return self._step_impl(ids, t_x, y, t_y)
-        if self._graphs is None:
+            return self._step_impl(ids, t_x, y, t_y, lh)
+        key = self._rows_key(ids, y, lh) + (tuple(ids.shape), tuple(y.shape))
+        cap = self._captured.get(key)
+        if cap is None:
             try:
-                self._capture(ids, t_x, y, t_y)
+                cap = self._captured[key] = self._capture(ids, t_x, y, t_y, lh)
             except Exception as e:                   # e.g. a collective that refuses capture: keep training, eagerly
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({e!r}); continuing with eager launches")
-                self.graph_mode, self._graphs = False, None
-                return self._step_impl(ids, t_x, y, t_y)
-        else:
-            for dst, src in zip(self._static, (ids, t_x, y, t_y)):
-                if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src)
-        self._graphs[0].replay()
-        if len(self._graphs) > 1:
+                self.graph_mode = False
+                return self._step_impl(ids, t_x, y, t_y, lh)
+        graphs, static, out, ctxs = cap
+        for dst, src in zip(static, (ids, t_x, y, t_y)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)
+            ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
+            assert ok, "row count of the batch does not match the captured graph"
+        graphs[0].replay()
+        if len(graphs) > 1:
             self.buckets.allreduce()                 # RCCL all-reduce of the flat gradient buffer, between the graphs
-            self._graphs[1].replay()
-        return self._out
+            graphs[1].replay()
+        return out

@@ -92,8 +92,11 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
 
 /* ------------------------------------------------------------------------------------
  * "Rows" activation layout used by every kernel below: [R, C] channels-last (C contiguous),
- * R = B * Tp, utterance b owns rows [b*Tp, (b+1)*Tp), Tp = T + 2*HALO (HALO = 2), frame t of
- * utterance b is row b*Tp + HALO + t; halo rows and rows past the utterance length are zero
+ * uniform: R = B * Tp, utterance b owns rows [b*Tp, (b+1)*Tp), Tp = T + 2*HALO (HALO = 2); ragged: every entry point
+ * that takes Tp also takes `row0` (device int32 [B+1], NULL = uniform): utterance b owns rows [row0[b], row0[b+1]) =
+ * its own frames + 2*HALO (the last utterance also owns the rows that round R up), so frames past an utterance's
+ * length cost no work, and Tp is only an upper bound on the rows of one utterance (grid sizing).  Frame t of
+ * utterance b is row base(b) + HALO + t; halo rows and rows past the utterance length are zero
  * (rowmask[R] is 1 on valid frames, 0 elsewhere).  bf16 tensors are raw uint16 bit patterns.
  */
 #define GT_HALO 2
@@ -120,7 +123,8 @@ int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                       void* gate_t, void* gate_s, int ldts,
                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                      int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
+                      int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
+                      const int32_t* row0, int B, void* stream);
 
 /* Second-generation implicit GEMM (LDS-DMA rings for both operands, 128x192 / 128x96 / 64x192 / 64x96 tiles): same
  * arguments and semantics as gt_conv_gemm_bf16, for shapes gt_conv_gemm2_supported() accepts (Cin % 64 == 0,
@@ -132,7 +136,8 @@ int gt_conv_gemm2_bf16(const void* X, int ldx, const void* Wp, const float* bias
                        void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                        void* gate_t, void* gate_s, int ldts,
                        int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
+                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
+                      const int32_t* row0, int B, void* stream);
 
 /* Weight preparation for gt_conv_gemm_bf16: w = g*v/||v|| when g != NULL (torch weight_norm,
  * dim 0: modules.py:127,132,141, attentions.py:103) else w = v; v is [Cout, Cin, taps] fp32.
@@ -197,8 +202,10 @@ int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, int N, void
 
 /* commons.squeeze / unsqueeze (commons.py:339-364) fused with the [B,C,T] <-> rows layout change.
  * len_sq[b] = valid squeezed frames; Tp = Ty/2 + 2*GT_HALO; C <= 80.  Each is the other's backward. */
-int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream);
-int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp, void* stream);
+int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int B, int C, int Ty, int Tp,
+                        const int32_t* row0, void* stream);
+int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp,
+                          const int32_t* row0, void* stream);
 
 /* ActNorm (modules.py:584-599) + InvConvNear (modules.py:635-665) fused, rows layout fp32 [R,C]:
  *   y = (W_4x4 applied per group {2g,2g+1,C/2+2g,C/2+2g+1} to (bias + exp(logs)*x)) * mask
@@ -217,9 +224,10 @@ int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx, const flo
 /* Affine coupling (attentions.py:174-186): out = [m|logs] fp32 rows from the `end` conv.
  *   z = [x0 | (m + exp(logs)*x1)*mask],  logdet[b] += sum(logs*mask). */
 int gt_coupling_fwd(const float* out, const float* x, float* z, const float* rowmask, float* logdet,
-                    int R, int C, int Tp, int sigmoid_scale, void* stream);
+                    int B, int R, int C, int Tp, const int32_t* row0, int sigmoid_scale, void* stream);
 int gt_coupling_bwd(const float* out, const float* x, const float* dz, const float* dlogdet, const float* rowmask,
-                    float* dx, void* dout_bf16, int R, int C, int Tp, int sigmoid_scale, void* stream);
+                    float* dx, void* dout_bf16, int B, int R, int C, int Tp, const int32_t* row0, int sigmoid_scale,
+                    void* stream);
 
 /* WaveNet gate backward (commons.py:61-68): dpre [R,2*half] bf16 from d(acts), saved T and S;
  * dpre carries the replayed dropout mask, dpre_cond (optional) does not. */
@@ -254,19 +262,20 @@ int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma,
  * (softmax before dropout, kept for the backward); workspace: gt_attn_bwd_workspace_bytes(B,T,H) bytes of
  * scratch, 16-byte aligned; dEk/dEv ACCUMULATE.  D = 96, win = 4, T <= 256 run on bf16 MFMA. */
 int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
-                const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, int H, int D, int win,
+                const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, int D, int win,
                 float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
 size_t gt_attn_bwd_workspace_bytes(int B, int T, int H);
 int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float* Ek, const float* Ev,
                 const int32_t* lens, const void* dout, int lddo, const float* P, void* workspace, size_t workspace_bytes,
                 void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
-                int B, int T, int Tp, int H, int D, int win, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev, void* stream);
+                int B, int T, int Tp, const int32_t* row0, int H, int D, int win, float drop_p, uint32_t drop_seed,
+                const uint32_t* seed_dev, void* stream);
 
 /* Embedding * scale into rows (models.py:693): fp32 and/or bf16 output, zero halo / padded rows. */
 int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
-                     int B, int T, int Tp, int C, float scale, void* stream);
+                     int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream);
 int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
-                     int B, int T, int Tp, int C, float scale, void* stream);
+                     int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream);
 
 /* log-likelihood lattice (models.py:1076-1082) on exact-fp32 MFMA: x_m, x_logs (NULL = 0): [B,C,Tx],
  * z: [B,C,Ty] -> logp [B,Tx,Ty] fp32. */
