@@ -75,6 +75,43 @@ def mas_leg(dev, wl, rank, iters=100):
             "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes, "logp": logp, "t_x": t_x, "t_y": t_y}
 
 
+def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
+    """The dominant kernel alone, on the step's own shapes and weights: the WN in_layer k=5 conv + gate of the first
+    coupling block, `launches` back-to-back launches captured in ONE HIP graph (no host launch gaps, as in the step's own
+    graph) and timed with HIP events on the stream they run on.  -> average launch duration in ms."""
+    from glow_tts_amd import ops
+    wn = model.decoder.flows[2].wn
+    conv = wn.in_layers[0]
+    lens = torch.tensor([v // 2 for v in lh[1]], dtype=torch.int32, device=dev)
+    rc = ops.RowsCtx(lens, T_y // 2, lengths_host=[v // 2 for v in lh[1]]) if ops.RAGGED else ops.RowsCtx(lens, T_y // 2)
+    H = wn.hidden_channels
+    x = (torch.randn(rc.R, H, device=dev) * rc.rowmask[:, None]).to(torch.bfloat16)
+    y = torch.empty(rc.R, H, dtype=torch.bfloat16, device=dev); t = torch.empty_like(y); s_ = torch.empty_like(y)
+
+    def run():
+        ops.conv_rows(x, conv.pc, rc, bias=conv.bias, gate=True, out=y, gate_t=t, gate_s=s_, drop_p=p_drop, seed=1)
+    run(); torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        run()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(launches):
+                run()
+    torch.cuda.synchronize(dev)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / (replays * launches), rc.R
+
+
 def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4):
     """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
     from oracle import glowtts_ref as R
@@ -140,6 +177,7 @@ def main():
     use_graph = not args.no_graph
     tr = train.Trainer(model, world=world, graph=use_graph)
     ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
+    lh = (t_x.tolist(), t_y.tolist())                # host copy of the lengths (a data loader has them): no per-step sync
     valid_frames = int(t_y.sum().item())
     padded_frames = wl["B"] * wl["T_y"]
 
@@ -149,13 +187,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        tr.step(ids, t_x, y, t_y)
+        tr.step(ids, t_x, y, t_y, lengths_host=lh)
     barrier()
     if not use_graph:
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")  # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, mle = tr.step(ids, t_x, y, t_y)
+        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh)
     barrier()
     wall = time.perf_counter() - t0
     if use_graph:
@@ -164,7 +202,7 @@ def main():
         # (same process, same stream, same data), with HIP events around each of its 48 launches per step.
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")
         for _ in range(3):
-            tr._step_impl(ids, t_x, y, t_y)
+            tr._step_impl(ids, t_x, y, t_y, lh)
     kt = ops.KERNEL_TIMER.collect()
     if world > 1:
         t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)
@@ -177,8 +215,14 @@ def main():
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        R_dec = wl["B"] * (wl["T_y"] // 2 + 2 * ops.HALO)
-        flops_launch = 2.0 * R_dec * 384 * 192 * 5                   # in_layer 192 -> 384, k = 5, per row
+        if ops.RAGGED:                                # utterances packed back to back: only their own frames (+ halos) are rows
+            _, R_dec = ops.RowsCtx.row_starts([v // 2 for v in lh[1]], wl["T_y"] // 2, ops.ROW_ROUND)
+        else:
+            R_dec = wl["B"] * (wl["T_y"] // 2 + 2 * ops.HALO)
+        # in_layer 192 -> 384, k = 5: 368 640 MAC per squeezed frame.  Ragged layout: only the VALID squeezed
+        # frames count as algorithmic work (halo / rounding rows the kernel also walks do not)
+        rows_alg = valid_frames // 2 if ops.RAGGED else R_dec
+        flops_launch = 2.0 * rows_alg * 384 * 192 * 5
         line = {
             "metric": "mel_frames_per_sec_train_step",
             "value": total_valid / (wall / args.steps),
@@ -188,6 +232,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": wl["B"], "T_x": wl["T_x"], "T_y": wl["T_y"],
                        "valid_frames_per_gpu_step": valid_frames, "padded_frames_per_gpu_step": padded_frames,
+                       "rows_layout": (f"ragged (decoder rows {R_dec})" if ops.RAGGED else f"uniform (decoder rows {R_dec})"),
                        "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
                        "launch": (("one HIP graph per step" if world == 1 else "two HIP graphs per step (fwd+bwd | optimizer), RCCL all-reduce between them")
                                   if tr.graph_mode else "eager launches"),
@@ -196,13 +241,22 @@ def main():
                        "final_loss": float(loss)},
             "padded_frames_per_sec": world * padded_frames / (wall / args.steps),
         }
-        if kt["count"]:
-            avg_ms = kt["ms"] / kt["count"]
-            tf = flops_launch / (avg_ms * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                                "kernel": "gt_conv_gemm_kernel<128,true> (WN in_layer k=5 conv + gate, 48 launches/step)",
-                                "algorithmic_flops_per_launch": flops_launch, "launch_ms": avg_ms, "launches_timed": kt["count"]}
+        avg_ms, rows_launched = gate_conv_leg(dev, model, lh, wl["T_y"], model.decoder.flows[2].wn.p_dropout)
+        tf = flops_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None                               # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gate_conv_pmc.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                            "traffic_source": "profiles/r01_gate_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                                              "FETCH_SIZE x2 per the gfx950 correction; tools/gate_conv_pmc.py)",
+                            "kernel": "gt_conv_gemm_kernel<128,true> (WN in_layer k=5 conv + gate, 48 launches/step)",
+                            "algorithmic_flops_per_launch": flops_launch, "launch_ms": avg_ms,
+                            "how": "20 launches on the step's shapes and weights captured in one HIP graph, HIP events around 20 replays",
+                            "rows_per_launch": rows_launched,
+                            "launch_ms_eager_in_step": (kt["ms"] / kt["count"]) if kt["count"] else None}
         m = mas_leg(dev, wl, rank)
         line["mas"] = {"metric": "mas_alignments_per_sec", "value": world * m["alignments_per_sec"], "unit": "alignments/s",
                        "ms_per_batch": m["ms_per_batch"],

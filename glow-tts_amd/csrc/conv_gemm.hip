@@ -54,7 +54,14 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wm = wave / WN;
   const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the column tiles
+  // that share one activation row tile are given to ONE XCD (row tile rt lives on XCD rt % 8) — otherwise every
+  // activation tile is pulled from HBM/MALL into N/BN different L2s (measured: FETCH_SIZE 4x the algorithmic bytes).
+  const int nct = a.Np / BN, nrt = (a.R + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rt = xcd + 8 * (slot / nct), ct = slot - (slot / nct) * nct;
+  if (rt >= nrt) return;
+  const int n0 = ct * BN, m0 = rt * BM;
   const int taps = a.taps, padl = taps >> 1;
   const int NS = a.Kp / BK, NIT = NS * taps;
   const int xrows = BM + taps - 1;
@@ -277,13 +284,13 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if (gate == 1) {
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
     if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 128)), block, 0, st, a);
   } else if (Np % 128 == 0) {
     if (Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, false>), dim3(Np / 128, (R + BM - 1) / BM), block, 0, st, a);
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, false>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 128)), block, 0, st, a);
   } else {
     if (Np % 64 || Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<64, false>), dim3(Np / 64, (R + BM - 1) / BM), block, 0, st, a);
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<64, false>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 64)), block, 0, st, a);
   }
   return gt_launch_status(__func__);
 }
