@@ -71,7 +71,7 @@ PROTOTYPES = {
     "gt_prior_expand_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_mle_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gt_mle_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "gt_pack_conv_weights_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "gt_pack_conv_weights_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_pack_conv_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }

@@ -28,16 +28,19 @@
 namespace {
 using gtconv::ConvArgs;
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int LDP = 72;                       // halfs per LDS row (64 + 8 pad)
 constexpr int MAXTAPS = 5;
-constexpr int XROWS = BM + MAXTAPS - 1;
 
 
-template <int BN, bool GATE>
-__global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
+// BM x BN tile: 128 x {128|64} (2 workgroups per CU), or 256 x 64 (1 per CU): the weight tile is re-streamed from L2
+// once per ROW tile, so for a wide-N, many-tap conv (in_layer: 737 KB of weights) the tall tile halves the L2->LDS
+// fill traffic per output (295 -> 221 KB per 16 K outputs) at the same accumulator count per wave.
+template <int BM, int BN, bool GATE>
+__global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(ConvArgs a)
 {
+  constexpr int XROWS = BM + MAXTAPS - 1;
+  constexpr int XCH = (XROWS * 8 + 255) / 256;                      // activation 16-B chunks per thread per slice (5 or 9)
   constexpr int WN = BN / 64;                 // waves along channels
   constexpr int WM = 4 / WN;                  // waves along rows
   constexpr int MB = BM / (32 * WM);          // 32-row MFMA blocks per wave
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
 
   // staging registers as named scalars (arrays that live across the conditional prefetch end up
   // in scratch memory)
-  uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, x0 = {}, x1 = {}, x2 = {}, x3 = {}, x4 = {};
+  uint4 w0 = {}, w1 = {}, w2 = {}, w3 = {}, x0 = {}, x1 = {}, x2 = {}, x3 = {}, x4 = {}, x5 = {}, x6 = {}, x7 = {}, x8 = {};
   auto ldw1 = [&](int it, int i) -> uint4 {
     const int slice = it / taps, tap = it - slice * taps;
     const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
@@ -93,8 +96,10 @@ __global__ __launch_bounds__(256, 2) void gt_conv_gemm_kernel(ConvArgs a)
   };
 #define load_W(it)  do { w0 = ldw1(it, 0); w1 = ldw1(it, 1); if (WCH > 2) { w2 = ldw1(it, 2); w3 = ldw1(it, 3); } } while (0)
 #define store_W(bf) do { stw1(bf, 0, w0); stw1(bf, 1, w1); if (WCH > 2) { stw1(bf, 2, w2); stw1(bf, 3, w3); } } while (0)
-#define load_X(sl)  do { x0 = ldx1(sl, 0); x1 = ldx1(sl, 1); x2 = ldx1(sl, 2); x3 = ldx1(sl, 3); x4 = ldx1(sl, 4); } while (0)
-#define store_X(bf) do { stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); stx1(bf, 3, x3); stx1(bf, 4, x4); } while (0)
+#define load_X(sl)  do { x0 = ldx1(sl, 0); x1 = ldx1(sl, 1); x2 = ldx1(sl, 2); x3 = ldx1(sl, 3); x4 = ldx1(sl, 4); \
+                          if (XCH > 5) { x5 = ldx1(sl, 5); x6 = ldx1(sl, 6); x7 = ldx1(sl, 7); x8 = ldx1(sl, 8); } } while (0)
+#define store_X(bf) do { stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); stx1(bf, 3, x3); stx1(bf, 4, x4); \
+                          if (XCH > 5) { stx1(bf, 5, x5); stx1(bf, 6, x6); stx1(bf, 7, x7); stx1(bf, 8, x8); } } while (0)
 
   f32x16_t acc[2][MB];
 #pragma unroll
@@ -221,6 +226,84 @@ __device__ __forceinline__ void pack_one_row(
   }
 }
 
+// Same packing, 8 output channels per workgroup (Cout % 8 == 0, Cin % 8 == 0, Cin*taps <= PK8_MAXN): the scaled bf16
+// rows are staged in LDS so that BOTH images leave as 16-byte stores — 8 consecutive input channels of one row for
+// the forward image, 8 consecutive output channels of one (tap, ci) for the data-gradient image (one workgroup per
+// row writes that image as scattered 2-byte stores: 0.8 TB/s).
+constexpr int PK8_MAXN = 2304;
+__device__ __forceinline__ size_t pk_index(bool frag, int t, int nrow, int k, int Np, int Kp)
+{
+  return frag ? ((((size_t)t * (Np >> 5) + (nrow >> 5)) * (Kp >> 4) + (k >> 4)) * 64 + (nrow & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7)
+              : ((size_t)t * Np + nrow) * Kp + k;
+}
+__device__ __forceinline__ void pack_rows8(
+    const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
+    float* __restrict__ inv_norm, int co0, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate,
+    bf16_t* tile, float* scl)
+{
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = Cin * taps;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {                                   // wave w: rows 2w, 2w+1
+    const int rr = 2 * w + k, co = co0 + rr;
+    float sc = 1.0f;
+    if (g) {
+      const float* vr = v + (size_t)co * n;
+      float ss = 0.f;
+      for (int i = lane; i < n; i += 64) { const float x = vr[i]; ss += x * x; }
+      ss = wave_sum(ss);
+      const float inv = 1.0f / sqrtf(ss);
+      if (lane == 0 && inv_norm) inv_norm[co] = inv;
+      sc = g[co] * inv;
+    }
+    if (lane == 0) scl[rr] = sc;
+  }
+  __syncthreads();
+  for (int rr = 0; rr < 8; ++rr) {
+    const float* vr = v + (size_t)(co0 + rr) * n;
+    const float sc = scl[rr];
+    for (int i = tid; i < n; i += 256) tile[rr * n + i] = f2bf(vr[i] * sc);
+  }
+  __syncthreads();
+  const bool ffrag = gate & 2, dfrag = gate & 4;
+  const int C8 = Cin >> 3;
+  if (Pf) {
+    for (int q = tid; q < 8 * taps * C8; q += 256) {
+      const int rr = q / (taps * C8), rem = q - rr * (taps * C8), tap = rem / C8, c8 = rem - tap * C8;
+      const int co = co0 + rr;
+      int pn = co;
+      if (gate & 1) { const int half = Cout >> 1, c = co < half ? co : co - half; pn = (c >> 5) * 64 + (co < half ? 0 : 32) + (c & 31); }
+      const bf16_t* t = tile + rr * n + (c8 * 8) * taps + tap;
+      uint32_t u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = (uint32_t)t[(2 * j) * taps] | ((uint32_t)t[(2 * j + 1) * taps] << 16);
+      *reinterpret_cast<uint4*>(Pf + pk_index(ffrag, tap, pn, c8 * 8, Npf, Kpf)) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+  }
+  if (Pd) {
+    for (int q = tid; q < taps * Cin; q += 256) {
+      const int tap = q / Cin, ci = q - tap * Cin;
+      const bf16_t* t = tile + ci * taps + tap;
+      uint32_t u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = (uint32_t)t[(2 * j) * n] | ((uint32_t)t[(2 * j + 1) * n] << 16);
+      *reinterpret_cast<uint4*>(Pd + pk_index(dfrag, taps - 1 - tap, ci, co0, Npd, Kpd)) = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gt_pack_conv_weights_multi8_kernel(const gt_pack_desc* __restrict__ descs, int n)
+{
+  __shared__ __attribute__((aligned(16))) bf16_t tile[8 * PK8_MAXN];
+  __shared__ float scl[8];
+  int lo = 0, hi = n - 1;
+  const int row = blockIdx.x * 8;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].row_start <= row) lo = mid; else hi = mid - 1; }
+  const gt_pack_desc d = descs[lo];
+  pack_rows8(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, row - d.row_start,
+             d.Cout, d.Cin, d.taps, d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, tile, scl);
+}
+
 __global__ __launch_bounds__(256) void gt_pack_conv_weights_kernel(
     const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
     float* __restrict__ inv_norm, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate)
@@ -284,13 +367,19 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if (gate == 1) {
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
     if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, true>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 128)), block, 0, st, a);
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("GT_CONV_BM256"); tall = e ? atoi(e) : 0; }      // measured: no gain on cfg2 (the loop is not fill-bound), kept for experiments
+    const int wgs256 = ((R + 255) / 256) * (Np / 64);
+    if (tall && wgs256 >= 150 && wgs256 <= 300)
+      hipLaunchKernelGGL((gt_conv_gemm_kernel<256, 64, true>), dim3(8 * (((R + 255) / 256 + 7) / 8) * (Np / 64)), block, 0, st, a);
+    else
+      hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, true>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 128)), block, 0, st, a);
   } else if (Np % 128 == 0) {
     if (Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, false>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 128)), block, 0, st, a);
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, false>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 128)), block, 0, st, a);
   } else {
     if (Np % 64 || Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<64, false>), dim3(8 * (((R + BM - 1) / BM + 7) / 8) * (Np / 64)), block, 0, st, a);
+    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 64, false>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 64)), block, 0, st, a);
   }
   return gt_launch_status(__func__);
 }
@@ -310,9 +399,15 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
   return gt_launch_status(__func__);
 }
 
-extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, void* stream)
+extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, int group8, void* stream)
 {
   if (!descs_device || n_convs <= 0 || total_rows <= 0) return GT_E_INVAL;
+  if (group8) {
+    if (total_rows & 7) return GT_E_INVAL;
+    hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel, dim3(total_rows / 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const gt_pack_desc*>(descs_device), n_convs);
+    return gt_launch_status(__func__);
+  }
   hipLaunchKernelGGL(gt_pack_conv_weights_multi_kernel, dim3(total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
                      static_cast<const gt_pack_desc*>(descs_device), n_convs);
   return gt_launch_status(__func__);

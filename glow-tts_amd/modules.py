@@ -114,6 +114,8 @@ class _PackPlan:
         entries = []                                     # (v, g, PackedConv)
         for m in module.modules():
             if isinstance(m, ConvP):
+                if getattr(m, "no_pack", False):
+                    continue
                 m._ensure_pcs()
                 entries += m._pack_entries()
             elif hasattr(m, "_pack_entries_extra"):
@@ -134,6 +136,8 @@ class _PackPlan:
             d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, pc.flags, row
             row += pc.Cout
         self.rows = row
+        # 8 output channels per workgroup (coalesced 16-byte stores of both images) when every conv allows it
+        self.group8 = int(all(pc.Cout % 8 == 0 and pc.Cin % 8 == 0 and pc.Cin * pc.taps <= 2304 for _, _, pc in entries))
         dev = entries[0][0].device
         raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self.table = raw.to(dev)
@@ -142,7 +146,7 @@ class _PackPlan:
         if self.n == 0:
             return
         dev = self.keep[0][0].device
-        _lib.check(_lib.lib().gt_pack_conv_weights_multi(_lib.ptr(self.table), self.n, self.rows, _lib.current_stream(dev)),
+        _lib.check(_lib.lib().gt_pack_conv_weights_multi(_lib.ptr(self.table), self.n, self.rows, self.group8, _lib.current_stream(dev)),
                    "gt_pack_conv_weights_multi")
 
 

@@ -52,6 +52,7 @@ class DurationPredictor(nn.Module):
         self.conv_2 = ConvP(filter_channels, filter_channels, kernel_size)
         self.norm_2 = LayerNorm(filter_channels)
         self.proj = ConvP(filter_channels, 1, 1)
+        self.proj.no_pack = True                      # runs through proj_pad (8 output channels); parameters only
         self.proj_pad = _PaddedConv(self.proj)
 
     def _refresh_padded(self):

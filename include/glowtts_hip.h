@@ -152,12 +152,14 @@ int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* p
                          int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
 
 /* The same for every conv of a model in ONE launch: `descs_device` is a device array of n_convs
- * descriptors sorted by row_start (row_start = prefix sum of Cout), total_rows = sum of Cout. */
+ * descriptors sorted by row_start (row_start = prefix sum of Cout), total_rows = sum of Cout.  group8 != 0: every conv has
+ * Cout % 8 == 0, Cin % 8 == 0 and Cin*taps <= 2304 — 8 output channels per workgroup, both images written with 16-byte
+ * stores (else one workgroup per output channel). */
 typedef struct gt_pack_desc {
   const float* v; const float* g; void* pack_fwd; void* pack_dgrad; float* inv_norm;
   int32_t Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate, row_start, pad_;
 } gt_pack_desc;
-int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, void* stream);
+int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, int group8, void* stream);
 
 /* Weight gradient of the rows-layout convolution: partial sums over S row slabs into
  * workspace [S][taps][Cout][Cin] fp32 (S from gt_conv_wgrad_workspace_bytes), bf16 MFMA with
