@@ -219,7 +219,7 @@ class Trainer:
         self._captured = {}                       # (text rows, mel rows) -> (graphs, static inputs, outputs, row contexts)
         from . import ops
         ops.RAGGED = os.environ.get("GT_RAGGED", "1") != "0"
-        ops.ROW_ROUND = 512 if self.graph_mode else 128
+        self.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
 
     def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None):
         from . import ops
@@ -298,6 +298,7 @@ class Trainer:
 
     def step(self, ids, t_x, y, t_y, lengths_host=None):
         from . import ops
+        ops.ROW_ROUND = self.row_round
         if self.total_steps:
             self.opt.set_schedule(*one_cycle(self.n_steps, self.total_steps, self.max_lr))
         self.n_steps += 1

@@ -86,3 +86,35 @@ def test_graph_step_matches_eager_step(built):
     assert math.isfinite(l1.item()) and abs(l2.item() - l3.item()) <= 2e-2 * max(1.0, abs(l3.item())), (l2.item(), l3.item())
     worst = max((a - b).abs().max().item() for a, b in zip(m2.parameters(), m3.parameters()))
     assert worst < 5e-3, worst
+
+
+def test_graph_replay_follows_new_batches_of_the_same_row_bucket(built):
+    """Ragged rows under graphs: ONE captured graph serves different batches whose rounded row counts agree — a replay
+    only refreshes the row offsets / masks.  Same updates as the eager trainer on the same batch sequence."""
+    from glow_tts_amd import ops, train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    bA, bB = train.synth_batch(4, 40, 120, 0, dev()), train.synth_batch(4, 40, 120, 7, dev())
+    assert bA[1].tolist() != bB[1].tolist() and bA[3].tolist() != bB[3].tolist()
+    te, tg = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+    te.row_round = tg.row_round = 1024                      # both batches fall into one bucket
+    seq = [bA, bA, bA, bA, bB, bA, bB, bB]                 # the graph trainer's first call = 3 warm-ups + 1 replay on bA
+    for b in seq:
+        le, _ = te.step(*b)
+    lg, _ = tg.step(*bA)
+    for b in seq[4:]:
+        lg, _ = tg.step(*b)
+    torch.cuda.synchronize()
+    assert len(tg._captured) == 1
+    assert abs(le.item() - lg.item()) <= 2e-2 * max(1.0, abs(le.item())), (le.item(), lg.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst
