@@ -302,6 +302,13 @@ class FlowGenerator(nn.Module):
                                        sigmoid_scale=sigmoid_scale, gin_channels=gin_channels)
         self._step = 0
 
+    def backward_encoder(self):
+        """Second half of a backward started with defer_encoder_backward=True."""
+        pend = [(src, leaf.grad) for src, leaf in self._deferred if leaf.grad is not None]
+        self._deferred = []
+        if pend:
+            torch.autograd.backward([s for s, _ in pend], [g for _, g in pend])
+
     def prepare(self):
         """Re-pack every conv weight for the MFMA kernels (once per optimizer step)."""
         prepare_all(self)
@@ -316,9 +323,12 @@ class FlowGenerator(nn.Module):
         return y, y_lengths, y_max_length
 
     def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None,
-                lengths_host=None):
+                lengths_host=None, defer_encoder_backward=False):
         """lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (ops.RAGGED) size its buffers
-        without a device sync (the data loader has them); without it they are read back from the device."""
+        without a device sync (the data loader has them); without it they are read back from the device.
+        defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
+        decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
+        data-parallel trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs."""
         assert g is None and emo is None and pitch is None and energy is None and l is None, "cfg 4/5 conditioning: next round"
         self.prepare()
         self._step += 1
@@ -328,6 +338,13 @@ class FlowGenerator(nn.Module):
         else:
             ops._HOST_LENGTHS.clear()
         xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
+        self._deferred = []
+        if defer_encoder_backward:
+            leaf = x_m.detach().requires_grad_(True)
+            self._deferred.append((x_m, leaf)); x_m = leaf
+            if not self.mean_only:
+                leaf = x_logs.detach().requires_grad_(True)
+                self._deferred.append((x_logs, leaf)); x_logs = leaf
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
         z, logdet = self.decoder(y, z_mask, prepared=True)

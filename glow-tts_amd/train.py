@@ -96,12 +96,15 @@ class GradBuckets:
         p, o = self.params[i], self.offsets[i]
         return self.flat[o:o + p.numel()].view_as(p)
 
-    def gather(self):
-        """Make every p.grad the parameter's slice of the flat buffer (copy only what is not there already)."""
+    def gather(self, lo=0, hi=None):
+        """Make p.grad the parameter's slice of the flat buffer for parameters [lo, hi) (copy only what is not there
+        already)."""
         from . import wgrad
         wgrad.join(self.flat.device)             # weight gradients flushed on the side stream land first
         dsts, srcs = [], []
-        for i, p in enumerate(self.params):
+        hi = len(self.params) if hi is None else hi
+        for i in range(lo, hi):
+            p = self.params[i]
             g = p.grad
             self.active[i] = g is not None
             if g is None:
@@ -131,20 +134,30 @@ class GradBuckets:
         self.gather()
         self.allreduce()
 
-    def allreduce(self):
-        if self.world == 1:
+    def allreduce(self, lo=0, hi=None, wait=True):
+        """All-reduce (mean) floats [lo, hi) of the flat buffer in bucket-sized pieces.  GPU: on the communication
+        stream, after everything queued so far on the current stream; wait=False leaves the current stream free to run
+        ahead (the caller overlaps the backward of the remaining parameters) until `wait_comm()`."""
+        hi = self.total if hi is None else hi
+        if self.world == 1 or hi <= lo:
             return
+        pieces = [(max(s, lo), min(e, hi)) for s, e in self.buckets if min(e, hi) > max(s, lo)]
         if self.on_gpu:
             cur = torch.cuda.current_stream()
             self.comm.wait_stream(cur)
             with torch.cuda.stream(self.comm):
-                for s, e in self.buckets:
+                for s, e in pieces:
                     dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG)       # RCCL over xGMI
-            cur.wait_stream(self.comm)
+            if wait:
+                cur.wait_stream(self.comm)
         else:                                                                   # gloo (CPU tests): SUM then scale
-            for s, e in self.buckets:
+            for s, e in pieces:
                 dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM)
-            self.flat.mul_(1.0 / self.world)
+                self.flat[s:e].mul_(1.0 / self.world)
+
+    def wait_comm(self):
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
 
 
 class FlatAdamW:
@@ -192,9 +205,11 @@ class Trainer:
     graph=True captures the step (forward, MAS, backward, optimizer: ~1 k kernel launches) into HIP graphs after
     three eager warm-up steps and replays them; the batch then lives in static buffers (`step` copies into them)
     and dropout masks still change every replay because every dropout kernel mixes the device-resident seed word
-    (ops.seed_word) that the graph itself bumps.  One process alone: ONE graph.  Data-parallel (world > 1): two
-    graphs — forward/backward/gather and the optimizer — with the RCCL all-reduce of the flat gradient buffer
-    launched between them (collectives stay outside the captured region).
+    (ops.seed_word) that the graph itself bumps.  One process alone: ONE graph.  Data-parallel (world > 1): the
+    backward is phased (everything but the text encoder, then the text encoder) and the step is three graphs —
+    forward + first backward | encoder backward | optimizer — with the RCCL all-reduces of the flat gradient buffer
+    launched between them: the decoder's slice (~90 % of the bytes) is on the wire while the encoder's backward runs
+    (collectives stay outside the captured regions).
 
     Rows layout: ragged (ops.RAGGED, GT_RAGGED=0 turns it off) — every utterance owns exactly its own frames, so the
     ~30 % of padded frames of an LJSpeech-shaped batch cost nothing.  The row count is rounded (128 eager, 512 under
@@ -205,12 +220,18 @@ class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
-        None keeps lr / betas constant.  split_graph forces the two-graph form (default: world > 1)."""
+        None keeps lr / betas constant.  split_graph forces the phased, several-graph form (default: world > 1)."""
         self.model = model
         self.world = world
         self.graph_mode = bool(graph)
         self.split = (world > 1) if split_graph is None else bool(split_graph)
         self.buckets = GradBuckets(list(model.parameters()), world)
+        # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
+        # first backward call and travel over xGMI while the text encoder's backward runs
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        self.dec0 = next((i for i, n in enumerate(names) if n.startswith("decoder.")), len(names))
+        assert all(n.startswith("decoder.") for n in names[self.dec0:]), "decoder parameters must be the tail of the model"
+        self.dec0_off = self.buckets.offsets[self.dec0] if self.dec0 < len(names) else self.buckets.total
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
         from . import wgrad
         wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "1") != "0"      # weight-gradient batches on a side stream
@@ -242,9 +263,35 @@ class Trainer:
         self.grad_norm = torch.sqrt(self.opt.step())
         ops.arena_end(device)
 
+    def _phase1(self, ids, t_x, y, t_y, lengths_host=None):
+        """forward + the backward of everything but the text encoder; the decoder's gradients are then in the flat buffer."""
+        from . import ops
+        m = self.model
+        ops.bump_seed(ids.device)
+        ops.arena_begin(ids.device)
+        for p in self.buckets.params:
+            p.grad = None
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host,
+                                                                           defer_encoder_backward=True)
+        l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
+        loss = l_mle + torch.sum(l_length)
+        loss.backward()
+        self.buckets.gather(self.dec0, None)
+        return loss.detach(), l_mle.detach()
+
+    def _phase2(self):
+        self.model.backward_encoder()
+        self.buckets.gather(0, self.dec0)
+
     def _step_impl(self, ids, t_x, y, t_y, lengths_host=None):
-        out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host)
-        self.buckets.allreduce()
+        if not self.split:
+            out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host)
+            self.buckets.allreduce()
+        else:
+            out = self._phase1(ids, t_x, y, t_y, lengths_host)
+            self.buckets.allreduce(self.dec0_off, None, wait=False)      # on the wire while the encoder's backward runs
+            self._phase2()
+            self.buckets.allreduce(0, self.dec0_off, wait=True)
         self._optim(ids.device)
         return out
 
@@ -281,11 +328,14 @@ class Trainer:
             graphs = (g1,)
         else:
             with torch.cuda.graph(g1, stream=side):
-                out = self._fwd_bwd(*static, lengths_host=lh)
+                out = self._phase1(*static, lengths_host=lh)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, stream=side, pool=g1.pool()):
+                self._phase2()
+            g3 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g3, stream=side, pool=g1.pool()):
                 self._optim(ids.device)
-            graphs = (g1, g2)
+            graphs = (g1, g2, g3)
         return graphs, static, out, ctxs
 
     def _rows_key(self, ids, y, lh):
@@ -325,7 +375,9 @@ class Trainer:
             ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
             assert ok, "row count of the batch does not match the captured graph"
         graphs[0].replay()
-        if len(graphs) > 1:
-            self.buckets.allreduce()                 # RCCL all-reduce of the flat gradient buffer, between the graphs
+        if len(graphs) > 1:                          # collectives sit BETWEEN the graphs, never inside one
+            self.buckets.allreduce(self.dec0_off, None, wait=False)      # decoder slice: overlaps the encoder's backward
             graphs[1].replay()
+            self.buckets.allreduce(0, self.dec0_off, wait=True)
+            graphs[2].replay()
         return out
