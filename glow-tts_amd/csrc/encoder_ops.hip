@@ -80,10 +80,10 @@ struct LnBwdArgs {
   int rows_per_block;
 };
 
-// 8 waves, one row per wave at a time; gamma/beta partials are folded in LDS so that each channel gets ONE
-// atomic per workgroup (same-address float atomics serialise at L2, ~50 ns each: 32 rows per workgroup keeps both
+// 16 waves, one row per wave at a time; gamma/beta partials are folded in LDS so that each channel gets ONE
+// atomic per workgroup (same-address float atomics serialise at L2, ~50 ns each: 64 rows per workgroup keeps both
 // the atomic chain and the per-wave row loop short).
-constexpr int LNB_WAVES = 8;
+constexpr int LNB_WAVES = 16;
 __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdArgs q)
 {
   if (q.f.seed_dev) { const uint32_t x = *q.f.seed_dev; q.f.din_seed ^= x; q.f.dout_seed ^= x; }
@@ -573,8 +573,8 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
-  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 32;
-  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 31) / 32), dim3(64 * LNB_WAVES), 0, GT_ST(stream), q);
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 64;
+  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 63) / 64), dim3(64 * LNB_WAVES), 0, GT_ST(stream), q);
   GT_RET();
 }
 
