@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_q_kernel(
     if (i >= T) break;
     float* qv = Qs + ii * 2 * D; float* dov = qv + D;
     float* pv = Ps + (size_t)ii * T;
-    for (int c = lane; c < D; c += 64) { qv[c] = bf2f(q[RW(i) * ld + h * D + c]); dov[c] = bf2f(dout[(rbase + i) * lddo + h * D + c]); }
+    for (int c = lane; c < D; c += 64) { qv[c] = bf2f(q[RW(i) * ld + h * D + c]); dov[c] = bf2f(dout[RW(i) * lddo + h * D + c]); }
     __builtin_amdgcn_wave_barrier();
     const float* prow = P + (((size_t)b * H + h) * T + i) * T;
     // dPd_j = dO.V_j + [band] dO.Ev[rel];  dP_j = dropout'(dPd_j);  Dsum = sum_j dP_j P_j

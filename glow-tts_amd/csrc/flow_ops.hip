@@ -111,6 +111,35 @@ __global__ __launch_bounds__(256) void gt_actnorm_invconv_fwd_kernel(
   if (y0_bf16) *reinterpret_cast<uint32_t*>(y0_bf16 + (size_t)m * ld0 + 2 * g) = pack2bf(o[0], o[1]);
 }
 
+// reverse (inference): InvConvNear^-1 then ActNorm^-1 (modules.py:647-652, 592-594):
+//   x = ((W^-1 y) * mask - bias) * exp(-logs) * mask;   W^-1[k][j] = scal[2 + 4 j + k]  (scal holds W^-T row major)
+__global__ __launch_bounds__(256) void gt_actnorm_invconv_rev_kernel(
+    const float* __restrict__ y, float* __restrict__ x, bf16_t* __restrict__ x0_bf16, int ld0,
+    const float* __restrict__ logs, const float* __restrict__ bias, const float* __restrict__ scal,
+    const float* __restrict__ rowmask, int R, int C)
+{
+  const int G = C >> 2, half = C >> 1;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * G) return;
+  const int m = idx / G, g = idx - m * G;
+  const float rm = rowmask[m];
+  const float2 ya = *reinterpret_cast<const float2*>(y + (size_t)m * C + 2 * g);
+  const float2 yb = *reinterpret_cast<const float2*>(y + (size_t)m * C + half + 2 * g);
+  const float yv[4] = {ya.x, ya.y, yb.x, yb.y};
+  const int ch[4] = {2 * g, 2 * g + 1, half + 2 * g, half + 2 * g + 1};
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a += scal[2 + 4 * j + k] * yv[j];
+    o[k] = (a * rm - bias[ch[k]]) * __expf(-logs[ch[k]]) * rm;
+  }
+  *reinterpret_cast<float2*>(x + (size_t)m * C + 2 * g) = make_float2(o[0], o[1]);
+  *reinterpret_cast<float2*>(x + (size_t)m * C + half + 2 * g) = make_float2(o[2], o[3]);
+  if (x0_bf16) *reinterpret_cast<uint32_t*>(x0_bf16 + (size_t)m * ld0 + 2 * g) = pack2bf(o[0], o[1]);
+}
+
 // backward: dx = exp(logs) * W^T (dy*mask);  reductions into dlogs[C], dbias[C], dW[16] by atomics.
 __global__ __launch_bounds__(256) void gt_actnorm_invconv_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
@@ -236,6 +265,21 @@ __global__ __launch_bounds__(256) void gt_coupling_fwd_kernel(const float* __res
   if (lane == 0) red[w] = s;
   __syncthreads();
   if (threadIdx.x == 0) { const float tot = red[0] + red[1] + red[2] + red[3]; if (tot != 0.f) atomicAdd(logdet + b, tot); }
+}
+
+// reverse (inference, attentions.py:178-180): x = [z0 | (z1 - m) * exp(-logs) * mask]
+__global__ __launch_bounds__(256) void gt_coupling_rev_kernel(const float* __restrict__ out, const float* __restrict__ z,
+                                                              float* __restrict__ x, const float* __restrict__ rowmask,
+                                                              int R, int C, int sigmoid_scale)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x, half = C >> 1;
+  if (idx >= R * half) return;
+  const int m = idx / half, c = idx - m * half;
+  const float mm = out[(size_t)m * C + c];
+  float lg = out[(size_t)m * C + half + c];
+  if (sigmoid_scale) lg = __logf(1e-6f + sigmoidf_(lg + 2.0f));
+  x[(size_t)m * C + c] = z[(size_t)m * C + c];
+  x[(size_t)m * C + half + c] = (z[(size_t)m * C + half + c] - mm) * __expf(-lg) * rowmask[m];
 }
 
 // backward: dz -> dx (x0 part passed through, the start-conv contribution is added later),
@@ -383,6 +427,23 @@ extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx
     if (!scal || !len) return GT_E_INVAL;
     hipLaunchKernelGGL(gt_flow_logdet_bwd_kernel, dim3(1), dim3(256), 0, GT_ST(stream), scal, len, dlogdet, dlogs, dW, B, C);
   }
+  GT_RET();
+}
+extern "C" int gt_actnorm_invconv_rev(const float* y, float* x, void* x0_bf16, int ld0, const float* logs, const float* bias,
+                                      const float* scal, const float* rowmask, int R, int C, void* stream)
+{
+  if (!y || !x || !logs || !bias || !scal || !rowmask || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
+  const int G = C >> 2;
+  hipLaunchKernelGGL(gt_actnorm_invconv_rev_kernel, dim3((R * G + 255) / 256), dim3(256), 0, GT_ST(stream),
+                     y, x, static_cast<bf16_t*>(x0_bf16), ld0, logs, bias, scal, rowmask, R, C);
+  GT_RET();
+}
+extern "C" int gt_coupling_rev(const float* out, const float* z, float* x, const float* rowmask, int R, int C,
+                               int sigmoid_scale, void* stream)
+{
+  if (!out || !z || !x || !rowmask || R <= 0 || (C & 1)) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_coupling_rev_kernel, dim3((R * (C / 2) + 255) / 256), dim3(256), 0, GT_ST(stream),
+                     out, z, x, rowmask, R, C, sigmoid_scale);
   GT_RET();
 }
 extern "C" int gt_coupling_fwd(const float* out, const float* x, float* z, const float* rowmask, float* logdet,

@@ -214,3 +214,36 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
     dx0 = conv_rows(dh0, cb.start.pc, rc, dgrad=True)
     _lib.check(L.gt_rows_add_bf16(_lib.ptr(dx), C, _lib.ptr(dx0), dx0.stride(0), R, C // 2, _st(dev)), "gt_rows_add_bf16")
     return dx, grads, dcond
+
+
+# ----------------------------------------------------------------------------- reverse flow (inference)
+def actnorm_invconv_rev(rc, y, logs, bias, W, want_x0=True):
+    """InvConvNear^-1 then ActNorm^-1 on rows (modules.py:647-652, 592-594).  y: [R,C] fp32 -> x, bf16(x[:, :C/2])."""
+    L = _lib.lib()
+    dev = y.device
+    R, C = y.shape
+    x = torch.empty_like(y)
+    x0 = torch.empty(R, C // 2, dtype=torch.bfloat16, device=dev) if want_x0 else None
+    scal = torch.empty(18, dtype=torch.float32, device=dev)
+    lg = logs.detach().reshape(-1).contiguous()
+    bs = bias.detach().reshape(-1).contiguous()
+    Wc = W.detach().contiguous()
+    _lib.check(L.gt_flow_scalars(_lib.ptr(lg), C, _lib.ptr(Wc), _lib.ptr(scal), _st(dev)), "gt_flow_scalars")
+    _lib.check(L.gt_actnorm_invconv_rev(_lib.ptr(y), _lib.ptr(x), _lib.ptr(x0), C // 2, _lib.ptr(lg), _lib.ptr(bs), _lib.ptr(scal),
+                                        _lib.ptr(rc.rowmask), R, C, _st(dev)), "gt_actnorm_invconv_rev")
+    return x, x0
+
+
+def coupling_rev(rc, cb, z, z0_bf16, cond):
+    """attentions.CouplingBlock.forward with reverse=True on rows: the same start / WN / end GEMMs as the forward
+    (evaluation mode), then x1 = (z1 - m) * exp(-logs) * mask."""
+    L = _lib.lib()
+    dev = z.device
+    R, C = z.shape
+    h0 = conv_rows(z0_bf16, cb.start.pc, rc, bias=cb.start.bias, mask=True)
+    wn_out, _ = wn_fwd(rc, cb.wn, h0, cond, False, 0)
+    out = conv_rows(wn_out, cb.end.pc, rc, bias=cb.end.bias, out_f32=True)
+    x = torch.empty_like(z)
+    _lib.check(L.gt_coupling_rev(_lib.ptr(out), _lib.ptr(z), _lib.ptr(x), _lib.ptr(rc.rowmask), R, C, int(cb.sigmoid_scale),
+                                 _st(dev)), "gt_coupling_rev")
+    return x

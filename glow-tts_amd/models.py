@@ -42,12 +42,14 @@ class FlowSpecDecoder(nn.Module):
     def forward(self, x, x_mask, g=None, emo=None, pitch=None, energy=None, reverse=False, prepared=False):
         """x: [b, 80, t] (t even after the caller's preprocess, models.py:1248-1253; an odd trailing
         frame is dropped like commons.squeeze does), x_mask: [b, 1, t].  Returns (z, logdet_tot)."""
-        if reverse:
-            raise NotImplementedError("reverse flow (inference) is out of the training hot-path scope (SURVEY §8 f3)")
         if pitch is not None or energy is not None:
             raise NotImplementedError("pitch/energy conditioning (cfg 5) is out of the round-1 scope")
         if not prepared:
             prepare_all(self)
+        if reverse:                                  # inference direction (models.py:769-770,781-782): no log-det, no autograd
+            with torch.no_grad():
+                conds = [None] * self.n_blocks if g is None else [_wn_cond(self.flows[3 * b + 2].wn, g) for b in range(self.n_blocks)]
+                return _DecoderRunner(self, x_mask, g is not None, False, 0).reverse(x.detach(), conds), None
         self._step += 1
         runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed=(self._step * 7919) & 0x7fffffff)
         conds = []
@@ -88,6 +90,29 @@ class _DecoderRunner:
         z = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
         _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(z), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
         return (z.to(x.dtype), logdet), (rc, saved, (B, C, T))
+
+    def reverse(self, z, conds):
+        """z [B, C, T] -> x: flows in reverse order (coupling^-1, InvConvNear^-1, ActNorm^-1 per block)."""
+        L = _lib.lib()
+        dec = self.dec
+        B, C, T = z.shape
+        dev = z.device
+        T2 = T // 2
+        len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)
+        rc = ops.make_ctx(len_sq, T2, "y", div=2)
+        zin = z.float().contiguous()
+        cur = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
+        st = _lib.current_stream(dev)
+        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(zin), _lib.ptr(cur), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
+        x0 = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
+        _lib.check(L.gt_rows_f32_to_bf16(_lib.ptr(cur), 2 * C, _lib.ptr(x0), C, None, rc.R, C, st), "gt_rows_f32_to_bf16")
+        for b in reversed(range(dec.n_blocks)):
+            an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+            cur = flow_impl.coupling_rev(rc, cb, cur, x0, conds[b])
+            cur, x0 = flow_impl.actnorm_invconv_rev(rc, cur, an.logs, an.bias, ic.weight, want_x0=b > 0)
+        x = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
+        _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(x), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
+        return x.to(z.dtype)
 
     def backward(self, saved_all, dz, dlogdet):
         L = _lib.lib()

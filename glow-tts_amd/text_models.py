@@ -302,6 +302,51 @@ class FlowGenerator(nn.Module):
                                        sigmoid_scale=sigmoid_scale, gin_channels=gin_channels)
         self._step = 0
 
+    @torch.no_grad()
+    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0):
+        """Synthesis (reference FlowGenerator.infer, models.py:1122-1232, on the live sub-graph: no speaker / emotion /
+        pitch / energy inputs): text -> durations -> expanded prior -> z = z_m + noise -> decoder(reverse=True) -> mel.
+        Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)).  The output length is data
+        dependent, so this reads the predicted lengths back from the device once."""
+        self.prepare()
+        ops._HOST_LENGTHS.clear()
+        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
+        rc, xb = self.encoder._last_rows
+        runner = _DurationRunner(self.encoder.proj_w, rc, xb, False, 0)
+        (logw,), _ = runner.forward()
+        w = torch.exp(logw) * x_mask * length_scale
+        w_ceil = torch.ceil(w)
+        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        Ty = int(y_lengths.max().item())
+        z_mask = (torch.arange(Ty, device=x.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
+        # commons.generate_path (commons.py:127-143): token i owns frames [cum_i - d_i, cum_i)
+        dur = w_ceil.squeeze(1)
+        cum = torch.cumsum(dur, 1)
+        j = torch.arange(Ty, device=x.device, dtype=dur.dtype)
+        attn = ((j[None, None, :] < cum[:, :, None]) & (j[None, None, :] >= (cum - dur)[:, :, None])).to(x_mask.dtype)
+        attn = (attn * x_mask.transpose(1, 2) * z_mask).unsqueeze(1)
+        frame2token = torch.searchsorted(cum.contiguous(), j[None, :].expand(cum.shape[0], Ty).contiguous(), right=True)
+        frame2token = frame2token.clamp_(max=dur.shape[1] - 1).to(torch.int32)
+        L = _lib.lib()
+        B, C, Tx = x_m.shape
+        xm = x_m.float().contiguous()
+        z_m = torch.empty(B, C, Ty, dtype=torch.float32, device=x.device)
+        _lib.check(L.gt_prior_expand(_lib.ptr(xm), _lib.ptr(frame2token), _lib.ptr(z_m), B, C, Tx, Ty, _lib.current_stream(x.device)),
+                   "gt_prior_expand")
+        z_m = z_m * z_mask
+        if self.mean_only:
+            z_logs = torch.zeros_like(z_m)
+        else:
+            xs = x_logs.float().contiguous()
+            z_logs = torch.empty_like(z_m)
+            _lib.check(L.gt_prior_expand(_lib.ptr(xs), _lib.ptr(frame2token), _lib.ptr(z_logs), B, C, Tx, Ty, _lib.current_stream(x.device)),
+                       "gt_prior_expand")
+            z_logs = z_logs * z_mask
+        logw_ = torch.log(1e-8 + torch.sum(attn.squeeze(1), -1)).unsqueeze(1) * x_mask
+        z = (z_m + torch.exp(z_logs) * torch.randn_like(z_m) * noise_scale) * z_mask
+        y, logdet = self.decoder(z, z_mask, reverse=True, prepared=True)
+        return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
+
     def backward_encoder(self):
         """Second half of a backward started with defer_encoder_backward=True."""
         pend = [(src, leaf.grad) for src, leaf in self._deferred if leaf.grad is not None]

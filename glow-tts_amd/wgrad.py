@@ -35,7 +35,7 @@ ASYNC = False
 _SIDE = {}
 _PENDING = set()
 _ACTIVE = []            # stack of open queues
-_KEEP = []              # host tables referenced by captured graphs
+_KEEP = []              # tables referenced by captured graphs whose queue had no owning module (site)
 _SCRATCH = {}
 
 
@@ -168,6 +168,19 @@ class WgradQueue:
         else:
             self._flush()
 
+    def _keep(self, obj):
+        """Whatever a captured graph reads (pinned staging, device tables from the graph's private pool) must outlive
+        the graph — but not the interpreter: hang it on the module that owns the queue, so it dies with the model
+        instead of at interpreter shutdown (device memory of a graph pool freed after the allocator is gone aborts)."""
+        if self.site is not None:
+            lst = getattr(self.site, "_wgrad_keep", None)
+            if lst is None:
+                lst = []
+                object.__setattr__(self.site, "_wgrad_keep", lst)
+            lst.append(obj)
+        else:
+            _KEEP.append(obj)
+
     def _flush(self):
         L = _lib.lib()
         dev = self.dev
@@ -186,7 +199,7 @@ class WgradQueue:
                                        "(run one eager step first)")
                 host = _POOL.pop()[: raw.size]
                 host.numpy()[:] = raw
-                _KEEP.append(host)
+                self._keep(host)
             else:
                 host = torch.from_numpy(raw).pin_memory()
             return host.to(dev, non_blocking=True)
@@ -229,5 +242,5 @@ class WgradQueue:
                    "gt_conv_wgrad_batched")
         _lib.check(L.gt_weightnorm_bwd_batched(_lib.ptr(cache["wnb"]), len(wnbs), rows, max_n, st), "gt_weightnorm_bwd_batched")
         if capturing:
-            _KEEP.append(cache)
+            self._keep(cache)
         self.items = []

@@ -294,6 +294,15 @@ int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, 
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
                size_t n, void* stream);
 
+/* Reverse (inference) direction of the flows — models.py:765-785 with reverse=True.
+ *   gt_actnorm_invconv_rev: x = ((W^-1 y) * mask - bias) * exp(-logs) * mask  (InvConvNear^-1 then ActNorm^-1,
+ *     modules.py:647-652,592-594); scal from gt_flow_scalars (holds W^-T); x0_bf16 (optional) = bf16(x[:, :C/2]).
+ *   gt_coupling_rev: x = [z0 | (z1 - m) * exp(-logs) * mask] with [m | logs] = out (attentions.py:178-180). */
+int gt_actnorm_invconv_rev(const float* y, float* x, void* x0_bf16, int ld0, const float* logs, const float* bias,
+                           const float* scal, const float* rowmask, int R, int C, void* stream);
+int gt_coupling_rev(const float* out, const float* z, float* x, const float* rowmask, int R, int C,
+                    int sigmoid_scale, void* stream);
+
 /* AdamW over flat fp32 buffers (parameters, gradients, both moments are slices of four buffers of n floats,
  * n % 4 == 0, 16-B aligned) — replaces torch.optim.AdamW.step + commons.clip_grad_value_(params, None)
  * (train_ms_emo_lang_pitch.py:311-312, commons.py:320-336).  hyper (device) = {lr, beta1, beta2, eps,

@@ -150,6 +150,57 @@ def decoder_fwd(P, pre, x, x_mask, g=None, n_blocks=12, n_layers=4, hidden=192, 
     return x, logdet_tot
 
 
+# ----------------------------------------------------------------------------- reverse flow (inference)
+def actnorm_rev(P, pre, x, x_mask):
+    """modules.ActNorm.forward with reverse=True (modules.py:592-594)."""
+    return (x - P[pre + "bias"]) * torch.exp(-P[pre + "logs"]) * x_mask
+
+
+def invconv_rev(P, pre, x, x_mask, n_split=4):
+    """modules.InvConvNear.forward with reverse=True (modules.py:647-652,658-664): the grouped 4x4 mix with W^-1."""
+    W = torch.inverse(P[pre + "weight"].float())
+    b, c, t = x.shape
+    h = n_split // 2
+    xg = x.view(b, 2, c // n_split, h, t).permute(0, 1, 3, 2, 4).reshape(b, n_split, c // n_split, t)
+    zg = torch.einsum("oi,bigt->bogt", W, xg)
+    return zg.view(b, 2, h, c // n_split, t).permute(0, 1, 3, 2, 4).reshape(b, c, t) * x_mask
+
+
+def coupling_rev(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, sigmoid_scale=False):
+    """attentions.CouplingBlock.forward with reverse=True (attentions.py:178-180)."""
+    c = x.shape[1]
+    x0, x1 = x[:, :c // 2], x[:, c // 2:]
+    h = conv1d(P, pre + "start", x0) * x_mask
+    h = wn_fwd(P, pre + "wn.", h, x_mask, g, n_layers, hidden, kernel_size)
+    out = conv1d(P, pre + "end", h)
+    m, logs = out[:, :c // 2], out[:, c // 2:]
+    if sigmoid_scale:
+        logs = torch.log(1e-6 + torch.sigmoid(logs + 2))
+    z1 = (x1 - m) * torch.exp(-logs) * x_mask
+    return torch.cat([x0, z1], 1)
+
+
+def decoder_rev(P, pre, z, z_mask, g=None, n_blocks=12, n_layers=4, hidden=192, kernel_size=5,
+                n_split=4, n_sqz=2, sigmoid_scale=False):
+    """models.FlowSpecDecoder.forward with reverse=True (models.py:765-785): flows in reverse order, no log-det."""
+    x, m = squeeze(z, z_mask, n_sqz)
+    for b in reversed(range(n_blocks)):
+        x = coupling_rev(P, pre + f"flows.{3 * b + 2}.", x, m, g, n_layers, hidden, kernel_size, sigmoid_scale)
+        x = invconv_rev(P, pre + f"flows.{3 * b + 1}.", x, m, n_split)
+        x = actnorm_rev(P, pre + f"flows.{3 * b}.", x, m)
+    x, _ = unsqueeze(x, m, n_sqz)
+    return x
+
+
+def generate_path(duration, mask):
+    """commons.generate_path (commons.py:127-143): token i owns frames [cum_i - d_i, cum_i)."""
+    b, t_x, t_y = mask.shape
+    cum = torch.cumsum(duration, 1)
+    j = torch.arange(t_y, dtype=duration.dtype)[None, None, :]
+    path = ((j < cum[:, :, None]) & (j >= (cum - duration)[:, :, None])).to(mask.dtype)
+    return path * mask
+
+
 # ----------------------------------------------------------------------------- text encoder
 def mha_fwd(P, pre, x, c, attn_mask, n_heads=2, window_size=4):
     """attentions.MultiHeadAttention.forward/attention (attentions.py:231-272), eval mode, restated

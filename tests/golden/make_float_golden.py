@@ -158,6 +158,17 @@ def main():
     mle = commons.mle_loss(zz, z_m, torch.zeros_like(z_m), torch.tensor([1.5, -0.5]), ym[:, :, :24])
     out.update(glue_xm=x_m, glue_z=zz, glue_logp=logp, glue_attn=attn, glue_zm=z_m, glue_mle=mle)
 
+    # ---- reverse flow (models.py:765-785 with reverse=True; attentions.py:178-180; modules.py:592-594,647-652) and
+    # commons.generate_path (commons.py:127-143) — appended last so that every draw above keeps its value
+    zr = rnd(2, 80, 24) * ym[:, :, :24]
+    with torch.no_grad():
+        xr, ldr = dec(zr, ym[:, :, :24], reverse=True)
+    assert ldr is None
+    dur = torch.tensor([[3., 1., 0., 2., 4., 1., 0., 0., 0., 0., 0.], [2., 2., 5., 1., 1., 3., 0., 0., 0., 0., 0.]])
+    gmask = (xm.unsqueeze(-1) * ym[:, :, :24].unsqueeze(2)).squeeze(1)
+    gp = commons.generate_path(dur, gmask)
+    out.update(dec_rev_z=zr, dec_rev_x=xr, genpath_dur=dur, genpath_mask=gmask, genpath_out=gp)
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

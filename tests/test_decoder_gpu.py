@@ -166,3 +166,54 @@ def test_decoder_train_mode_dropout_runs(built):
     assert torch.isfinite(z1).all() and not torch.equal(z1, z2)        # different dropout masks per call
     (z1.sum() + ld1.sum()).backward()
     assert torch.isfinite(y.grad).all()
+
+
+@pytest.mark.parametrize("n_blocks,T,lens", [(2, 48, [48, 26]), (12, 65, [65, 30, 2])])
+def test_decoder_reverse_vs_oracle_and_round_trip(built, n_blocks, T, lens):
+    """Inference direction (models.py:765-785, reverse=True): against the oracle restatement (itself pinned to the
+    imported reference by tests/test_float_oracle.py), and the size-independent property reverse(forward(x)) == x:
+    both directions evaluate the SAME m / logs from the untouched half, so the round trip only carries fp32 rounding."""
+    from glow_tts_amd import models
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, n_blocks, 4, p_dropout=0.05), "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    B = len(lens)
+    m = lens_mask(lens, T)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(B, 80, T, generator=g) * m
+    want = R.decoder_rev(P, "decoder.", z, m, n_blocks=n_blocks)
+    dec = dec.to(dev())
+    x, ld = dec(z.to(dev()), m.to(dev()), reverse=True)
+    assert ld is None and x.shape == want.shape
+    assert relerr(x.cpu(), want) < 3e-2
+    with torch.no_grad():
+        z2, _ = dec(x, m.to(dev())[:, :, :x.shape[2]])
+    T2 = x.shape[2]
+    valid = (m[:, :, :T2] * (torch.arange(T2)[None, None, :] < (torch.tensor(lens) // 2 * 2)[:, None, None])).bool().expand(B, 80, T2)
+    err = (z2.cpu() - z[:, :, :T2])[valid].abs().max().item()
+    # not bit-exact: an fp32 rounding difference in the untouched half can flip ITS bf16 rounding in front of the WN
+    # GEMMs of the next block (measured: 2e-3 after 2 blocks, 9e-3 after 12, on |z| <= 3.8)
+    assert err < 5e-3 * max(1.0, z.abs().max().item()), err
+
+
+def test_infer_generates_mel_through_the_reverse_flow(built):
+    """FlowGenerator.infer: predicted durations -> generate_path (== the oracle's, commons.py:127-143) -> prior expansion
+    -> reverse decoder; with noise_scale = 0 the mel equals the oracle's reverse decoder of the expanded means."""
+    from glow_tts_amd import models
+    gen = fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1,
+                                           n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
+                                           p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True), "").eval()
+    P = cpu_state(gen)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, 148, (2, 19), generator=g); xl = torch.tensor([19, 11])
+    ids = ids * (torch.arange(19)[None, :] < xl[:, None])
+    gen = gen.to(dev())
+    (y, z_m, z_logs, ld, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = gen.infer(ids.to(dev()), xl.to(dev()), noise_scale=0.0)
+    assert ld is None and torch.isfinite(y).all() and z_logs.abs().max().item() == 0
+    dur = torch.ceil(torch.exp(logw) * x_mask).squeeze(1).cpu()
+    assert torch.equal(attn.squeeze(1).sum(-1).cpu(), dur)
+    want_attn = R.generate_path(dur, (x_mask.transpose(1, 2) * z_mask).cpu())
+    assert torch.equal(attn.squeeze(1).cpu(), want_attn)
+    zm_want = torch.matmul(want_attn.transpose(1, 2), x_m.cpu().float().transpose(1, 2)).transpose(1, 2)
+    assert torch.allclose(z_m.cpu(), zm_want, atol=1e-5)
+    y_want = R.decoder_rev(P, "decoder.", zm_want * z_mask.cpu(), z_mask.cpu(), n_blocks=2)
+    assert relerr(y.cpu(), y_want) < 3e-2

@@ -139,3 +139,18 @@ def test_glue_logp_mas_mle(built):
     assert close(z_m, t("glue_zm"))
     mle = R.mle_loss(t("glue_z"), z_m, torch.zeros_like(z_m), torch.tensor([1.5, -0.5]), ym)
     assert close(mle, t("glue_mle"))
+
+
+def test_reverse_flow_and_generate_path_match_reference_golden(built):
+    """Inference direction: FlowSpecDecoder(reverse=True) and commons.generate_path of the imported reference
+    (fixtures appended to float_golden.npz by make_float_golden.py) against the oracle restatement; and the restated
+    reverse undoes the restated forward."""
+    from glow_tts_amd import models
+    P = module_state(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05), "decoder.")
+    z, mask = t("dec_rev_z"), t("dec_mask")
+    x = R.decoder_rev(P, "decoder.", z, mask, n_blocks=2)
+    assert close(x, t("dec_rev_x"), 2e-4), (x - t("dec_rev_x")).abs().max()
+    zz, _ = R.decoder_fwd(P, "decoder.", x, mask, n_blocks=2)
+    assert close(zz, z, 1e-3)
+    gp = R.generate_path(t("genpath_dur"), t("genpath_mask"))
+    assert torch.equal(gp, t("genpath_out"))

@@ -16,10 +16,10 @@ dEk = torch.zeros_like(Ek); dEv = torch.zeros_like(Ev)
 st = _lib.current_stream(dev)
 def fwd():
     assert L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(o), C, _lib.ptr(P),
-                         B, T, rc.Tp, H, D, 4, 0.1, 7, None, st) == 0
+                         B, T, rc.Tp, None, H, D, 4, 0.1, 7, None, st) == 0
 def bwd():
     assert L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(dS), wsb,
-                         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C, _lib.ptr(dEk), _lib.ptr(dEv), B, T, rc.Tp, H, D, 4, 0.1, 7, None, st) == 0
+                         _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C, _lib.ptr(dEk), _lib.ptr(dEv), B, T, rc.Tp, None, H, D, 4, 0.1, 7, None, st) == 0
 def timeit(fn, n=30):
     for _ in range(3): fn()
     torch.cuda.synchronize()
