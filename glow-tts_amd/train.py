@@ -199,6 +199,10 @@ class FlatAdamW:
         return self.gnorm_sq
 
 
+# other threads (the RCCL watchdog of torch.distributed, data loaders) may touch the runtime while this thread captures
+CAPTURE_MODE = "thread_local"
+
+
 class Trainer:
     """zero_grad -> forward -> loss -> backward -> all-reduce -> grad-norm -> AdamW step.
 
@@ -323,17 +327,17 @@ class Trainer:
         # created on, and work they launched on another stream would stay outside the captured graph
         g1 = torch.cuda.CUDAGraph()
         if not self.split:
-            with torch.cuda.graph(g1, stream=side):
+            with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
                 out = self._step_impl(*static, lengths_host=lh)
             graphs = (g1,)
         else:
-            with torch.cuda.graph(g1, stream=side):
+            with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
                 out = self._phase1(*static, lengths_host=lh)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, stream=side, pool=g1.pool()):
+            with torch.cuda.graph(g2, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
                 self._phase2()
             g3 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g3, stream=side, pool=g1.pool()):
+            with torch.cuda.graph(g3, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
                 self._optim(ids.device)
             graphs = (g1, g2, g3)
         return graphs, static, out, ctxs

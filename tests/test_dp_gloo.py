@@ -26,7 +26,11 @@ def _worker(rank, world, port, q):
     local = [p.grad.clone() for p in params]
     gb = GradBuckets(params, world, bucket_mb=1e-4)            # tiny buckets -> several collectives
     assert len(gb.buckets) > 1
-    gb.reduce_all()
+    # the data-parallel trainer reduces the flat buffer in two ranges (decoder tail first, then the head): same result
+    split = gb.offsets[2]
+    gb.gather()
+    gb.allreduce(split, None, wait=False)
+    gb.allreduce(0, split, wait=True)
     gathered = [[torch.zeros_like(g) for _ in range(world)] for g in local]
     for g, lst in zip(local, gathered):
         dist.all_gather(lst, g)
