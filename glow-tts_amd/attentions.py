@@ -10,7 +10,7 @@ from torch import nn
 
 from . import flow_impl, wgrad
 from .modules import WN, ConvP, WNConvP, _RowsFn, _mask_lengths, prepare_all
-from .ops import RowsCtx
+from .ops import PackedConv, PackSliceN, RowsCtx
 
 
 def _wn_cond(wn, g):
@@ -116,6 +116,22 @@ class MultiHeadAttention(nn.Module):
             self.conv_k.weight.data.copy_(self.conv_q.weight.data)
             self.conv_k.bias.data.copy_(self.conv_q.bias.data)
         nn.init.xavier_uniform_(self.conv_v.weight)
+        # q, k, v projections run as ONE GEMM: [R, C] x [C, 3C] forward, K = 3C for the data gradient
+        self._pc_qkv = None
+        self.qkv_bias = None
+        for i, cv in enumerate((self.conv_q, self.conv_k, self.conv_v)):
+            cv.cat_slice = (lambda i=i: PackSliceN(self.pc_qkv, i * self.channels, self.channels, self.channels))
+
+    @property
+    def pc_qkv(self):
+        dev = self.conv_q.weight.device
+        if self._pc_qkv is None or self._pc_qkv.fwd.device != dev:
+            self._pc_qkv = PackedConv(3 * self.channels, self.channels, 1, False, device=dev)
+        return self._pc_qkv
+
+    def _refresh_padded(self):
+        with torch.no_grad():
+            self.qkv_bias = torch.cat([self.conv_q.bias, self.conv_k.bias, self.conv_v.bias])
 
     def forward(self, x, c, attn_mask=None):
         """x is c (self-attention); attn_mask [b,1,t,t] = x_mask ⊗ x_mask as attentions.py:61 builds it."""

@@ -61,16 +61,15 @@ def mha_fwd(rc, att, xb, p, seed):
     dev = xb.device
     R = rc.R
     H, D, C = att.n_heads, att.k_channels, att.channels
-    q = conv_rows(xb, att.conv_q.pc, rc, bias=att.conv_q.bias)
-    k = conv_rows(xb, att.conv_k.pc, rc, bias=att.conv_k.bias)
-    v = conv_rows(xb, att.conv_v.pc, rc, bias=att.conv_v.bias)
+    qkv = conv_rows(xb, att.pc_qkv, rc, bias=att.qkv_bias)           # one GEMM: [R, C] x [C, 3C]
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     # the attention kernel writes frame rows only: halo rows must be finite zeros (they meet zero
     # gradients in the wgrad GEMM, and 0 * NaN garbage would poison it)
     o = torch.zeros(R, C, dtype=torch.bfloat16, device=dev)
     P = torch.empty(rc.B, H, rc.T, rc.T, dtype=torch.float32, device=dev)
     Ek = att.emb_rel_k.detach().reshape(-1, D).contiguous()
     Ev = att.emb_rel_v.detach().reshape(-1, D).contiguous()
-    _lib.check(L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
+    _lib.check(L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 3 * C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
                              _lib.ptr(o), C, _lib.ptr(P), rc.B, rc.T, rc.Tp, _lib.ptr(rc.row0), H, D, att.window_size, float(p), int(seed),
                              _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_fwd")
@@ -87,18 +86,17 @@ def mha_bwd(rc, att, saved, dy, grads):
     H, D, C = att.n_heads, att.k_channels, att.channels
     grads.update(conv_param_grads(att.conv_o, o, dy, R))
     do = conv_rows(dy, att.conv_o.pc, rc, dgrad=True)
-    dq = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-    dk = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-    dv = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
-    # halo / padded rows of dq,dk,dv are never written by the kernel: zero them once
-    dq.zero_(); dk.zero_(); dv.zero_()
+    # dq | dk | dv side by side (one K = 3C data-gradient GEMM below); halo / padded rows are never written by the
+    # kernel: zero the buffer once
+    dqkv = torch.zeros(R, 3 * C, dtype=torch.bfloat16, device=dev)
+    dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
     from .flow_impl import _scratch
     ws_bytes = L.gt_attn_bwd_workspace_bytes(rc.B, rc.T, H)
     ws = _scratch("attn_bwd", ws_bytes, dev)
     dEk = zeros_small(Ek.shape, Ek.dtype, dev)
     dEv = zeros_small(Ev.shape, Ev.dtype, dev)
-    _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
-                             _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), C,
+    _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 3 * C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
+                             _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), 3 * C,
                              _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, _lib.ptr(rc.row0), H, D, att.window_size, float(p), int(seed),
                              _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
                "gt_attn_bwd")
@@ -107,10 +105,7 @@ def mha_bwd(rc, att, saved, dy, grads):
     grads.update(conv_param_grads(att.conv_q, xb, dq, R))
     grads.update(conv_param_grads(att.conv_k, xb, dk, R))
     grads.update(conv_param_grads(att.conv_v, xb, dv, R))
-    dxb = conv_rows(dq, att.conv_q.pc, rc, dgrad=True)
-    dxb = conv_rows(dk, att.conv_k.pc, rc, dgrad=True, addend=dxb)
-    dxb = conv_rows(dv, att.conv_v.pc, rc, dgrad=True, addend=dxb)
-    return dxb
+    return conv_rows(dqkv, att.pc_qkv, rc, dgrad=True)              # [dq | dk | dv] @ [Wq; Wk; Wv]
 
 
 # ----------------------------------------------------------------------------- one encoder layer

@@ -32,6 +32,7 @@ class ConvP(nn.Module):
         self.weight = nn.Parameter(w)
         self.bias = nn.Parameter(b)
         self._pc = None
+        self.cat_slice = None                      # set by an owner that runs this conv as a window of a concatenated GEMM
 
     @property
     def pc(self):
@@ -40,19 +41,23 @@ class ConvP(nn.Module):
         return self._pc
 
     def _new_pc(self, Cout=None):
-        return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device)
+        return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device,
+                          norm_only=self.cat_slice is not None)
 
     def _ensure_pcs(self):
-        if self._pc is None or self._pc.fwd.device != self.weight.device:
+        if self._pc is None or self._pc.inv_norm.device != self.weight.device:
             self._pc = self._new_pc()
 
     def _pack_entries(self):
+        if self.cat_slice is not None:             # the images live in the owner's concatenated GEMM
+            return [(self.weight, None, self.cat_slice())]
         return [(self.weight, None, self._pc)]
 
     def prepare(self):
         """(Re)pack the current weights for the MFMA kernels — once per optimizer step."""
         self._ensure_pcs()
-        self._pc.pack(self.weight, None)
+        for v, g, pc in self._pack_entries():
+            _pack_one(pc, v, g)
         return self
 
 

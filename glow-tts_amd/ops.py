@@ -259,6 +259,25 @@ class PackSlice:
         return 2 * int(self.frag_f) + 4 * int(self.frag_d)
 
 
+class PackSliceN:
+    """The transposed window: output channels [n0, n0+Cout) of an N-concatenated GEMM (`parent`, taps = 1) — q, k and v
+    projections of one attention layer as ONE [R, C] x [C, 3C] GEMM forward and one K = 3C GEMM for the data gradient."""
+
+    def __init__(self, parent, n0, Cout, Cin):
+        assert parent.taps == 1 and not parent.gate and n0 % 32 == 0
+        self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, 1, False
+        self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
+        self.frag_f, self.frag_d = parent.frag_f, parent.frag_d
+        # forward image Pf[n0 + co][ci] / data-gradient image Pd[ci][n0 + co]
+        self.fwd = parent.fwd[(n0 // 32) * (parent.Kp_f // 16) * 512:] if parent.frag_f else parent.fwd[n0 * parent.Kp_f:]
+        self.dgrad = parent.dgrad[(n0 // 16) * 512:] if parent.frag_d else parent.dgrad[n0:]
+        self.inv_norm = None
+
+    @property
+    def flags(self):
+        return 2 * int(self.frag_f) + 4 * int(self.frag_d)
+
+
 class PackedConv:
     """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing.  Shapes the second
     generation kernel takes (gt_conv_gemm2_supported) are packed in MFMA-fragment order, the rest row-major."""
