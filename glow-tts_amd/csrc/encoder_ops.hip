@@ -81,9 +81,9 @@ struct LnBwdArgs {
 };
 
 // 16 waves, one row per wave at a time; gamma/beta partials are folded in LDS so that each channel gets ONE
-// atomic per workgroup (same-address float atomics serialise at L2, ~50 ns each: 64 rows per workgroup keeps both
+// atomic per workgroup (same-address float atomics serialise at L2, ~50 ns each: 32 rows per workgroup keeps both
 // the atomic chain and the per-wave row loop short).
-constexpr int LNB_WAVES = 16;
+template <int LNB_WAVES>
 __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdArgs q)
 {
   if (q.f.seed_dev) { const uint32_t x = *q.f.seed_dev; q.f.din_seed ^= x; q.f.dout_seed ^= x; }
@@ -573,8 +573,14 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
-  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.rows_per_block = 64;
-  hipLaunchKernelGGL(gt_layernorm_bwd_kernel, dim3((R + 63) / 64), dim3(64 * LNB_WAVES), 0, GT_ST(stream), q);
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta;
+  static int cfg = -1;                                   // dev knob: waves * 1000 + rows per workgroup
+  if (cfg < 0) { const char* e = getenv("GT_LNB"); cfg = e ? atoi(e) : 16032; }      // measured best on the cfg2 encoder (R = 3584): 16 waves x 32 rows
+  const int waves = cfg / 1000, rpb = cfg % 1000;
+  q.rows_per_block = rpb;
+  if (waves == 16)     hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + rpb - 1) / rpb), dim3(1024), 0, GT_ST(stream), q);
+  else if (waves == 8) hipLaunchKernelGGL(gt_layernorm_bwd_kernel<8>, dim3((R + rpb - 1) / rpb), dim3(512), 0, GT_ST(stream), q);
+  else                 hipLaunchKernelGGL(gt_layernorm_bwd_kernel<4>, dim3((R + rpb - 1) / rpb), dim3(256), 0, GT_ST(stream), q);
   GT_RET();
 }
 
