@@ -12,6 +12,7 @@
 //                          converted pairwise to bf16 and fed as B; V^T comes from LDS through
 //                          ds_read_b64_tr_b16 (pitch 192 B) in the permuted k order that map requires.
 //   O^T += Ev^T band(P)^T  the relative-value term as one K=16 MFMA per 32 channels.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/glowtts_hip.h"
 #include "internal.h"
@@ -604,6 +605,11 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   bf16_t* w16 = static_cast<bf16_t*>(ws);
   bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
   if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  // 161 <= T <= 256: the 8-key-tile backward (2 waves per workgroup, 153 KB of LDS, register spills) raised a memory
+  // access fault on MI355X once q / k / v became windows of one [R, 3C] buffer (tools/dbg_mha200.py reproduces it under
+  // AMD_SERIALIZE_KERNEL=3); until that is understood the generic kernels take these lengths (cfg2 has T_x <= 150).
+  static const bool bwd8 = getenv("GT_ATTN_BWD8") != nullptr;
+  if (!bwd8) return 1;
   return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }
 

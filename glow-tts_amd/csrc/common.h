@@ -23,8 +23,9 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
 }
 __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t row, uint32_t col, uint32_t thresh) {
-  // keep with probability 1-p, thresh = p * 2^32
-  return hash_u32(seed ^ hash_u32(row * 0x9E3779B1U + col)) >= thresh;
+  // keep with probability 1-p, thresh = p * 2^32.  One finalizer round over a (seed, row, col) mix with odd multipliers:
+  // half the VALU work of hashing twice, and it is paid per element in the gate conv's epilogue and its backward.
+  return hash_u32(seed + row * 0x9E3779B1U + col * 0x85EBCA6BU) >= thresh;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -4,6 +4,7 @@
 //   affine coupling              attentions.py:174-186      (forward, backward)
 //   WaveNet gate backward        commons.py:61-68 (autograd of tanh*sigmoid, dropout replay)
 // All fp32 math; bf16 only where a tensor feeds an MFMA GEMM.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/glowtts_hip.h"
 
@@ -420,7 +421,8 @@ extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx
                                       const float* dlogdet, float* dlogs, float* dbias, float* dW, int B, int R, int C, void* stream)
 {
   if (!x || !dy || !dx || !logs || !bias || !W || !rowmask || !dlogs || !dbias || !dW || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
-  const int rows_per_block = 128;
+  static int rows_per_block = 0;                          // dev knob GT_ANB_ROWS
+  if (!rows_per_block) { const char* e = getenv("GT_ANB_ROWS"); rows_per_block = e ? atoi(e) : 128; if (rows_per_block < 4) rows_per_block = 128; }
   hipLaunchKernelGGL(gt_actnorm_invconv_bwd_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(256), 0, GT_ST(stream),
                      x, dy, dx, logs, bias, W, rowmask, dlogs, dbias, dW, R, C, rows_per_block);
   if (dlogdet) {
