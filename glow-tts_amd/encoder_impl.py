@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from .flow_impl import _st, conv_param_grads
-from .ops import conv_rows, seed_word, zeros_small
+from .ops import conv_rows, grad_accumulator, seed_word, zeros_small
 
 LN_EPS = 1e-4
 
@@ -42,8 +42,8 @@ def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads):
     dev = rc.device
     da = torch.empty(R, C, dtype=torch.float32, device=dev) if want_da else None
     dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if want_dy else None
-    dg = zeros_small(C, torch.float32, dev)
-    db = zeros_small(C, torch.float32, dev)
+    dg = grad_accumulator(ln.gamma, (C,))
+    db = grad_accumulator(ln.beta, (C,))
     _lib.check(L.gt_layernorm_bwd(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
                                   _lib.ptr(rc.rowmask), _lib.ptr(mean), _lib.ptr(rstd), R, C, LN_EPS,
                                   float(p_in), int(seed_in), float(p_out), int(seed_out), int(relu),
@@ -93,8 +93,8 @@ def mha_bwd(rc, att, saved, dy, grads):
     from .flow_impl import _scratch
     ws_bytes = L.gt_attn_bwd_workspace_bytes(rc.B, rc.T, H)
     ws = _scratch("attn_bwd", ws_bytes, dev)
-    dEk = zeros_small(Ek.shape, Ek.dtype, dev)
-    dEv = zeros_small(Ev.shape, Ev.dtype, dev)
+    dEk = grad_accumulator(att.emb_rel_k, Ek.shape)
+    dEv = grad_accumulator(att.emb_rel_v, Ev.shape)
     _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 3 * C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths),
                              _lib.ptr(do), C, _lib.ptr(P), _lib.ptr(ws), ws_bytes, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), 3 * C,
                              _lib.ptr(dEk), _lib.ptr(dEv), rc.B, rc.T, rc.Tp, _lib.ptr(rc.row0), H, D, att.window_size, float(p), int(seed),

@@ -9,7 +9,7 @@ backward mirrors what autograd derives for the reference modules:
 import torch
 
 from . import _lib
-from .ops import RowsCtx, conv_rows, seed_word, zeros_small  # noqa: F401
+from .ops import RowsCtx, conv_rows, grad_accumulator, seed_word, zeros_small  # noqa: F401
 
 _SCRATCH = {}
 
@@ -96,9 +96,9 @@ def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
     dev = x.device
     R, C = x.shape
     dx = torch.empty_like(x)
-    dlogs = zeros_small(C, torch.float32, dev)
-    dbias = zeros_small(C, torch.float32, dev)
-    dW = zeros_small(16, torch.float32, dev)
+    dlogs = grad_accumulator(logs, (C,))
+    dbias = grad_accumulator(bias, (C,))
+    dW = grad_accumulator(W, (16,))
     _lib.check(L.gt_actnorm_invconv_bwd(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dx), _lib.ptr(lg), _lib.ptr(bs), _lib.ptr(Wc),
                                         _lib.ptr(scal), _lib.ptr(rc.rowmask), _lib.ptr(rc.lengths), _lib.ptr(dlogdet),
                                         _lib.ptr(dlogs), _lib.ptr(dbias), _lib.ptr(dW), rc.B, R, C, _st(dev)),

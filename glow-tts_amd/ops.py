@@ -116,6 +116,22 @@ RAGGED = False          # train.Trainer turns it on: utterances are packed back 
 ROW_ROUND = 128         # ragged R is rounded up to this (row tiles of the GEMMs)
 
 
+ACCUM_LIVE = False      # True between GradBuckets.zero_accum() and the last gather() of a step
+
+
+def grad_accumulator(param, shape=None):
+    """Zero-initialised fp32 buffer that a backward kernel accumulates a (non-conv) parameter's gradient into with
+    atomics.  Under train.Trainer it is the parameter's own slice of the flat gradient buffer (train.GradBuckets lays
+    these parameters out first and zeroes the region once per step), so no copy is needed afterwards; elsewhere it is
+    a zeros_small buffer."""
+    shape = tuple(shape) if shape is not None else tuple(param.shape)
+    fg = getattr(param, "_gt_flat_grad", None)
+    if ACCUM_LIVE and fg is not None and getattr(param, "_gt_prezeroed", False):
+        buf, off = fg
+        return buf[off:off + param.numel()].view(shape)
+    return zeros_small(shape, torch.float32, param.device)
+
+
 class RowsCtx:
     """Geometry of one batch in the rows layout; rowmask is 1 on valid frames.
 

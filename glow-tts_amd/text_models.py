@@ -167,7 +167,7 @@ class _TextEncoderRunner:
             if te.prenet:
                 dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
-        demb = torch.zeros_like(te.emb.weight)
+        demb = ops.grad_accumulator(te.emb.weight)
         B, T = self.ids.shape
         _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C,
                                       math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_bwd")

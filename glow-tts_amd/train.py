@@ -74,9 +74,16 @@ class GradBuckets:
     `gather()` (one multi-tensor copy); the optimizer and the collectives only ever see the flat buffer."""
     ALIGN = 64          # floats: every parameter starts on a 256-byte boundary
 
-    def __init__(self, params, world, bucket_mb=64):
+    def __init__(self, params, world, bucket_mb=64, accum=()):
+        """accum: parameters whose gradients are ACCUMULATED by atomics (LayerNorm, ActNorm, InvConvNear, relative-
+        position and token embeddings): they are laid out first, contiguously, and `zero_accum()` clears that region
+        with one fill per step, so that their backward kernels add straight into the flat buffer
+        (ops.grad_accumulator) — every other gradient is overwritten whole by the batched wgrad kernels."""
         self.world = world
-        self.params = [p for p in params if p.requires_grad]
+        ids = {id(p) for p in accum}
+        ps = [p for p in params if p.requires_grad]
+        self.params = [p for p in ps if id(p) in ids] + [p for p in ps if id(p) not in ids]
+        self.n_accum = sum(1 for p in ps if id(p) in ids)
         dev = self.params[0].device
         self.offsets, off = [], 0
         for p in self.params:
@@ -86,11 +93,21 @@ class GradBuckets:
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         cap = max(self.ALIGN, int(bucket_mb * (1 << 20) / 4) // self.ALIGN * self.ALIGN)
         self.buckets = [(s, min(s + cap, self.total)) for s in range(0, self.total, cap)]
-        for p, o in zip(self.params, self.offsets):
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             p._gt_flat_grad = (self.flat, o)
+            p._gt_prezeroed = i < self.n_accum
+        self.accum_end = self.offsets[self.n_accum] if self.n_accum < len(self.params) else self.total
         self.on_gpu = dev.type == "cuda"
         self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.on_gpu) else None
         self.active = [True] * len(self.params)
+
+    def zero_accum(self):
+        """Start of a step: clear the accumulated-gradient region and let ops.grad_accumulator hand out its slices
+        (until the step's last gather(); a model run outside a Trainer step never sees the flat buffer)."""
+        from . import ops
+        if self.n_accum:
+            self.flat[:self.accum_end].zero_()
+            ops.ACCUM_LIVE = True
 
     def view(self, i):
         p, o = self.params[i], self.offsets[i]
@@ -103,6 +120,9 @@ class GradBuckets:
         wgrad.join(self.flat.device)             # weight gradients flushed on the side stream land first
         dsts, srcs = [], []
         hi = len(self.params) if hi is None else hi
+        if lo == 0:
+            from . import ops
+            ops.ACCUM_LIVE = False
         for i in range(lo, hi):
             p = self.params[i]
             g = p.grad
@@ -229,11 +249,19 @@ class Trainer:
         self.world = world
         self.graph_mode = bool(graph)
         self.split = (world > 1) if split_graph is None else bool(split_graph)
-        self.buckets = GradBuckets(list(model.parameters()), world)
+        accum = []
+        for mod in model.modules():
+            kind = type(mod).__name__
+            if kind in ("LayerNorm", "ActNorm", "InvConvNear", "Embedding"):
+                accum += list(mod.parameters(recurse=False))
+            elif kind == "MultiHeadAttention":
+                accum += [mod.emb_rel_k, mod.emb_rel_v]
+        self.buckets = GradBuckets(list(model.parameters()), world, accum=accum)
         # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
         # first backward call and travel over xGMI while the text encoder's backward runs
-        names = [n for n, p in model.named_parameters() if p.requires_grad]
-        self.dec0 = next((i for i, n in enumerate(names) if n.startswith("decoder.")), len(names))
+        name_of = {id(p): n for n, p in model.named_parameters()}
+        names = [name_of[id(p)] for p in self.buckets.params]                 # flat-buffer order: accumulated ones first
+        self.dec0 = next((i for i, n in enumerate(names) if i >= self.buckets.n_accum and n.startswith("decoder.")), len(names))
         assert all(n.startswith("decoder.") for n in names[self.dec0:]), "decoder parameters must be the tail of the model"
         self.dec0_off = self.buckets.offsets[self.dec0] if self.dec0 < len(names) else self.buckets.total
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
@@ -251,6 +279,7 @@ class Trainer:
         m = self.model
         ops.bump_seed(ids.device)
         ops.arena_begin(ids.device)              # one fill for all the small zeroed accumulators of this step
+        self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
         (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host)
@@ -273,6 +302,7 @@ class Trainer:
         m = self.model
         ops.bump_seed(ids.device)
         ops.arena_begin(ids.device)
+        self.buckets.zero_accum()
         for p in self.buckets.params:
             p.grad = None
         (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host,

@@ -153,3 +153,50 @@ def test_phased_backward_matches_single_backward(built, graph):
     assert abs(l1.item() - l2.item()) <= 2e-2 * max(1.0, abs(l1.item())), (l1.item(), l2.item())
     worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
     assert worst < 5e-3, worst
+
+
+def test_trainer_gradients_match_plain_autograd(built):
+    """Under a Trainer the atomically accumulated gradients (LayerNorm, ActNorm, InvConvNear, relative-position and
+    token embeddings) are written straight into their slices of the flat gradient buffer (ops.grad_accumulator), the
+    region being cleared once per step; the rest arrives from the batched wgrad kernels.  Same numbers as the model run
+    by plain autograd without a Trainer, step after step (nothing left over from the previous step), and no copy is
+    needed for the accumulated ones."""
+    from glow_tts_amd import models, ops, train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    tr = train.Trainer(m2, graph=False)
+    gb = tr.buckets
+    assert gb.n_accum > 0 and all(p._gt_prezeroed for p in gb.params[:gb.n_accum])
+    copied = []
+    real = torch._foreach_copy_
+    for seed in (0, 7):
+        ids, t_x, y, t_y = train.synth_batch(4, 40, 120, seed, dev())
+        for p in m1.parameters():
+            p.grad = None
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m1(ids, t_x, y, t_y)
+        (models.mle_loss(z, z_m, None, logdet, z_mask) + l_length.sum()).backward()
+        want = {n: (None if p.grad is None else p.grad.clone()) for n, p in m1.named_parameters()}
+        torch._foreach_copy_ = lambda d, s: (copied.append([t.data_ptr() for t in d]), real(d, s))[1]
+        try:
+            tr._fwd_bwd(ids, t_x, y, t_y)
+        finally:
+            torch._foreach_copy_ = real
+            ops.arena_end(dev())                 # the step's zero arena is normally closed by Trainer._optim
+        head = {gb.view(i).data_ptr() for i in range(gb.n_accum)}
+        assert not (head & {q for c in copied for q in c}), "accumulated gradients were copied into the flat buffer"
+        for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+            ref = want[n]
+            if ref is None:
+                assert q.grad is None or q.grad.abs().max().item() == 0, n
+                continue
+            err = (q.grad - ref).abs().max().item()
+            assert err <= 1e-3 * max(1e-6, ref.abs().max().item()) + 1e-6, (seed, n, err)   # atomics: order of the sums differs
