@@ -283,9 +283,12 @@ def text_encoder_fwd(P, pre, ids, x_lengths, g=None, hidden=192, n_layers=6, n_h
     return x, x_m, x_logs, x_mask
 
 
-def duration_predictor_fwd(P, pre, x, x_mask, kernel_size=3):
-    """models.DurationPredictor.forward (models.py:585-612), g=l=emo=None, eval mode."""
+def duration_predictor_fwd(P, pre, x, x_mask, kernel_size=3, g=None):
+    """models.DurationPredictor.forward (models.py:585-612), l=emo=None, eval mode; g [b,gin,1] is detached and
+    added through the 1x1 `cond` conv (models.py:587-589)."""
     x = x.detach()
+    if g is not None:
+        x = x + conv1d(P, pre + "cond", g.detach())
     x = conv1d(P, pre + "conv_1", x * x_mask, padding=kernel_size // 2)
     x = layer_norm_c(torch.relu(x), P[pre + "norm_1.gamma"], P[pre + "norm_1.beta"])
     x = conv1d(P, pre + "conv_2", x * x_mask, padding=kernel_size // 2)
@@ -313,14 +316,16 @@ def mle_loss(z, m, logs, logdet, mask):
     return l + 0.5 * math.log(2 * math.pi)
 
 
-def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp):
+def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None):
     """The upstream-equivalent live sub-graph of models.FlowGenerator.forward
     (models.py:1050-1119) for the base configs (the fork's FlowGenerator does not
     construct for them): TextEncoder -> FlowSpecDecoder -> logp -> MAS -> duration loss
     (deterministic DurationPredictor, models.py:1089-1092) -> prior expansion -> mle loss.
-    `maximum_path(value, mask) -> path` is the MAS implementation to use (tests pass the oracle)."""
+    `maximum_path(value, mask) -> path` is the MAS implementation to use (tests pass the oracle).
+    g [b,gin,1]: the speaker vector of the multi-speaker configs as it reaches the encoder / duration predictor /
+    decoder (models.py:1046,1075,1090)."""
     n_sqz = hp.get("n_sqz", 2)
-    x, x_m, x_logs, x_mask = text_encoder_fwd(P, "encoder.", ids, x_lengths, None, hp["hidden_channels"],
+    x, x_m, x_logs, x_mask = text_encoder_fwd(P, "encoder.", ids, x_lengths, g, hp["hidden_channels"],
                                               hp["n_layers_enc"], hp["n_heads"], hp["window_size"],
                                               hp["kernel_size"], hp["prenet"], hp["mean_only"])
     y_max = (y.size(2) // n_sqz) * n_sqz                                     # models.py:1248-1253
@@ -328,14 +333,14 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp):
     y_lengths = (y_lengths // n_sqz) * n_sqz
     z_mask = sequence_mask(y_lengths, y_max).unsqueeze(1).to(x_mask.dtype)
     attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
-    z, logdet = decoder_fwd(P, "decoder.", y, z_mask, None, hp["n_blocks_dec"], hp["n_block_layers"],
+    z, logdet = decoder_fwd(P, "decoder.", y, z_mask, g, hp["n_blocks_dec"], hp["n_block_layers"],
                             hp["hidden_channels"], hp["kernel_size_dec"], 4, n_sqz)
     with torch.no_grad():
         logp = logp_lattice(x_m, x_logs, z)
         attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1).detach()
     w = attn.squeeze(1).sum(2).unsqueeze(1)
     logw_ = torch.log(w + 1e-8) * x_mask
-    logw = duration_predictor_fwd(P, "encoder.proj_w.", x, x_mask, hp["kernel_size"])
+    logw = duration_predictor_fwd(P, "encoder.proj_w.", x, x_mask, hp["kernel_size"], g)
     l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
     z_m = torch.matmul(attn.squeeze(1).transpose(1, 2), x_m.transpose(1, 2)).transpose(1, 2)
     z_logs = torch.matmul(attn.squeeze(1).transpose(1, 2), x_logs.transpose(1, 2)).transpose(1, 2)

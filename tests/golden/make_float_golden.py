@@ -169,6 +169,26 @@ def main():
     gp = commons.generate_path(dur, gmask)
     out.update(dec_rev_z=zr, dec_rev_x=xr, genpath_dur=dur, genpath_mask=gmask, genpath_out=gp)
 
+    # ---- speaker conditioning g [b,256,1] (cfg 4, configs/base_blank_ms.json): Encoder.cond_g before layer index 2
+    # (attentions.py:66-67), DurationPredictor.cond (models.py:587-589), WN.cond_layer inside the decoder
+    # (modules.py:148-149) — appended after everything above, so earlier draws keep their values
+    spk = rnd(2, 256, 1)
+    encg = fill_module(attentions.Encoder(192, 768, 2, 3, 3, 0.1, window_size=4, gin_channels=256), "encg.").eval()
+    xeg = xe.clone().requires_grad_(True); spg = spk.clone().requires_grad_(True)
+    og = encg(xeg, xm, g=spg)
+    gxe, gsp = grads_of([(og, 6)], [xeg, spg])
+    out.update(spk_g=spk, encg_out=og, encg_gx=gxe, encg_gg=gsp)
+    dpg = fill_module(models.DurationPredictor(192, 256, 3, 0.1, gin_channels=256), "dpg.").eval()
+    out.update(dpg_out=dpg(xe, xm, g=spk))
+    decg = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, n_split=4, n_sqz=2, gin_channels=256),
+                       "decoder.").eval()
+    yg = (y[:, :, :24] * ym[:, :, :24]).requires_grad_(True); spd = spk.clone().requires_grad_(True)
+    zg, ldg = decg(yg, ym[:, :, :24], g=spd)
+    gyg, gsd = grads_of([(zg, 7), (ldg, 8)], [yg, spd])
+    with torch.no_grad():
+        xrg, _ = decg(zr, ym[:, :, :24], g=spk, reverse=True)
+    out.update(decg_z=zg, decg_logdet=ldg, decg_gy=gyg, decg_gg=gsd, decg_rev_x=xrg)
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

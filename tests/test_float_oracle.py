@@ -154,3 +154,29 @@ def test_reverse_flow_and_generate_path_match_reference_golden(built):
     assert close(zz, z, 1e-3)
     gp = R.generate_path(t("genpath_dur"), t("genpath_mask"))
     assert torch.equal(gp, t("genpath_out"))
+
+
+def test_speaker_conditioning_matches_reference_golden(built):
+    """cfg 4 (configs/base_blank_ms.json, gin_channels=256): the speaker vector g [b,256,1] through Encoder.cond_g
+    (attentions.py:66-67), DurationPredictor.cond (models.py:587-589) and the WN cond_layer of every coupling block
+    (modules.py:148-149; forward, both gradients, reverse) — oracle restatement vs the imported reference."""
+    from glow_tts_amd import models
+    x, m, spk = t("enc_x"), t("enc_mask"), t("spk_g")
+    sh = dict(enc_shapes(3)); sh.update({"cond_g.weight": (192, 256), "cond_g.bias": (192,)})
+    xx, gg = x.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    o = R.encoder_fwd(filled_state(sh, "encg."), "encg.", xx, m, g=gg, n_layers=3)
+    assert close(o, t("encg_out"), 1e-4)
+    gx, g_g = torch.autograd.grad((o * torch.randn(o.shape, generator=torch.Generator().manual_seed(6))).sum(), [xx, gg])
+    assert close(gx, t("encg_gx"), 2e-4) and close(g_g, t("encg_gg"), 2e-4)
+    sh = dict(DP_SHAPES); sh.update({"cond.weight": (192, 256, 1), "cond.bias": (192,)})
+    assert close(R.duration_predictor_fwd(filled_state(sh, "dpg."), "dpg.", x, m, g=spk), t("dpg_out"), 1e-4)
+    P = module_state(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, gin_channels=256), "decoder.")
+    y, gg = t("dec_y").clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    z, ld = R.decoder_fwd(P, "decoder.", y, t("dec_mask"), gg, n_blocks=2)
+    assert close(z, t("decg_z"), 1e-4) and close(ld, t("decg_logdet"), 1e-4)
+    tot = (z * torch.randn(z.shape, generator=torch.Generator().manual_seed(7))).sum() + \
+          (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(8))).sum()
+    gy, g_g = torch.autograd.grad(tot, [y, gg])
+    assert close(gy, t("decg_gy"), 2e-4) and close(g_g, t("decg_gg"), 2e-4)
+    xr = R.decoder_rev(P, "decoder.", t("dec_rev_z"), t("dec_mask"), spk, n_blocks=2)
+    assert close(xr, t("decg_rev_x"), 2e-4)
