@@ -199,37 +199,54 @@ class Encoder(nn.Module):
         if gin_channels != 0:
             self.cond_g = nn.Linear(gin_channels, hidden_channels)
 
+    COND_LAYER = 2          # `if i == 3 - 1 and g is not None` (attentions.py:66)
+
+    def cond_vec(self, g):
+        """cond_g(g) (attentions.py:67) for g [b,gin,1]: a [B,gin]x[gin,H] product on B rows — host-side PyTorch
+        plumbing, differentiable w.r.t. g and cond_g's parameters; the kernels add it to the rows."""
+        if g is None or self.n_layers <= self.COND_LAYER:
+            return None
+        return torch.nn.functional.linear(g.squeeze(-1), self.cond_g.weight, self.cond_g.bias)
+
     def forward(self, x, x_mask, g=None, emo=None):
-        if g is not None:
-            raise NotImplementedError("speaker conditioning inside the encoder (cfg 4/5) is out of the round-1 scope")
+        assert emo is None, "emotion conditioning is commented out in the reference encoder (attentions.py:69-70)"
         prepare_all(self)
-        runner = _EncoderRunner(self, x_mask, self.training)
-        (out,) = _RowsFn.apply(runner, 1, x, *runner.params)
+        vec = self.cond_vec(g)
+        runner = _EncoderRunner(self, x_mask, self.training, has_cond=vec is not None)
+        (out,) = _RowsFn.apply(runner, 1, x, *([vec] if vec is not None else []), *runner.params)
         return out
 
 
 class _EncoderRunner:
-    def __init__(self, enc, x_mask, train, seed=0):
-        self.enc, self.x_mask, self.train, self.seed = enc, x_mask, train, seed
-        self.params = list(enc.parameters())
+    def __init__(self, enc, x_mask, train, seed=0, has_cond=False):
+        self.enc, self.x_mask, self.train, self.seed, self.has_cond = enc, x_mask, train, seed, has_cond
+        self.params = [p for n, p in enc.named_parameters() if not n.startswith("cond_g.")]
 
-    def forward(self, x, *_):
+    def forward(self, x, *rest):
+        from . import ops
+        vec = rest[0] if self.has_cond else None
         B, C, T = x.shape
         rc = RowsCtx(_mask_lengths(self.x_mask), T)
         xm = x.detach().float() * self.x_mask
         xr, xb = rc.to_rows(xm), rc.to_rows(xm, torch.bfloat16)
         saved = []
         for i in range(self.enc.n_layers):
+            if i == self.enc.COND_LAYER and vec is not None:
+                xr, xb = ops.rows_add_cond(rc, xr, None, vec)
             xr, xb, s = encoder_impl.layer_fwd(rc, self.enc, i, xr, xb, self.train, self.seed + 8 * i)
             saved.append(s)
         return (rc.from_rows(xr),), (rc, saved)
 
     def backward(self, saved_all, dout):
+        from . import ops
         rc, saved = saved_all
         grads = {}
+        dvec = None
         dx, dxb = rc.to_rows(dout.float() * self.x_mask), None
         with wgrad.WgradQueue(dout.device, site=self.enc):
             for i in reversed(range(self.enc.n_layers)):
                 dx, dxb = encoder_impl.layer_bwd(rc, self.enc, i, saved[i], dx, dxb, grads)
+                if i == self.enc.COND_LAYER and self.has_cond:
+                    dvec = ops.cond_grad(rc, dx, dxb)
         tot = rc.from_rows(dx) + rc.from_rows(dxb, torch.float32)
-        return [tot * self.x_mask] + [grads.get(p) for p in self.params]
+        return [tot * self.x_mask] + ([dvec] if self.has_cond else []) + [grads.get(p) for p in self.params]

@@ -415,6 +415,27 @@ __global__ __launch_bounds__(256) void gt_embedding_bwd_kernel(const int64_t* __
   for (int c = lane; c < C; c += 64) atomicAdd(demb + (size_t)id * C + c, dx[(size_t)m * C + c] * scale);
 }
 
+// ------------------------------------------------------------------ per-utterance vector added to every valid row
+// out[m,:] = (x[m,:] + cond[batch(m),:]) * rowmask[m]: the speaker vector of attentions.py:66-67 (Encoder.cond_g) and
+// models.py:587-589 (DurationPredictor.cond), which the reference broadcasts over time.  Source fp32 (x) or bf16 (xb);
+// fp32 and/or bf16 output; halo / padded rows stay zero.
+__global__ __launch_bounds__(256) void gt_rows_add_cond_kernel(const float* __restrict__ x, int ldx, const bf16_t* __restrict__ xb, int ldxb,
+                                                               const float* __restrict__ cond, const float* __restrict__ rowmask,
+                                                               float* __restrict__ out, int ldo, bf16_t* __restrict__ outb, int ldob,
+                                                               int B, int R, int C, int Tp, const int32_t* __restrict__ row0)
+{
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (m >= R) return;
+  const bool valid = rowmask[m] != 0.f;
+  const int b = valid ? gt_row_batch(row0, B, m, Tp) : 0;
+  for (int c = lane; c < C; c += 64) {
+    float v = 0.f;
+    if (valid) v = (x ? x[(size_t)m * ldx + c] : bf2f(xb[(size_t)m * ldxb + c])) + cond[(size_t)b * C + c];
+    if (out) out[(size_t)m * ldo + c] = v;
+    if (outb) outb[(size_t)m * ldob + c] = f2bf(v);
+  }
+}
+
 // ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
 // logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
 //               + sum_d -0.5 m_id^2 e^{-2 s_id}
@@ -670,6 +691,15 @@ extern "C" int gt_embedding_fwd(const int64_t* ids, const float* emb, const int3
   if (!row0 && R != B * Tp) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_embedding_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, emb, lens, out_f32,
                      static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale, row0, R);
+  GT_RET();
+}
+extern "C" int gt_rows_add_cond(const float* x, int ldx, const void* xb, int ldxb, const float* cond, const float* rowmask,
+                               float* out, int ldo, void* outb, int ldob, int B, int R, int C, int Tp, const int32_t* row0, void* stream)
+{
+  if ((!x && !xb) || !cond || !rowmask || (!out && !outb) || B <= 0 || R <= 0 || C <= 0) return GT_E_INVAL;
+  if (!row0 && R != B * Tp) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_add_cond_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), x, ldx, static_cast<const bf16_t*>(xb), ldxb,
+                     cond, rowmask, out, ldo, static_cast<bf16_t*>(outb), ldob, B, R, C, Tp, row0);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

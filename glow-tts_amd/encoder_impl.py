@@ -208,8 +208,9 @@ def dp_fwd(rc, dp, xb, train, seed):
     return out, (xb, c1, s1, h1, c2, s2, h2)
 
 
-def dp_bwd(rc, dp, saved, dout, grads):
-    """dout: [R, 8] fp32 (only column 0 non-zero).  x is detached in the reference: no input grad."""
+def dp_bwd(rc, dp, saved, dout, grads, want_dx=False):
+    """dout: [R, 8] fp32 (only column 0 non-zero).  x is detached in the reference: no input grad, except for the
+    speaker vector added to it (want_dx: returns the bf16 input gradient its cond conv needs)."""
     L = _lib.lib()
     xb, c1, s1, h1, c2, s2, h2 = saved
     R = rc.R
@@ -231,3 +232,4 @@ def dp_bwd(rc, dp, saved, dout, grads):
     dr1 = torch.empty_like(dc1)
     _lib.check(L.gt_relu_drop_bwd(_lib.ptr(dc1), F, _lib.ptr(c1), F, _lib.ptr(dr1), F, R, F, 0.0, _st(dev)), "gt_relu_drop_bwd")
     grads.update(conv_param_grads(dp.conv_1, xb, dr1, R))
+    return conv_rows(dr1, dp.conv_1.pc, rc, dgrad=True) if want_dx else None

@@ -116,6 +116,34 @@ RAGGED = False          # train.Trainer turns it on: utterances are packed back 
 ROW_ROUND = 128         # ragged R is rounded up to this (row tiles of the GEMMs)
 
 
+def rows_add_cond(rc, x, xb, cond, want_f32=True, want_bf16=True):
+    """(x or xb)[m,:] + cond[utterance(m),:] on the valid rows (gt_rows_add_cond): the speaker vector that
+    attentions.py:66-67 / models.py:587-589 broadcast over time.  Returns (fp32 rows or None, bf16 rows or None)."""
+    L = _lib.lib()
+    src = x if x is not None else xb
+    R, C = src.shape
+    dev = src.device
+    cond = cond.detach().float().contiguous()
+    assert cond.shape == (rc.B, C), (cond.shape, rc.B, C)
+    out = torch.empty(R, C, dtype=torch.float32, device=dev) if want_f32 else None
+    outb = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    _lib.check(L.gt_rows_add_cond(_lib.ptr(x), 0 if x is None else x.stride(0), _lib.ptr(xb), 0 if xb is None else xb.stride(0),
+                                  _lib.ptr(cond), _lib.ptr(rc.rowmask), _lib.ptr(out), C, _lib.ptr(outb), C,
+                                  rc.B, R, C, rc.Tp, _lib.ptr(rc.row0), _lib.current_stream(dev)), "gt_rows_add_cond")
+    return out, outb
+
+
+def cond_grad(rc, *row_grads):
+    """Gradient of the vector added by rows_add_cond: per-utterance sum over the valid rows of the output gradients."""
+    tot = None
+    for d in row_grads:
+        if d is None:
+            continue
+        s = rc.batch_sum(d.float() * rc.rowmask[:, None])
+        tot = s if tot is None else tot + s
+    return tot
+
+
 ACCUM_LIVE = False      # True between GradBuckets.zero_accum() and the last gather() of a step
 
 

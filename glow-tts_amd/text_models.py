@@ -45,8 +45,9 @@ class _PaddedConv:
 class DurationPredictor(nn.Module):
     def __init__(self, in_channels, filter_channels, kernel_size, p_dropout, gin_channels=0, lin_channels=0, emoin_channels=0):
         super().__init__()
-        assert gin_channels == 0 and lin_channels == 0 and emoin_channels == 0, "conditioned predictor: cfg 4/5, next round"
+        assert lin_channels == 0 and emoin_channels == 0, "language / emotion conditioned predictor: cfg 5, not on the round-1 path"
         self.in_channels, self.filter_channels, self.kernel_size, self.p_dropout = in_channels, filter_channels, kernel_size, p_dropout
+        self.gin_channels = gin_channels
         self.conv_1 = ConvP(in_channels, filter_channels, kernel_size)
         self.norm_1 = LayerNorm(filter_channels)
         self.conv_2 = ConvP(filter_channels, filter_channels, kernel_size)
@@ -54,6 +55,14 @@ class DurationPredictor(nn.Module):
         self.proj = ConvP(filter_channels, 1, 1)
         self.proj.no_pack = True                      # runs through proj_pad (8 output channels); parameters only
         self.proj_pad = _PaddedConv(self.proj)
+        if gin_channels != 0:
+            self.cond = nn.Conv1d(gin_channels, in_channels, 1)          # models.py:579-580; B rows: host-side plumbing
+
+    def cond_vec(self, g):
+        """cond(detach(g)) (models.py:587-589) for g [b,gin,1] -> [B, in_channels]; the kernels add it to the rows."""
+        if g is None:
+            return None
+        return self.cond(g.detach()).squeeze(-1)
 
     def _refresh_padded(self):
         self.proj_pad.refresh()
@@ -71,13 +80,14 @@ class TextEncoder(nn.Module):
                  gin_channels=0, lin_channels=0, emoin_channels=0):
         super().__init__()
         assert not use_sdp, "StochasticDurationPredictor is SURVEY §8 (f1): next round"
-        assert lin_channels == 0 and gin_channels == 0, "language / speaker conditioning: cfg 4/5, next round"
+        assert lin_channels == 0, "language conditioning (cfg 5) is not on the round-1 path"
+        self.gin_channels = gin_channels
         self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
         self.filter_channels, self.filter_channels_dp, self.n_heads, self.n_layers = filter_channels, filter_channels_dp, n_heads, n_layers
         self.kernel_size, self.p_dropout, self.window_size, self.mean_only, self.prenet = kernel_size, p_dropout, window_size, mean_only, prenet
         self.emb = nn.Embedding(n_vocab, hidden_channels)
         nn.init.normal_(self.emb.weight, 0.0, hidden_channels ** -0.5)
-        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout)
+        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout, gin_channels=gin_channels)
         if prenet:
             self.pre = ConvReluNorm(hidden_channels, hidden_channels, hidden_channels, kernel_size=5, n_layers=3, p_dropout=0.5)
         self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
@@ -90,28 +100,32 @@ class TextEncoder(nn.Module):
     def forward(self, x, x_lengths, l=None, g=None, emo=None, prepared=False):
         """ids [b, t] int64, lengths [b] -> (x [b,H,t], x_m [b,80,t], x_logs [b,80,t], x_mask [b,1,t])
         exactly as reference models.py:692-716."""
-        assert l is None and g is None, "conditioning: cfg 4/5, next round"
+        assert l is None and emo is None, "language / emotion conditioning (cfg 5) is not on the round-1 path"
         if not prepared:
             prepare_all(self)
         self._step += 1
         T = x.shape[1]
         x_mask = (torch.arange(T, device=x.device)[None, :] < x_lengths[:, None]).unsqueeze(1).to(torch.float32)
-        runner = _TextEncoderRunner(self, x, x_lengths, self.training, seed=(self._step * 104729) & 0x7fffffff)
-        outs = _RowsFn.apply(runner, 3, *runner.params)
+        vec = self.encoder.cond_vec(g)                # speaker vector, added before encoder layer index 2
+        runner = _TextEncoderRunner(self, x, x_lengths, self.training, seed=(self._step * 104729) & 0x7fffffff,
+                                    has_cond=vec is not None)
+        outs = _RowsFn.apply(runner, 3, *([vec] if vec is not None else []), *runner.params)
         xo, x_m, x_logs = outs[0], outs[1], outs[2]
         self._last_rows = runner.last            # (rc, xb_final) for the duration predictor
         return xo, x_m, x_logs, x_mask
 
 
 class _TextEncoderRunner:
-    def __init__(self, te, ids, lengths, train, seed):
+    def __init__(self, te, ids, lengths, train, seed, has_cond=False):
         self.te, self.ids, self.lengths, self.train, self.seed = te, ids.contiguous(), lengths, train, seed
-        self.params = [p for n, p in te.named_parameters() if not n.startswith("proj_w.")]
+        self.has_cond = has_cond
+        self.params = [p for n, p in te.named_parameters() if not n.startswith("proj_w.") and not n.startswith("encoder.cond_g.")]
         self.last = None
 
-    def forward(self, *_):
+    def forward(self, *rest):
         L = _lib.lib()
         te = self.te
+        vec = rest[0] if self.has_cond else None
         B, T = self.ids.shape
         dev = self.ids.device
         C = te.hidden_channels
@@ -126,6 +140,8 @@ class _TextEncoderRunner:
             x, xb, s_pre = encoder_impl.crn_fwd(rc, te.pre, x, xb, self.train, self.seed)
         s_layers = []
         for i in range(te.encoder.n_layers):
+            if i == te.encoder.COND_LAYER and vec is not None:
+                x, xb = ops.rows_add_cond(rc, x, None, vec)
             x, xb, s = encoder_impl.layer_fwd(rc, te.encoder, i, x, xb, self.train, self.seed + 16 + 8 * i)
             s_layers.append(s)
         from .ops import conv_rows
@@ -147,8 +163,9 @@ class _TextEncoderRunner:
         C = te.hidden_channels
         grads = {}
         dxb = None
+        dvec = None
         if dxo is None and dx_m is None and (te.mean_only or dx_logs is None):
-            return [None] * len(self.params)
+            return [None] * (len(self.params) + int(self.has_cond))
         from . import wgrad
         with wgrad.WgradQueue(dev, site=te):
             if dx_m is not None:
@@ -164,6 +181,8 @@ class _TextEncoderRunner:
                 dx = torch.zeros(rc.R, C, dtype=torch.float32, device=dev)
             for i in reversed(range(te.encoder.n_layers)):
                 dx, dxb = encoder_impl.layer_bwd(rc, te.encoder, i, s_layers[i], dx, dxb, grads)
+                if i == te.encoder.COND_LAYER and self.has_cond:
+                    dvec = ops.cond_grad(rc, dx, dxb)
             if te.prenet:
                 dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
@@ -172,19 +191,22 @@ class _TextEncoderRunner:
         _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C,
                                       math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_bwd")
         grads[te.emb.weight] = demb
-        return [grads.get(p) for p in self.params]
+        return ([dvec] if self.has_cond else []) + [grads.get(p) for p in self.params]
 
 
 class _DurationRunner:
     """logw = DurationPredictor(x.detach(), x_mask) as one autograd node over its own parameters."""
 
-    def __init__(self, dp, rc, xb, train, seed):
-        self.dp, self.rc, self.xb, self.train, self.seed = dp, rc, xb, train, seed
-        self.params = list(dp.parameters())
+    def __init__(self, dp, rc, xb, train, seed, has_cond=False):
+        self.dp, self.rc, self.xb, self.train, self.seed, self.has_cond = dp, rc, xb, train, seed, has_cond
+        self.params = [p for n, p in dp.named_parameters() if not n.startswith("cond.")]
 
-    def forward(self, *_):
-        out, saved = encoder_impl.dp_fwd(self.rc, self.dp, self.xb, self.train, self.seed)
+    def forward(self, *rest):
         rc = self.rc
+        xb = self.xb
+        if self.has_cond:                                   # x + cond(g), then * x_mask (models.py:587-589, 598)
+            _, xb = ops.rows_add_cond(rc, None, xb, rest[0], want_f32=False)
+        out, saved = encoder_impl.dp_fwd(rc, self.dp, xb, self.train, self.seed)
         logw = rc.from_rows(out)[:, :1].contiguous()                                              # [b,1,t]
         return (logw,), saved
 
@@ -196,8 +218,8 @@ class _DurationRunner:
         dout = rc.to_rows(d8)
         from . import wgrad
         with wgrad.WgradQueue(rc.device, site=self.dp):
-            encoder_impl.dp_bwd(rc, self.dp, saved, dout, grads)
-        return [grads.get(p) for p in self.params]
+            dxb = encoder_impl.dp_bwd(rc, self.dp, saved, dout, grads, want_dx=self.has_cond)
+        return ([ops.cond_grad(rc, dxb)] if self.has_cond else []) + [grads.get(p) for p in self.params]
 
 
 class _LogpMasFn:
@@ -292,28 +314,33 @@ class FlowGenerator(nn.Module):
                  block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False, **kwargs):
         super().__init__()
         from .models import FlowSpecDecoder
-        assert gin_channels == 0 and n_speakers <= 1, "multi-speaker configs (cfg 4/5): next round"
-        self.n_sqz, self.mean_only, self.out_channels = n_sqz, mean_only, out_channels
+        # Multi-speaker configs (cfg 4, configs/base_blank_ms.json: gin_channels=256): the speaker vector enters
+        # forward()/infer() as g [b, gin_channels, 1], i.e. AT the encoder / duration-predictor / decoder boundary
+        # (models.py:1046,1075,1090).  The fork's front end that produces it (emb_g over an external 512-d speaker
+        # embedding concatenated with its emotion/style embeddings, models.py:1007-1044) sits before that boundary.
+        self.n_sqz, self.mean_only, self.out_channels, self.gin_channels = n_sqz, mean_only, out_channels, gin_channels
         self.encoder = TextEncoder(n_vocab, out_channels, hidden_channels_enc or hidden_channels, filter_channels,
                                    filter_channels_dp, n_heads, n_layers_enc, kernel_size, p_dropout, window_size=window_size,
-                                   block_length=block_length, mean_only=mean_only, prenet=prenet, use_sdp=False)
+                                   block_length=block_length, mean_only=mean_only, prenet=prenet, use_sdp=False,
+                                   gin_channels=gin_channels)
         self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec, dilation_rate,
                                        n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec, n_split=n_split, n_sqz=n_sqz,
                                        sigmoid_scale=sigmoid_scale, gin_channels=gin_channels)
         self._step = 0
 
     @torch.no_grad()
-    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0):
+    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0, g=None):
         """Synthesis (reference FlowGenerator.infer, models.py:1122-1232, on the live sub-graph: no speaker / emotion /
         pitch / energy inputs): text -> durations -> expanded prior -> z = z_m + noise -> decoder(reverse=True) -> mel.
         Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)).  The output length is data
         dependent, so this reads the predicted lengths back from the device once."""
         self.prepare()
         ops._HOST_LENGTHS.clear()
-        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
+        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
         rc, xb = self.encoder._last_rows
-        runner = _DurationRunner(self.encoder.proj_w, rc, xb, False, 0)
-        (logw,), _ = runner.forward()
+        dvec = self.encoder.proj_w.cond_vec(g)
+        runner = _DurationRunner(self.encoder.proj_w, rc, xb, False, 0, has_cond=dvec is not None)
+        (logw,), _ = runner.forward(*([dvec] if dvec is not None else []))
         w = torch.exp(logw) * x_mask * length_scale
         w_ceil = torch.ceil(w)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -344,7 +371,7 @@ class FlowGenerator(nn.Module):
             z_logs = z_logs * z_mask
         logw_ = torch.log(1e-8 + torch.sum(attn.squeeze(1), -1)).unsqueeze(1) * x_mask
         z = (z_m + torch.exp(z_logs) * torch.randn_like(z_m) * noise_scale) * z_mask
-        y, logdet = self.decoder(z, z_mask, reverse=True, prepared=True)
+        y, logdet = self.decoder(z, z_mask, g=g, reverse=True, prepared=True)
         return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
 
     def backward_encoder(self):
@@ -374,7 +401,9 @@ class FlowGenerator(nn.Module):
         defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
         decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
         data-parallel trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs."""
-        assert g is None and emo is None and pitch is None and energy is None and l is None, "cfg 4/5 conditioning: next round"
+        assert emo is None and emo_cartesian is None and pitch is None and energy is None and l is None, \
+            "emotion / pitch / energy / language inputs (cfg 5) are not on the round-1 path"
+        assert (g is None) == (self.gin_channels == 0), "g [b, gin_channels, 1] is required exactly when gin_channels != 0"
         self.prepare()
         self._step += 1
         if ops.RAGGED:
@@ -382,7 +411,7 @@ class FlowGenerator(nn.Module):
             ops._HOST_LENGTHS["x"], ops._HOST_LENGTHS["y"] = list(lh[0]), list(lh[1])
         else:
             ops._HOST_LENGTHS.clear()
-        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, prepared=True)
+        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
         self._deferred = []
         if defer_encoder_backward:
             leaf = x_m.detach().requires_grad_(True)
@@ -392,15 +421,17 @@ class FlowGenerator(nn.Module):
                 self._deferred.append((x_logs, leaf)); x_logs = leaf
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
-        z, logdet = self.decoder(y, z_mask, prepared=True)
+        z, logdet = self.decoder(y, z_mask, g=g, prepared=True)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             attn = mas.path.unsqueeze(1)
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         logw_ = torch.log(w + 1e-8) * x_mask
         rc, xb = self.encoder._last_rows
-        runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff)
-        (logw,) = _RowsFn.apply(runner, 1, *runner.params)
+        dvec = self.encoder.proj_w.cond_vec(g)
+        runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff,
+                                 has_cond=dvec is not None)
+        (logw,) = _RowsFn.apply(runner, 1, *([dvec] if dvec is not None else []), *runner.params)
         l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)  # models.py:1089-1092
         z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
         z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)

@@ -279,6 +279,14 @@ int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, 
 int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
                      int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream);
 
+/* out[m,:] = (x[m,:] + cond[utterance(m),:]) * rowmask[m]: a per-utterance vector added to every valid row — the
+ * speaker conditioning the reference broadcasts over time in attentions.py:66-67 (Encoder.cond_g, before layer index 2)
+ * and models.py:587-589 (DurationPredictor.cond).  Source fp32 `x` (wins) or bf16 `xb`; cond [B,C] fp32; fp32 and/or
+ * bf16 output (either may be NULL, in place allowed); halo / padded rows are written as zero.  The gradient of cond is
+ * the per-utterance row sum of the output gradient (gt_colsum). */
+int gt_rows_add_cond(const float* x, int ldx, const void* xb, int ldxb, const float* cond, const float* rowmask,
+                     float* out, int ldo, void* outb, int ldob, int B, int R, int C, int Tp, const int32_t* row0, void* stream);
+
 /* log-likelihood lattice (models.py:1076-1082) on exact-fp32 MFMA: x_m, x_logs (NULL = 0): [B,C,Tx],
  * z: [B,C,Ty] -> logp [B,Tx,Ty] fp32. */
 int gt_logp_f32(const float* x_m, const float* x_logs, const float* z, float* logp, int B, int C, int Tx, int Ty, void* stream);

@@ -102,6 +102,34 @@ def test_encoder_stack_fwd_bwd(built):
         assert grad_ok(prm.grad.cpu(), P["enc." + name].grad, 8e-2, name=name), name
 
 
+def test_encoder_speaker_conditioning_fwd_bwd(built):
+    """Encoder.cond_g (attentions.py:66-67): the speaker vector added before layer index 2 — output, input gradient, the
+    gradient of g and of cond_g's parameters against the oracle (pinned to the reference by float_golden.npz: encg_*)."""
+    from glow_tts_amd import attentions
+    enc = fill_module(attentions.Encoder(192, 768, 2, 3, 3, 0.1, window_size=4, gin_channels=256), "enc.").eval()
+    P = cpu_state(enc, "enc.")
+    T, lens = 41, [41, 17, 30]
+    xm = lens_mask(lens, T)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 192, T, generator=g) * xm
+    spk = torch.randn(3, 256, 1, generator=g)
+    xx, gg = x.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    o = R.encoder_fwd(P, "enc.", xx, xm, g=gg, n_layers=3)
+    o0 = R.encoder_fwd(P, "enc.", x, xm, g=None, n_layers=3)
+    assert relerr(o0.detach(), o.detach()) > 0.05                      # the conditioning matters at these weights
+    r = torch.randn(o.shape, generator=g)
+    (o * r).sum().backward()
+    enc = enc.to(dev())
+    xd, gd = x.to(dev()).requires_grad_(True), spk.to(dev()).requires_grad_(True)
+    od = enc(xd, xm.to(dev()), g=gd)
+    assert relerr(od.detach().cpu(), o.detach()) < 3e-2
+    (od * r.to(dev())).sum().backward()
+    assert relerr(xd.grad.cpu(), xx.grad) < 5e-2
+    assert grad_ok(gd.grad.cpu(), gg.grad, 8e-2), relerr(gd.grad.cpu(), gg.grad)
+    for name, prm in enc.named_parameters():
+        assert grad_ok(prm.grad.cpu(), P["enc." + name].grad, 8e-2, name=name), name
+
+
 def test_logp_kernel(built):
     from glow_tts_amd.text_models import _LogpMasFn
     g = torch.Generator().manual_seed(4)
@@ -124,11 +152,12 @@ HP = dict(hidden_channels=192, n_layers_enc=2, n_heads=2, window_size=4, kernel_
           n_blocks_dec=2, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
 
 
-def _make_generator():
+def _make_generator(n_layers_enc=2, gin_channels=0):
     from glow_tts_amd import models
-    return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1,
+    return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=n_layers_enc, p_dropout=0.1,
                                             n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
-                                            p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True), "").eval()
+                                            p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True,
+                                            gin_channels=gin_channels), "").eval()
 
 
 def test_text_encoder_fwd(built):
@@ -145,17 +174,24 @@ def test_text_encoder_fwd(built):
     assert xld.abs().max().item() == 0
 
 
-@pytest.mark.parametrize("Tx,Ty,xl,yl,ragged", [(21, 64, [21, 12], [64, 37], False), (21, 64, [21, 12], [64, 37], True),
-                                                 (300, 640, [300, 131], [640, 402], True), (300, 640, [300, 131], [640, 402], False)])   # cfg3-like (T_x > 256)
-def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged):
+@pytest.mark.parametrize("Tx,Ty,xl,yl,ragged,gin", [(21, 64, [21, 12], [64, 37], False, 0), (21, 64, [21, 12], [64, 37], True, 0),
+                                                     (300, 640, [300, 131], [640, 402], True, 0),       # cfg3-like (T_x > 256)
+                                                     (300, 640, [300, 131], [640, 402], False, 0),
+                                                     (45, 130, [45, 20], [130, 64], False, 256),        # cfg4-like: speaker vector g
+                                                     (45, 130, [45, 20], [130, 64], True, 256)])
+def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     """Whole hot path: TextEncoder -> decoder -> logp -> MAS -> losses, forward and backward.  The
     alignment is compared on the HIP path's own lattice (bit-exact), then injected into the oracle so
-    that the remaining quantities are comparable.  Uniform and ragged rows layouts; short and cfg3-like lengths."""
+    that the remaining quantities are comparable.  Uniform and ragged rows layouts; short and cfg3-like lengths;
+    with gin: the multi-speaker form (cfg 4), g [b,256,1] into the encoder (3 layers, so that cond_g is reached),
+    the duration predictor and every coupling block."""
     from glow_tts_amd import models, ops
-    gen = _make_generator()
+    gen = _make_generator(3 if gin else 2, gin)
     P = cpu_state(gen)
     g = torch.Generator().manual_seed(7)
     B = 2
+    spk = torch.randn(B, gin, 1, generator=g) if gin else None
+    hp = dict(HP, n_layers_enc=3) if gin else HP
     ids = torch.randint(1, 148, (B, Tx), generator=g); xl = torch.tensor(xl)
     yl = torch.tensor(yl)
     y = torch.randn(B, 80, Ty, generator=g) * lens_mask(yl.tolist(), Ty)
@@ -165,7 +201,7 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged):
     ops.RAGGED = ragged
     try:
         (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
-            gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()))
+            gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=None if spk is None else spk.to(dev()))
     finally:
         ops.RAGGED = False
     l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
@@ -177,7 +213,7 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged):
     p = omas.oracle_maximum_path(gen.last_logp.cpu().numpy(), amask.cpu().numpy())
     assert np.array_equal(attn.squeeze(1).cpu().numpy().astype(np.int32), p)
 
-    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), HP)
+    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), hp, g=spk)
     out["loss"].backward()
     assert relerr(gen.last_logp.cpu(), out["logp"]) < 3e-2
     assert relerr(z.detach().cpu(), out["z"].detach()) < 3e-2

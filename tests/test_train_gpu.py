@@ -200,3 +200,38 @@ def test_trainer_gradients_match_plain_autograd(built):
                 continue
             err = (q.grad - ref).abs().max().item()
             assert err <= 1e-3 * max(1e-6, ref.abs().max().item()) + 1e-6, (seed, n, err)   # atomics: order of the sums differs
+
+
+def test_speaker_conditioned_graph_step_matches_eager(built):
+    """cfg 4 form of the step (gin_channels=256, speaker vectors g [b,256,1] as a fifth static input of the graph):
+    captured and eager trainers give the same updates, and the conditioning parameters (Encoder.cond_g,
+    DurationPredictor.cond, every WN.cond_layer) do get updated."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=3, p_dropout=0.0, p_dropout_dec=0.0, gin_channels=256)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    before = {n: p.detach().clone() for n, p in m1.named_parameters()}
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    spk = torch.randn(4, 256, 1, device=dev())
+    lh = (batch[1].tolist(), batch[3].tolist())
+    t1, t2 = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+    for _ in range(4):
+        l1, _ = t1.step(*batch, lengths_host=lh, g=spk)
+    l2, _ = t2.step(*batch, lengths_host=lh, g=spk)            # 3 warm-ups + 1 replay
+    torch.cuda.synchronize()
+    assert t2.graph_mode and len(t2._captured) == 1
+    assert math.isfinite(l1.item()) and abs(l1.item() - l2.item()) <= 2e-2 * max(1.0, abs(l1.item())), (l1.item(), l2.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst
+    moved = {n for n, p in m1.named_parameters() if (p.detach() - before[n]).abs().max().item() > 0}
+    for key in ("encoder.encoder.cond_g.weight", "encoder.proj_w.cond.weight", "decoder.flows.2.wn.cond_layer.weight_v",
+                "decoder.flows.5.wn.cond_layer.bias"):
+        assert key in moved, key
