@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Glow-TTS training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
 
 One "step" = one full training step of the hot path (zero_grad, TextEncoder + FlowSpecDecoder
 forward, logp + MAS, mle + duration loss, backward, gradient all-reduce, grad-norm, AdamW) on
@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
     "cfg2": dict(B=32, T_x=150, T_y=800, desc="configs/base.json, LJSpeech-shaped synthetic batch, B=32/GPU, T_x<=150, T_y<=800, bf16 GEMMs"),
     "cfg3": dict(B=32, T_x=375, T_y=872, desc="configs/base_blank.json-shaped synthetic batch, B=32/GPU, T_x<=375, T_y<=872, bf16 GEMMs"),
+    "cfg4": dict(B=20, T_x=235, T_y=500, gin=256,
+                 desc="configs/base_blank_ms.json-shaped synthetic batch (multi-speaker, gin_channels=256, g ~ N(0,1) [B,256,1]), "
+                      "B=20/GPU, T_x<=235, T_y<=500, bf16 GEMMs"),
 }
 
 
@@ -112,7 +115,7 @@ def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
     return e0.elapsed_time(e1) / (replays * launches), rc.R
 
 
-def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4):
+def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None):
     """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
     from oracle import glowtts_ref as R
     from oracle import mas as omas
@@ -133,7 +136,7 @@ def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4):
     times = []
     for it in range(2):
         t0 = time.perf_counter()
-        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp)
+        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=None if g is None else g[:n].cpu())
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
         for v in P.values():
@@ -170,13 +173,15 @@ def main():
     _lib.lib()                                       # fails loudly if the HIP library is missing
     wl = WORKLOADS[args.workload]
     torch.manual_seed(1234)                          # identical initial weights on every rank
-    model = train.build_model(device=dev).train()
+    gin = wl.get("gin", 0)
+    model = train.build_model(dict(train.BASE_MODEL, gin_channels=gin) if gin else None, device=dev).train()
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
     use_graph = not args.no_graph
     tr = train.Trainer(model, world=world, graph=use_graph)
     ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
+    spk = torch.randn(wl["B"], gin, 1, generator=torch.Generator().manual_seed(4321 + rank)).to(dev) if gin else None
     lh = (t_x.tolist(), t_y.tolist())                # host copy of the lengths (a data loader has them): no per-step sync
     valid_frames = int(t_y.sum().item())
     padded_frames = wl["B"] * wl["T_y"]
@@ -187,13 +192,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        tr.step(ids, t_x, y, t_y, lengths_host=lh)
+        tr.step(ids, t_x, y, t_y, lengths_host=lh, g=spk)
     barrier()
     if not use_graph:
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")  # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh)
+        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh, g=spk)
     barrier()
     wall = time.perf_counter() - t0
     if use_graph:
@@ -202,7 +207,7 @@ def main():
         # (same process, same stream, same data), with HIP events around each of its 48 launches per step.
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")
         for _ in range(3):
-            tr._step_impl(ids, t_x, y, t_y, lh)
+            tr._step_impl(ids, t_x, y, t_y, lh, g=spk)
     kt = ops.KERNEL_TIMER.collect()
     if world > 1:
         t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)
@@ -264,7 +269,7 @@ def main():
                                     "frac": m["hbm_frac"], "traffic": None, "kernel": "gt_mas_dp_kernel + gt_mas_expand_kernel",
                                     "algorithmic_bytes_per_launch": m["algorithmic_bytes"]}}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model)
+            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model, g=spk)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -21,7 +21,7 @@ def _wn_cond(wn, g):
     cl = wn.cond_layer
     v = cl.weight_v
     w = v * (cl.weight_g / v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, 1, 1))
-    return torch.nn.functional.conv1d(g, w, cl.bias).squeeze(-1).contiguous()
+    return torch.nn.functional.linear(g.squeeze(-1), w.squeeze(-1), cl.bias)     # (a matmul: MIOpen's 1x1 conv path is slow here)
 
 
 class CouplingBlock(nn.Module):

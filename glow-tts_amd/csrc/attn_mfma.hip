@@ -340,104 +340,193 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
       for (int e = 0; e < 4; ++e) doe[r * NW + e + 4 * hh] = acc[e];
       if (hh == 0) doe[r * NW + 8] = acc[4];
     }
-    f32x16_t s[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 6; ++ks) {
-        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], s[t], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-
     const float inv_sqrt = rsqrtf((float)D);
     const float* prow = P + (((size_t)b * H + h) * T + ic) * T;
     const uint32_t drow = (uint32_t)((b * H + h) * T + i);
     const bool vec = (T & 3) == 0;
-    // pass A: dP in place, Dsum
-    float dsum = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j0 = 32 * t + 8 * g + 4 * hh;
-        float p4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
-        else {
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
-        }
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          const int j = j0 + e2;
-          float dp = s[t][4 * g + e2];
-          const int rel = j - i + WIN;
-          if ((unsigned)rel <= 2u * WIN) dp += doe[r * NW + rel];
-          if (drop_thresh) dp = drop_keep(drop_seed, drow, j, drop_thresh) ? dp * drop_scale : 0.f;
-          if (j >= T) dp = 0.f;
-          s[t][4 * g + e2] = dp;
-          dsum += dp * p4[e2];
-        }
-      }
-    dsum += __shfl_xor(dsum, 32);
-    // pass B: dS in place; write dS^T, dropout(P)^T and the band tables
     bf16_t* dst_base = dST + ((size_t)b * H + h) * T * TI;
     bf16_t* pdt_base = PdT + ((size_t)b * H + h) * T * TI;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j0 = 32 * t + 8 * g + 4 * hh;
-        float p4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
-        else {
-#pragma unroll
-          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
-        }
-#pragma unroll
-        for (int e2 = 0; e2 < 4; ++e2) {
-          const int j = j0 + e2;
-          float ds = p4[e2] * (s[t][4 * g + e2] - dsum) * inv_sqrt;
-          float pd = p4[e2];
-          if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
-          if (j >= T || j >= len || i >= len || i >= T) ds = 0.f;          // masked_fill blocks the gradient
-          if (i >= len || i >= T) pd = 0.f;                                // padded queries carry no upstream gradient
-          s[t][4 * g + e2] = ds;
-          if (j < T) {
-            dst_base[(size_t)j * TI + i] = f2bf(ds);
-            pdt_base[(size_t)j * TI + i] = f2bf(pd);
-            const int rel = j - i + WIN;
-            if ((unsigned)rel <= 2u * WIN) { const bf16_t db = f2bf(ds); dSB[r * 16 + rel] = db; dSBT[rel * BTP + r] = db; PdBT[rel * BTP + r] = f2bf(pd); }
-          }
-        }
-      }
-    __builtin_amdgcn_wave_barrier();
-
-    // dQ^T = K^T dS^T + Ek^T band(dS)^T
     f32x16_t o[3];
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     }
+    if constexpr (NT > 5) {
+      // 161 <= T <= 256: holding all NT score tiles of a wave (NT*16 accumulators) next to P and the dropout masks does
+      // not fit the register file.  One tile at a time instead: pass A walks the key tiles for Dsum only, pass B
+      // RECOMPUTES each tile's dPd^T (6 MFMAs, operands already in LDS / registers), turns it into dS^T, stores it and
+      // feeds dQ^T straight away — live state is one tile + the dQ^T accumulators, whatever NT is.
+      auto dp_tile = [&](int t, f32x16_t& st) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        float f8[8];
+        for (int ks = 0; ks < 6; ++ks) {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], st, 0, 0, 0);
+        }
+      };
+      auto load_p4 = [&](int j0, float* p4) {
+        p4[0] = p4[1] = p4[2] = p4[3] = 0.f;
+        if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
+        else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f8[e] = s[t][8 * s2 + e];
-        const bf16x8_t pf = pack8(f8);
+          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
+        }
+      };
+      auto dp_elem = [&](float dp, int j) {
+        const int rel = j - i + WIN;
+        if ((unsigned)rel <= 2u * WIN) dp += doe[r * NW + rel];
+        if (drop_thresh) dp = drop_keep(drop_seed, drow, j, drop_thresh) ? dp * drop_scale : 0.f;
+        return j >= T ? 0.f : dp;
+      };
+      __builtin_amdgcn_wave_barrier();
+      float dsum = 0.f;
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        if (32 * t >= T) break;                                      // wave-uniform
+        f32x16_t st;
+        dp_tile(t, st);
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-          const bf16_t* ka = Ks + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
-          const bf16x8_t af = tr_frag8(ka, ka + 8 * VP);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          const int j0 = 32 * t + 8 * g + 4 * hh;
+          float p4[4];
+          load_p4(j0, p4);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) dsum += dp_elem(st[4 * g + e2], j0 + e2) * p4[e2];
         }
       }
+      dsum += __shfl_xor(dsum, 32);
+#pragma unroll 1
+      for (int t = 0; t < NT; ++t) {
+        if (32 * t >= T) break;
+        f32x16_t st;
+        dp_tile(t, st);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j0 = 32 * t + 8 * g + 4 * hh;
+          float p4[4];
+          load_p4(j0, p4);
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int j = j0 + e2;
+            float ds = p4[e2] * (dp_elem(st[4 * g + e2], j) - dsum) * inv_sqrt;
+            float pd = p4[e2];
+            if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
+            if (j >= T || j >= len || i >= len || i >= T) ds = 0.f;          // masked_fill blocks the gradient
+            if (i >= len || i >= T) pd = 0.f;                                // padded queries carry no upstream gradient
+            st[4 * g + e2] = ds;
+            if (j < T) {
+              dst_base[(size_t)j * TI + i] = f2bf(ds);
+              pdt_base[(size_t)j * TI + i] = f2bf(pd);
+              const int rel = j - i + WIN;
+              if ((unsigned)rel <= 2u * WIN) { const bf16_t db = f2bf(ds); dSB[r * 16 + rel] = db; dSBT[rel * BTP + r] = db; PdBT[rel * BTP + r] = f2bf(pd); }
+            }
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float f8[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f8[e] = st[8 * s2 + e];
+          const bf16x8_t pf = pack8(f8);
+#pragma unroll
+          for (int dt = 0; dt < 3; ++dt) {
+            const bf16_t* ka = Ks + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+            const bf16x8_t af = tr_frag8(ka, ka + 8 * VP);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      f32x16_t s[NT];
+  #pragma unroll
+      for (int t = 0; t < NT; ++t) {
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+  #pragma unroll
+        for (int ks = 0; ks < 6; ++ks) {
+          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], s[t], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // pass A: dP in place, Dsum
+      float dsum = 0.f;
+  #pragma unroll
+      for (int t = 0; t < NT; ++t)
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j0 = 32 * t + 8 * g + 4 * hh;
+          float p4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
+          else {
+  #pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
+          }
+  #pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int j = j0 + e2;
+            float dp = s[t][4 * g + e2];
+            const int rel = j - i + WIN;
+            if ((unsigned)rel <= 2u * WIN) dp += doe[r * NW + rel];
+            if (drop_thresh) dp = drop_keep(drop_seed, drow, j, drop_thresh) ? dp * drop_scale : 0.f;
+            if (j >= T) dp = 0.f;
+            s[t][4 * g + e2] = dp;
+            dsum += dp * p4[e2];
+          }
+        }
+      dsum += __shfl_xor(dsum, 32);
+      // pass B: dS in place; write dS^T, dropout(P)^T and the band tables
+  #pragma unroll
+      for (int t = 0; t < NT; ++t)
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int j0 = 32 * t + 8 * g + 4 * hh;
+          float p4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (vec && j0 + 3 < T) { const float4 pv = *reinterpret_cast<const float4*>(prow + j0); p4[0] = pv.x; p4[1] = pv.y; p4[2] = pv.z; p4[3] = pv.w; }
+          else {
+  #pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) p4[e2] = prow[j0 + e2];
+          }
+  #pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const int j = j0 + e2;
+            float ds = p4[e2] * (s[t][4 * g + e2] - dsum) * inv_sqrt;
+            float pd = p4[e2];
+            if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
+            if (j >= T || j >= len || i >= len || i >= T) ds = 0.f;          // masked_fill blocks the gradient
+            if (i >= len || i >= T) pd = 0.f;                                // padded queries carry no upstream gradient
+            s[t][4 * g + e2] = ds;
+            if (j < T) {
+              dst_base[(size_t)j * TI + i] = f2bf(ds);
+              pdt_base[(size_t)j * TI + i] = f2bf(pd);
+              const int rel = j - i + WIN;
+              if ((unsigned)rel <= 2u * WIN) { const bf16_t db = f2bf(ds); dSB[r * 16 + rel] = db; dSBT[rel * BTP + r] = db; PdBT[rel * BTP + r] = f2bf(pd); }
+            }
+          }
+        }
+      __builtin_amdgcn_wave_barrier();
+
+      // dQ^T = K^T dS^T + Ek^T band(dS)^T
+  #pragma unroll
+      for (int t = 0; t < NT; ++t)
+  #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float f8[8];
+  #pragma unroll
+          for (int e = 0; e < 8; ++e) f8[e] = s[t][8 * s2 + e];
+          const bf16x8_t pf = pack8(f8);
+  #pragma unroll
+          for (int dt = 0; dt < 3; ++dt) {
+            const bf16_t* ka = Ks + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+            const bf16x8_t af = tr_frag8(ka, ka + 8 * VP);
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+          }
+        }
+    }
     {
       const bf16x8_t bfp = *reinterpret_cast<const bf16x8_t*>(dSB + r * 16 + 8 * hh);
 #pragma unroll
@@ -605,11 +694,8 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   bf16_t* w16 = static_cast<bf16_t*>(ws);
   bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
   if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
-  // 161 <= T <= 256: the 8-key-tile backward (2 waves per workgroup, 153 KB of LDS, register spills) raised a memory
-  // access fault on MI355X once q / k / v became windows of one [R, 3C] buffer (tools/dbg_mha200.py reproduces it under
-  // AMD_SERIALIZE_KERNEL=3); until that is understood the generic kernels take these lengths (cfg2 has T_x <= 150).
-  static const bool bwd8 = getenv("GT_ATTN_BWD8") != nullptr;
-  if (!bwd8) return 1;
+  // 161 <= T <= 256: 8 key tiles, 2 waves per workgroup (153 KB of LDS), one score tile live at a time (recompute form:
+  // the first version kept all 8 tiles in registers, needed scratch and faulted — see DESIGN.md §4.5)
   return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }
 

@@ -436,6 +436,33 @@ __global__ __launch_bounds__(256) void gt_rows_add_cond_kernel(const float* __re
   }
 }
 
+// out[b, c] (+)= sum over the rows m of utterance b of y[m, c] * rowmask[m]: the gradient of a per-utterance vector
+// (gt_rows_add_cond; the cond input of the WN gate, modules.py:148-156).  One workgroup per (utterance, 64 channels):
+// waves stride the rows, lanes own channels, one LDS fold — no atomics.
+template <bool F32>
+__global__ __launch_bounds__(256) void gt_rows_utt_sum_kernel(const void* __restrict__ y, int ldy, const float* __restrict__ rowmask,
+                                                              float* __restrict__ out, int ldo, int accumulate,
+                                                              int B, int C, int Tp, const int32_t* __restrict__ row0)
+{
+  __shared__ float part[4][64];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int base = gt_row_base(row0, b, Tp), cnt = gt_row_count(row0, b, Tp);
+  float acc = 0.f;
+  if (c < C)
+    for (int t = w; t < cnt; t += 4) {
+      const size_t m = (size_t)(base + t);
+      const float k = rowmask ? rowmask[m] : 1.f;
+      if (k != 0.f) acc += k * (F32 ? static_cast<const float*>(y)[m * ldy + c] : bf2f(static_cast<const bf16_t*>(y)[m * ldy + c]));
+    }
+  part[w][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const float s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    float* o = out + (size_t)b * ldo + c;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
 // ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
 // logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
 //               + sum_d -0.5 m_id^2 e^{-2 s_id}
@@ -700,6 +727,16 @@ extern "C" int gt_rows_add_cond(const float* x, int ldx, const void* xb, int ldx
   if (!row0 && R != B * Tp) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_rows_add_cond_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), x, ldx, static_cast<const bf16_t*>(xb), ldxb,
                      cond, rowmask, out, ldo, static_cast<bf16_t*>(outb), ldob, B, R, C, Tp, row0);
+  GT_RET();
+}
+extern "C" int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* rowmask, float* out, int ldo, int accumulate,
+                              int B, int R, int C, int Tp, const int32_t* row0, void* stream)
+{
+  if (!y || !out || B <= 0 || R <= 0 || C <= 0 || ldy < C || ldo < C) return GT_E_INVAL;
+  if (!row0 && R != B * Tp) return GT_E_INVAL;
+  const dim3 grid(B, (C + 63) / 64);
+  if (is_f32) hipLaunchKernelGGL(gt_rows_utt_sum_kernel<true>, grid, dim3(256), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
+  else        hipLaunchKernelGGL(gt_rows_utt_sum_kernel<false>, grid, dim3(256), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

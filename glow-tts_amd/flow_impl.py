@@ -145,7 +145,7 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
     dev = dskip.device
     n = wn.n_layers
     grads = {}
-    dcond = None if not want_dcond else torch.zeros(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    dcond = None if not want_dcond else torch.empty(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
     dres = None             # gradient arriving at x_{i+1} (masked), i.e. at res_i's output
@@ -175,7 +175,7 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre
-            dcond[:, 2 * H * i:2 * H * (i + 1)] = rc.batch_sum(src.float())
+            rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
         # d x_i = dgrad(in_layer) + (residual path), then through the mask of x_i's producer
         dres = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=dres, mask=True)
     return dres, grads, dcond

@@ -139,8 +139,11 @@ def cond_grad(rc, *row_grads):
     for d in row_grads:
         if d is None:
             continue
-        s = rc.batch_sum(d.float() * rc.rowmask[:, None])
-        tot = s if tot is None else tot + s
+        if tot is None:
+            tot = torch.empty(rc.B, d.shape[1], dtype=torch.float32, device=d.device)
+            rc.utt_sum(d, tot)
+        else:
+            rc.utt_sum(d, tot, accumulate=True)
     return tot
 
 
@@ -207,6 +210,18 @@ class RowsCtx:
         self.rowbatch.copy_(torch.searchsorted(self.row0[1:].contiguous(), m, right=True).clamp_(max=self.B - 1))
         self.rowframe.copy_(m - self.row0[:-1][self.rowbatch] - HALO)
         self.rowmask.copy_(((self.rowframe >= 0) & (self.rowframe < self.lengths[self.rowbatch])).to(torch.float32))
+
+    def utt_sum(self, rows, out, accumulate=False, masked=True):
+        """out[b, :] (+)= sum of the (valid) rows of utterance b; rows bf16 or fp32 [R, C] (a column slice is fine),
+        out fp32 [B, C] (a column slice is fine) — gt_rows_utt_sum."""
+        L = _lib.lib()
+        C = rows.shape[1]
+        assert rows.stride(1) == 1 and out.stride(1) == 1 and out.shape == (self.B, C) and out.dtype == torch.float32
+        _lib.check(L.gt_rows_utt_sum(_lib.ptr(rows), rows.stride(0), int(rows.dtype == torch.float32),
+                                     _lib.ptr(self.rowmask) if masked else None, _lib.ptr(out), out.stride(0), int(accumulate),
+                                     self.B, self.R, C, self.Tp, _lib.ptr(self.row0), _lib.current_stream(rows.device)),
+                   "gt_rows_utt_sum")
+        return out
 
     def batch_sum(self, rows):
         """[R, C] -> [B, C]: sum over the rows of each utterance."""

@@ -283,9 +283,16 @@ int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, f
  * speaker conditioning the reference broadcasts over time in attentions.py:66-67 (Encoder.cond_g, before layer index 2)
  * and models.py:587-589 (DurationPredictor.cond).  Source fp32 `x` (wins) or bf16 `xb`; cond [B,C] fp32; fp32 and/or
  * bf16 output (either may be NULL, in place allowed); halo / padded rows are written as zero.  The gradient of cond is
- * the per-utterance row sum of the output gradient (gt_colsum). */
+ * the per-utterance row sum of the output gradient (gt_rows_utt_sum). */
 int gt_rows_add_cond(const float* x, int ldx, const void* xb, int ldxb, const float* cond, const float* rowmask,
                      float* out, int ldo, void* outb, int ldob, int B, int R, int C, int Tp, const int32_t* row0, void* stream);
+
+/* out[b, :C] (+)= sum over the rows m of utterance b of y[m, :C] * rowmask[m] (rowmask NULL = 1): the gradient of a
+ * per-utterance vector broadcast over time — gt_rows_add_cond's cond, and the speaker conditioning g_l that WN adds
+ * inside the gate (modules.py:148-156).  y bf16 (is_f32 == 0) or fp32 rows; out [B, ldo] fp32; accumulate != 0 adds to
+ * out.  No atomics: one workgroup per (utterance, 64 channels). */
+int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* rowmask, float* out, int ldo, int accumulate,
+                    int B, int R, int C, int Tp, const int32_t* row0, void* stream);
 
 /* log-likelihood lattice (models.py:1076-1082) on exact-fp32 MFMA: x_m, x_logs (NULL = 0): [B,C,Tx],
  * z: [B,C,Ty] -> logp [B,Tx,Ty] fp32. */

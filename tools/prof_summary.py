@@ -7,7 +7,7 @@ top = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("--")
 out_csv = sys.argv[sys.argv.index("--csv") + 1] if "--csv" in sys.argv else None
 
 rows = []
-dbs = glob.glob(d + "/*.db")
+dbs = glob.glob(d + "/**/*.db", recursive=True)
 f = [] if dbs else glob.glob(d + "/**/*kernel_stats.csv", recursive=True)
 if f:
     for r in csv.DictReader(open(f[0])):
