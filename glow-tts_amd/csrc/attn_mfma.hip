@@ -238,6 +238,229 @@ int launch_fwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   return gt_launch_status(__func__);
 }
 
+// -----------------------------------------------------------------------------------------
+// Long sequences (256 < T <= 384: configs/base_blank.json interleaves blanks, T_x <= 375).  K and V no longer fit the
+// LDS together and NT score tiles no longer fit the register file, so: V stays in LDS (it is read through transposing
+// reads), K fragments (plain row reads) come straight from L2 with a one-tile register prefetch, and the wave walks the
+// key tiles twice — pass 1 an online max / denominator, pass 2 recomputes each tile's scores, normalises, writes P and
+// feeds O^T at once.  Live state: one tile + the O^T accumulators, whatever NT is.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void gt_attn_fwd_mfma_long_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
+    const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
+    bf16_t* __restrict__ out, int ldo, float* __restrict__ Pout,
+    int T, int Tp, const int32_t* row0, int H, uint32_t drop_thresh, uint32_t drop_seed, float drop_scale, const uint32_t* __restrict__ seed_dev)
+{
+  if (seed_dev) drop_seed ^= *seed_dev;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int TPAD = NT * 32;
+  bf16_t* Vs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][VP]
+  bf16_t* Eks = Vs + TPAD * VP;                                  // [32][KP]   rows >= 9 are zero
+  bf16_t* EvT = Eks + 32 * KP;                                   // [96][16]   EvT[d][r], r >= 9 zero
+  float*  QE  = reinterpret_cast<float*>(EvT + D * 16);          // [4 waves][32][NW]
+  bf16_t* PB  = reinterpret_cast<bf16_t*>(QE + 4 * 32 * NW);     // [4 waves][32][16]
+
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int len = lens[b];
+  const size_t rbase = (size_t)gt_row_base(row0, b, Tp) + HALO;
+  const int nv1 = gt_row_count(row0, b, Tp) - HALO - 1;          // see gt_attn_fwd_mfma_kernel
+  auto RW = [&](int t) { return rbase + (size_t)(t < nv1 ? t : nv1); };
+
+  for (int i = tid; i < TPAD * (D / 8); i += 256) {
+    const int j = i / (D / 8), c8 = i - j * (D / 8);
+    uint4 vv = make_uint4(0, 0, 0, 0);
+    if (j < T) vv = *reinterpret_cast<const uint4*>(v + RW(j) * ld + h * D + c8 * 8);
+    *reinterpret_cast<uint4*>(Vs + j * VP + c8 * 8) = vv;
+  }
+  for (int i = tid; i < 32 * D; i += 256) { const int rr = i / D, c = i - rr * D; Eks[rr * KP + c] = rr < NW ? f2bf(Ek[rr * D + c]) : (bf16_t)0; }
+  for (int i = tid; i < D * 16; i += 256) { const int d = i >> 4, rr = i & 15; EvT[i] = rr < NW ? f2bf(Ev[rr * D + d]) : (bf16_t)0; }
+  for (int i = tid; i < 4 * 32 * 16; i += 256) PB[i] = 0;
+  __syncthreads();
+
+  const int i0 = blockIdx.x * 128 + 32 * w;
+  if (i0 >= T) return;                                           // wave-uniform, after the only block barrier
+  const int i = i0 + r;
+  const int ic = i < T ? i : T - 1;
+  float* qe = QE + w * 32 * NW;
+  bf16_t* pb = PB + w * 32 * 16;
+
+  bf16x8_t qf[6];
+#pragma unroll
+  for (int ks = 0; ks < 6; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(q + RW(ic) * ld + h * D + ks * 16 + 8 * hh);
+  {
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Eks + r * KP + ks * 16 + 8 * hh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qf[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) qe[r * NW + e + 4 * hh] = acc[e];
+    if (hh == 0) qe[r * NW + 8] = acc[4];
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  const int nt = (T + 31) >> 5;                                  // key tiles that hold keys (wave-uniform)
+  const float inv_sqrt = rsqrtf((float)D);
+  // K fragments of key tile t: lane (key r of the tile, k-half hh); rows >= T are zero
+  auto load_k = [&](int t, bf16x8_t* kf) {
+    const int j = 32 * t + r;
+    if (j < T) {
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) kf[ks] = *reinterpret_cast<const bf16x8_t*>(k + RW(j) * ld + h * D + ks * 16 + 8 * hh);
+    } else {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 6; ++ks) kf[ks] = __builtin_bit_cast(bf16x8_t, z);
+    }
+  };
+  // masked, scaled scores of one tile (element e <-> key 32t + (e&3) + 8(e>>2) + 4hh)
+  auto scores = [&](int t, const bf16x8_t* kf, f32x16_t& st) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], st, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int j = 32 * t + (e & 3) + 8 * (e >> 2) + 4 * hh;
+      float sc = st[e];
+      const int rel = j - i + WIN;
+      if ((unsigned)rel <= 2u * WIN) sc += qe[r * NW + rel];
+      sc *= inv_sqrt;
+      if (j >= T) sc = -3.0e38f;                                 // not a key at all
+      else if (j >= len || i >= len) sc = -1e4f;                 // masked_fill(mask == 0, -1e4), attentions.py:260
+      st[e] = sc;
+    }
+  };
+
+  // ---- pass 1: online max / denominator over this lane's keys, then the two lane halves are merged
+  float mx = -3.0e38f, den = 0.f;
+  bf16x8_t kf[6], kn[6];
+  load_k(0, kf);
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) load_k(t + 1, kn);
+    f32x16_t st;
+    scores(t, kf, st);
+    float tm = st[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) tm = fmaxf(tm, st[e]);
+    const float mn = fmaxf(mx, tm);
+    float add = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) add += __expf(st[e] - mn);
+    den = den * __expf(mx - mn) + add;
+    mx = mn;
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) kf[ks] = kn[ks];
+  }
+  {
+    const float mo = __shfl_xor(mx, 32), dn = __shfl_xor(den, 32);
+    const float mm = fmaxf(mx, mo);
+    den = den * __expf(mx - mm) + dn * __expf(mo - mm);
+    mx = mm;
+  }
+  const float rden = 1.0f / den;
+
+  // ---- pass 2: P = softmax, dropout, O^T = V^T P^T (+ Ev^T band(P)^T)
+  float* prow = Pout + (((size_t)b * H + h) * T + ic) * T;
+  const uint32_t drow = (uint32_t)((b * H + h) * T + i);
+  const int li = lane & 15, qd = li >> 2, pp = li & 3, colhalf = ((lane >> 4) & 1) * 16;
+  const bool vec = (T & 3) == 0;
+  f32x16_t o[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+  }
+  load_k(0, kf);
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) load_k(t + 1, kn);
+    f32x16_t st;
+    scores(t, kf, st);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j0 = 32 * t + 8 * g + 4 * hh;
+      float p4[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) p4[e2] = __expf(st[4 * g + e2] - mx) * rden;
+      if (i < T) {
+        if (vec && j0 + 3 < T) *reinterpret_cast<float4*>(prow + j0) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+        else {
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) if (j0 + e2 < T) prow[j0 + e2] = p4[e2];
+        }
+      }
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int j = j0 + e2;
+        float pd = p4[e2];
+        if (drop_thresh) pd = drop_keep(drop_seed, drow, j, drop_thresh) ? pd * drop_scale : 0.f;
+        st[4 * g + e2] = pd;
+        const int rel = j - i + WIN;
+        if ((unsigned)rel <= 2u * WIN && j < T) pb[r * 16 + rel] = f2bf(pd);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float f8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f8[e] = st[8 * s2 + e];
+      const bf16x8_t pf = pack8(f8);
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        const bf16_t* va = Vs + (32 * t + 16 * s2 + 4 * hh + qd) * VP + 32 * dt + colhalf + 4 * pp;
+        const bf16x8_t af = tr_frag8(va, va + 8 * VP);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pf, o[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) kf[ks] = kn[ks];
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    const bf16x8_t bfp = *reinterpret_cast<const bf16x8_t*>(pb + r * 16 + 8 * hh);      // band(P)^T: k = rel
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(EvT + (32 * dt + r) * 16 + 8 * hh);
+      o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfp, o[dt], 0, 0, 0);
+    }
+  }
+  if (i < T && i <= nv1) {
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 32 * dt + 8 * g + 4 * hh;
+        *reinterpret_cast<uint2*>(out + (rbase + i) * ldo + h * D + d) =
+            make_uint2(pack2bf(o[dt][4 * g], o[dt][4 * g + 1]), pack2bf(o[dt][4 * g + 2], o[dt][4 * g + 3]));
+      }
+  }
+}
+
+template <int NT>
+int launch_fwd_long(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
+                    bf16_t* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
+{
+  constexpr int TPAD = NT * 32;
+  const size_t lds = (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 4 * 32 * NW * 4 + 4 * 32 * 16 * 2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_fwd_mfma_long_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return GT_E_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gt_attn_fwd_mfma_long_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds, st,
+                     q, k, v, ld, Ek, Ev, lens, out, ldo, P, T, Tp, row0, H, th, sd, sc, seed_dev);
+  return gt_launch_status(__func__);
+}
+
 // =========================================================================================
 // Backward.  Pass 1 (per 32-query block, same wave/lane mapping as the forward):
 //   dPd^T = V dO^T (+ band: Ev dO^T)      dP = dropout'(dPd)       Dsum_i = sum_j dP P
@@ -261,8 +484,9 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
   if (seed_dev) drop_seed ^= *seed_dev;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TPAD = NT * 32, NTH = 64 * WV;
-  bf16_t* Vs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]  A of dPd^T (ds_read_b128)
-  bf16_t* Ks  = Vs + TPAD * KP;                                  // [TPAD][VP]  A of dQ^T (transposing reads)
+  constexpr bool VG = NT > 8;                                    // long sequences: V rows (plain row reads) come from L2, not LDS
+  bf16_t* Vs  = reinterpret_cast<bf16_t*>(smem);                 // [TPAD][KP]  A of dPd^T (ds_read_b128); absent if VG
+  bf16_t* Ks  = Vs + (VG ? 0 : TPAD * KP);                       // [TPAD][VP]  A of dQ^T (transposing reads)
   bf16_t* Evs = Ks + TPAD * VP;                                  // [32][KP]    rows >= 9 zero
   bf16_t* EkT = Evs + 32 * KP;                                   // [96][16]
   float*  Acc = reinterpret_cast<float*>(EkT + D * 16);          // [2][NW][D]  block-local dEk | dEv
@@ -285,10 +509,10 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
     uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
     if (j < T) {
       kk = *reinterpret_cast<const uint4*>(k + RW(j) * ld + h * D + c8 * 8);
-      vv = *reinterpret_cast<const uint4*>(v + RW(j) * ld + h * D + c8 * 8);
+      if (!VG) vv = *reinterpret_cast<const uint4*>(v + RW(j) * ld + h * D + c8 * 8);
     }
     *reinterpret_cast<uint4*>(Ks + j * VP + c8 * 8) = kk;
-    *reinterpret_cast<uint4*>(Vs + j * KP + c8 * 8) = vv;
+    if (!VG) *reinterpret_cast<uint4*>(Vs + j * KP + c8 * 8) = vv;
   }
   for (int i = tid; i < 32 * D; i += NTH) { const int rr = i / D, c = i - rr * D; Evs[rr * KP + c] = rr < NW ? f2bf(Ev[rr * D + c]) : (bf16_t)0; }
   for (int i = tid; i < D * 16; i += NTH) { const int d = i >> 4, rr = i & 15; EkT[i] = rr < NW ? f2bf(Ek[rr * D + d]) : (bf16_t)0; }
@@ -362,7 +586,14 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 6; ++ks) {
-          const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
+          bf16x8_t af;
+          if (VG) {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            af = 32 * t + r < T ? *reinterpret_cast<const bf16x8_t*>(v + RW(32 * t + r) * ld + h * D + ks * 16 + 8 * hh)
+                                : __builtin_bit_cast(bf16x8_t, z);
+          } else {
+            af = *reinterpret_cast<const bf16x8_t*>(Vs + (32 * t + r) * KP + ks * 16 + 8 * hh);
+          }
           st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dof[ks], st, 0, 0, 0);
         }
       };
@@ -655,7 +886,7 @@ int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   const int TI = ((T + 31) / 32) * 32;
   bf16_t* dST = ws;
   bf16_t* PdT = ws + (size_t)B * H * T * TI;
-  const size_t lds1 = (size_t)TPAD * KP * 2 + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 2 * NW * D * 4 +
+  const size_t lds1 = (NT > 8 ? 0 : (size_t)TPAD * KP * 2) + (size_t)TPAD * VP * 2 + 32 * KP * 2 + D * 16 * 2 + 2 * NW * D * 4 +
                       (size_t)WV * 32 * NW * 4 + (size_t)WV * WBN * 2;
   const size_t lds2 = (size_t)2 * TPAD * VP * 2;
   static bool attr = false;
@@ -685,7 +916,7 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
                           void* dq, void* dk, void* dv, int lddq, float* dEk, float* dEv,
                           int B, int T, int Tp, const int32_t* row0, int H, int Dh, int win, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
-  if (Dh != D || win != WIN || T > 256 || (ld & 7) || (lddo & 7) || (lddq & 3)) return 1;
+  if (Dh != D || win != WIN || T > 384 || (ld & 7) || (lddo & 7) || (lddq & 3)) return 1;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)ws) & 15) return 1;
   if (ws_bytes < gt_attn_bwd_mfma_ws_bytes(B, T, H)) return 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -696,7 +927,9 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
   // 161 <= T <= 256: 8 key tiles, 2 waves per workgroup (153 KB of LDS), one score tile live at a time (recompute form:
   // the first version kept all 8 tiles in registers, needed scratch and faulted — see DESIGN.md §4.5)
-  return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  if (T <= 256) return launch_bwd<8, 2>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  // 257 <= T <= 384 (cfg3): 12 key tiles; K^T (transposing reads) stays in LDS, the V rows come from L2
+  return launch_bwd<12, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
@@ -704,11 +937,12 @@ int gt_attn_fwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
                           const int32_t* lens, void* out, int ldo, float* P, int B, int T, int Tp, const int32_t* row0, int H, int Dh, int win,
                           uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, void* stream)
 {
-  if (Dh != D || win != WIN || T > 256 || (ld & 7) || (ldo & 3)) return 1;
+  if (Dh != D || win != WIN || T > 384 || (ld & 7) || (ldo & 3)) return 1;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bf16_t* qq = static_cast<const bf16_t*>(q); const bf16_t* kk = static_cast<const bf16_t*>(k); const bf16_t* vv = static_cast<const bf16_t*>(v);
   bf16_t* oo = static_cast<bf16_t*>(out);
   if (T <= 160) return launch_fwd<5>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
-  return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  if (T <= 256) return launch_fwd<8>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
+  return launch_fwd_long<12>(qq, kk, vv, ld, Ek, Ev, lens, oo, ldo, P, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
 }

@@ -53,7 +53,9 @@ def cpu_state(mod, prefix=""):
     return P
 
 
-@pytest.mark.parametrize("T", [3, 5, 37, 150, 200, 300, 375])   # <= 160 / <= 256: MFMA kernels (5 / 8 key tiles); above: the generic kernel (cfg3: T_x <= 375)
+# MFMA kernels: <= 160 (5 key tiles in registers), <= 256 (8 tiles; backward one tile at a time), <= 384 (12 tiles, one
+# operand from L2; cfg3: T_x <= 375); above that the generic kernels (400)
+@pytest.mark.parametrize("T", [3, 5, 37, 150, 161, 200, 256, 257, 300, 375, 384, 400])
 def test_mha_fwd_bwd(built, T):
     from glow_tts_amd import attentions
     att = fill_module(attentions.MultiHeadAttention(192, 192, 2, window_size=4, p_dropout=0.1), "mha.").eval()
