@@ -24,6 +24,19 @@ def _wn_cond(wn, g):
     return torch.nn.functional.linear(g.squeeze(-1), w.squeeze(-1), cl.bias)     # (a matmul: MIOpen's 1x1 conv path is slow here)
 
 
+def _wn_cond_all(wns, g):
+    """_wn_cond for every coupling block of the decoder at once: one batched [n, B, gin] x [n, gin, 2*H*layers]
+    product instead of n small ones (same arithmetic; ~10x fewer launches in the step)."""
+    if g is None:
+        return [None] * len(wns)
+    v = torch.stack([w.cond_layer.weight_v.squeeze(-1) for w in wns])          # [n, O, gin]
+    gg = torch.stack([w.cond_layer.weight_g.reshape(-1) for w in wns])         # [n, O]
+    bias = torch.stack([w.cond_layer.bias for w in wns])                       # [n, O]
+    w = v * (gg / v.norm(dim=2)).unsqueeze(-1)
+    out = torch.einsum("bg,nog->nbo", g.squeeze(-1), w) + bias[:, None, :]
+    return list(out.unbind(0))
+
+
 class CouplingBlock(nn.Module):
     """reference attentions.CouplingBlock (attentions.py:89-194).  `with_prosody_wn=True` also
     creates the fork's wn_pitch / wn_energy parameter containers (state_dict compatibility; they are

@@ -440,24 +440,33 @@ __global__ __launch_bounds__(256) void gt_rows_add_cond_kernel(const float* __re
 // (gt_rows_add_cond; the cond input of the WN gate, modules.py:148-156).  One workgroup per (utterance, 64 channels):
 // waves stride the rows, lanes own channels, one LDS fold — no atomics.
 template <bool F32>
-__global__ __launch_bounds__(256) void gt_rows_utt_sum_kernel(const void* __restrict__ y, int ldy, const float* __restrict__ rowmask,
-                                                              float* __restrict__ out, int ldo, int accumulate,
-                                                              int B, int C, int Tp, const int32_t* __restrict__ row0)
+__global__ __launch_bounds__(1024) void gt_rows_utt_sum_kernel(const void* __restrict__ y, int ldy, const float* __restrict__ rowmask,
+                                                               float* __restrict__ out, int ldo, int accumulate,
+                                                               int B, int C, int Tp, const int32_t* __restrict__ row0)
 {
-  __shared__ float part[4][64];
+  // latency-bound (a few hundred rows of 128 B per workgroup): 16 waves, 4 independent row loads in flight per lane
+  __shared__ float part[16][64];
   const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
   const int base = gt_row_base(row0, b, Tp), cnt = gt_row_count(row0, b, Tp);
+  auto ld1 = [&](int t) -> float {
+    if (t >= cnt) return 0.f;
+    const size_t m = (size_t)(base + t);
+    const float k = rowmask ? rowmask[m] : 1.f;             // both loads independent; masked rows may hold anything
+    const float val = F32 ? static_cast<const float*>(y)[m * ldy + c] : bf2f(static_cast<const bf16_t*>(y)[m * ldy + c]);
+    return k != 0.f ? k * val : 0.f;
+  };
   float acc = 0.f;
   if (c < C)
-    for (int t = w; t < cnt; t += 4) {
-      const size_t m = (size_t)(base + t);
-      const float k = rowmask ? rowmask[m] : 1.f;
-      if (k != 0.f) acc += k * (F32 ? static_cast<const float*>(y)[m * ldy + c] : bf2f(static_cast<const bf16_t*>(y)[m * ldy + c]));
+    for (int t = w; t < cnt; t += 64) {
+      const float a0 = ld1(t), a1 = ld1(t + 16), a2 = ld1(t + 32), a3 = ld1(t + 48);
+      acc += (a0 + a1) + (a2 + a3);
     }
   part[w][threadIdx.x & 63] = acc;
   __syncthreads();
   if (w == 0 && c < C) {
-    const float s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i][threadIdx.x];
     float* o = out + (size_t)b * ldo + c;
     *o = accumulate ? *o + s : s;
   }
@@ -735,8 +744,8 @@ extern "C" int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* 
   if (!y || !out || B <= 0 || R <= 0 || C <= 0 || ldy < C || ldo < C) return GT_E_INVAL;
   if (!row0 && R != B * Tp) return GT_E_INVAL;
   const dim3 grid(B, (C + 63) / 64);
-  if (is_f32) hipLaunchKernelGGL(gt_rows_utt_sum_kernel<true>, grid, dim3(256), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
-  else        hipLaunchKernelGGL(gt_rows_utt_sum_kernel<false>, grid, dim3(256), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
+  if (is_f32) hipLaunchKernelGGL(gt_rows_utt_sum_kernel<true>, grid, dim3(1024), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
+  else        hipLaunchKernelGGL(gt_rows_utt_sum_kernel<false>, grid, dim3(1024), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from . import _lib, flow_impl, wgrad
-from .attentions import CouplingBlock, _wn_cond
+from .attentions import CouplingBlock, _wn_cond_all
 from .modules import ActNorm, InvConvNear, _RowsFn, _mask_lengths, prepare_all
 from . import ops
 from .ops import HALO, RowsCtx
@@ -48,13 +48,13 @@ class FlowSpecDecoder(nn.Module):
             prepare_all(self)
         if reverse:                                  # inference direction (models.py:769-770,781-782): no log-det, no autograd
             with torch.no_grad():
-                conds = [None] * self.n_blocks if g is None else [_wn_cond(self.flows[3 * b + 2].wn, g) for b in range(self.n_blocks)]
+                conds = _wn_cond_all([self.flows[3 * b + 2].wn for b in range(self.n_blocks)], g)
                 return _DecoderRunner(self, x_mask, g is not None, False, 0).reverse(x.detach(), conds), None
         self._step += 1
         runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed=(self._step * 7919) & 0x7fffffff)
         conds = []
         if g is not None:
-            conds = [_wn_cond(self.flows[3 * b + 2].wn, g) for b in range(self.n_blocks)]
+            conds = _wn_cond_all([self.flows[3 * b + 2].wn for b in range(self.n_blocks)], g)
         z, logdet = _RowsFn.apply(runner, 2, x, *conds, *runner.params)
         return z, logdet
 
