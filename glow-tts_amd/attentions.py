@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from . import flow_impl, wgrad
-from .modules import WN, ConvP, WNConvP, _RowsFn, _mask_lengths, prepare_all
+from .modules import WN, WNP, ConvP, WNConvP, _RowsFn, _mask_lengths, prepare_all
 from .ops import PackedConv, PackSliceN, RowsCtx
 
 
@@ -51,8 +51,9 @@ class CouplingBlock(nn.Module):
         self.start = WNConvP(in_channels // 2, hidden_channels, 1)
         self.end = ConvP(hidden_channels, in_channels, 1, zero_init=True)       # attentions.py:107-109
         self.wn = WN(in_channels, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels, p_dropout)
-        if with_prosody_wn:
-            raise NotImplementedError("wn_pitch / wn_energy (cfg 5) are outside the round-1 hot-path scope")
+        if with_prosody_wn:                                                      # attentions.py:113-114
+            self.wn_pitch = WNP(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout, 1, n_sqz)
+            self.wn_energy = WNP(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout, 1, n_sqz)
 
     def store_inverse(self):
         pass
@@ -61,7 +62,7 @@ class CouplingBlock(nn.Module):
         if reverse:
             raise NotImplementedError("reverse flow (inference) is out of the training hot-path scope")
         if pitch is not None or energy is not None:
-            raise NotImplementedError("pitch/energy conditioning (cfg 5) is out of the round-1 scope")
+            raise NotImplementedError("pitch / energy conditioning runs through models.FlowSpecDecoder (one autograd node)")
         prepare_all(self)
         runner = _CouplingRunner(self, x_mask, g is not None, self.training)
         tensors = [x] + ([_wn_cond(self.wn, g)] if g is not None else []) + runner.params
@@ -73,7 +74,7 @@ class _CouplingRunner:
     def __init__(self, cb, x_mask, has_cond, train, seed=0):
         self.cb, self.has_cond, self.train, self.seed = cb, has_cond, train, seed
         self.x_mask = x_mask
-        self.params = [p for n, p in cb.named_parameters() if not n.startswith("wn.cond_layer")]
+        self.params = [p for n, p in cb.named_parameters() if not n.startswith("wn.cond_layer") and "cond_layer1" not in n]
 
     def forward(self, x, *rest):
         cond = rest[0] if self.has_cond else None

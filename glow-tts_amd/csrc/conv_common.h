@@ -8,7 +8,7 @@ struct ConvArgs {
   const bf16_t* X; int ldx;                   // [R, >=Cin]
   const bf16_t* W;                            // packed [taps][Np][Kp]
   const float* bias;                          // [N] (gate: [2*half]) or null
-  const float* cond; int ldc;                 // [B, ldc] or null
+  const float* cond; int ldc;                 // [B, ldc] per utterance (B > 0), [R, ldc] per row (B == 0), or null
   const float* rowmask;                       // [R] or null
   void* Y; int ldy;
   const void* addend; int ldadd;              // same dtype as Y, or null
@@ -52,7 +52,7 @@ __device__ __forceinline__ void epilogue_gate(const ConvArgs& a, const float* es
       bs0 = *reinterpret_cast<const float4*>(a.bias + half + cg); bs1 = *reinterpret_cast<const float4*>(a.bias + half + cg + 4);
     }
     if (a.cond) {
-      const float* cp = a.cond + (size_t)gt_row_batch(a.row0, a.B, m, a.Tp) * a.ldc + cg;
+      const float* cp = a.cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, m, a.Tp) : m) * a.ldc + cg;   // B == 0: per-row cond
       ct0 = *reinterpret_cast<const float4*>(cp);        ct1 = *reinterpret_cast<const float4*>(cp + 4);
       cs0 = *reinterpret_cast<const float4*>(cp + half); cs1 = *reinterpret_cast<const float4*>(cp + half + 4);
     }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, const float* e
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
     if (a.cond) {
-      const float* cp = a.cond + (size_t)gt_row_batch(a.row0, a.B, m, a.Tp) * a.ldc;
+      const float* cp = a.cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, m, a.Tp) : m) * a.ldc;
       const float4 c0 = *reinterpret_cast<const float4*>(cp + n), c1 = *reinterpret_cast<const float4*>(cp + n1);
       v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
     }

@@ -107,8 +107,9 @@ def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
 
 
 # ----------------------------------------------------------------------------- WN
-def wn_fwd(rc, wn, h0, cond, train, seed):
-    """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None.
+def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
+    """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
+    it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
     Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
 
     The gated activations of all layers live side by side in ONE [R, n*H] buffer: the residual 1x1 reads its
@@ -125,7 +126,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts = acts_all[:, i * H:(i + 1) * H]
         _, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True, out=acts,
-                            drop_p=p, seed=seed + i, tag="in_layer_gate_conv")
+                            drop_p=p, seed=seed + i, tag="in_layer_gate_conv", cond_per_row=cond_per_row)
         ts.append(t); ss.append(s)
         if i < n - 1:
             rs = wn.res_skip_layers[i]
@@ -136,16 +137,17 @@ def wn_fwd(rc, wn, h0, cond, train, seed):
     return out, (xs, ts, ss, acts_all, p, seed)
 
 
-def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
+def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
     """dskip: [R,H] bf16, the MASKED gradient of the wn output (= d skip of every layer, since out = skip*mask).
-    Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond)."""
+    Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond); dcond is [B, 2*H*n] (per-utterance sums) or, with
+    cond_per_row, the per-frame gradient [R, 2*H*n] fp32."""
     L = _lib.lib()
     xs, ts, ss, acts_all, p, seed = saved
     R, H = dskip.shape
     dev = dskip.device
     n = wn.n_layers
     grads = {}
-    dcond = None if not want_dcond else torch.empty(rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    dcond = None if not want_dcond else torch.empty(R if cond_per_row else rc.B, 2 * H * n, dtype=torch.float32, device=dev)
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
     dres = None             # gradient arriving at x_{i+1} (masked), i.e. at res_i's output
@@ -175,20 +177,36 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False):
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
             src = dpre_c if dpre_c is not None else dpre
-            rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
+            if cond_per_row:
+                dcond[:, 2 * H * i:2 * H * (i + 1)] = src
+            else:
+                rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
         # d x_i = dgrad(in_layer) + (residual path), then through the mask of x_i's producer
         dres = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=dres, mask=True)
     return dres, grads, dcond
 
 
 # ----------------------------------------------------------------------------- coupling block
-def coupling_fwd(rc, cb, x, x0_bf16, cond, logdet, train, seed):
-    """attentions.CouplingBlock.forward on rows.  x [R,C] fp32, x0_bf16 = bf16(x[:, :C/2])."""
+def prosody_chain(cb, econd, pcond):
+    """The per-frame conditioned WaveNets that follow cb.wn, in the reference's order (attentions.py:153-154):
+    wn_energy then wn_pitch; each is the identity when its conditioning is None (modules.py:323-324)."""
+    return [(w, c) for w, c in ((getattr(cb, "wn_energy", None), econd), (getattr(cb, "wn_pitch", None), pcond)) if c is not None]
+
+
+def coupling_fwd(rc, cb, x, x0_bf16, cond, logdet, train, seed, econd=None, pcond=None):
+    """attentions.CouplingBlock.forward on rows.  x [R,C] fp32, x0_bf16 = bf16(x[:, :C/2]).
+    econd / pcond: [R, 2*H*n] fp32 per-frame conditioning of wn_energy / wn_pitch (cond_layer1 output, squeezed)."""
     L = _lib.lib()
     dev = x.device
     R, C = x.shape
     h0 = conv_rows(x0_bf16, cb.start.pc, rc, bias=cb.start.bias, mask=True)
     wn_out, wn_saved = wn_fwd(rc, cb.wn, h0, cond, train, seed)
+    pros_saved = []
+    for k, (wnp, c) in enumerate(prosody_chain(cb, econd, pcond)):
+        wn_out, sv = wn_fwd(rc, wnp, wn_out, c, train, seed + 4 * (k + 1), cond_per_row=True)
+        pros_saved.append(sv)
+    if pros_saved:
+        wn_saved = (wn_saved, pros_saved)
     out = conv_rows(wn_out, cb.end.pc, rc, bias=cb.end.bias, out_f32=True)      # [R,C] = [m | logs]
     z = torch.empty_like(x)
     _lib.check(L.gt_coupling_fwd(_lib.ptr(out), _lib.ptr(x), _lib.ptr(z), _lib.ptr(rc.rowmask), _lib.ptr(logdet),
@@ -196,9 +214,14 @@ def coupling_fwd(rc, cb, x, x0_bf16, cond, logdet, train, seed):
     return z, (x, x0_bf16, h0, wn_out, wn_saved, out)
 
 
-def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
+def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcond=False):
+    """econd / pcond: whether wn_energy / wn_pitch ran in the forward; returns (dx, grads, dcond, [d econd, d pcond])."""
     L = _lib.lib()
     x, x0_bf16, h0, wn_out, wn_saved, out = saved
+    chain = prosody_chain(cb, econd or None, pcond or None)
+    pros_saved = []
+    if chain:
+        wn_saved, pros_saved = wn_saved
     dev = x.device
     R, C = x.shape
     dx = torch.empty_like(x)
@@ -208,11 +231,19 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False):
                "gt_coupling_bwd")
     grads = conv_param_grads(cb.end, wn_out, dout, R)
     dskip = conv_rows(dout, cb.end.pc, rc, dgrad=True, mask=True)                # d(wn out) * mask = d skip
+    dpros = {}
+    for (wnp, _), sv in zip(reversed(chain), reversed(pros_saved)):              # each WN's masked input gradient is the
+        dskip, gp, dc = wn_bwd(rc, wnp, sv, dskip, True, cond_per_row=True)      # previous WN's d skip
+        grads.update(gp)
+        dpros[id(wnp)] = dc
     dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, dskip, want_dcond)
     grads.update(g2)
     grads.update(conv_param_grads(cb.start, x0_bf16, dh0, R))                    # dh0 is already masked
     dx0 = conv_rows(dh0, cb.start.pc, rc, dgrad=True)
     _lib.check(L.gt_rows_add_bf16(_lib.ptr(dx), C, _lib.ptr(dx0), dx0.stride(0), R, C // 2, _st(dev)), "gt_rows_add_bf16")
+    if econd or pcond:
+        return dx, grads, dcond, [dpros.get(id(getattr(cb, "wn_energy", None))) if econd else None,
+                                  dpros.get(id(getattr(cb, "wn_pitch", None))) if pcond else None]
     return dx, grads, dcond
 
 
@@ -234,7 +265,7 @@ def actnorm_invconv_rev(rc, y, logs, bias, W, want_x0=True):
     return x, x0
 
 
-def coupling_rev(rc, cb, z, z0_bf16, cond):
+def coupling_rev(rc, cb, z, z0_bf16, cond, econd=None, pcond=None):
     """attentions.CouplingBlock.forward with reverse=True on rows: the same start / WN / end GEMMs as the forward
     (evaluation mode), then x1 = (z1 - m) * exp(-logs) * mask."""
     L = _lib.lib()
@@ -242,6 +273,8 @@ def coupling_rev(rc, cb, z, z0_bf16, cond):
     R, C = z.shape
     h0 = conv_rows(z0_bf16, cb.start.pc, rc, bias=cb.start.bias, mask=True)
     wn_out, _ = wn_fwd(rc, cb.wn, h0, cond, False, 0)
+    for wnp, c in prosody_chain(cb, econd, pcond):
+        wn_out, _ = wn_fwd(rc, wnp, wn_out, c, False, 0, cond_per_row=True)
     out = conv_rows(wn_out, cb.end.pc, rc, bias=cb.end.bias, out_f32=True)
     x = torch.empty_like(z)
     _lib.check(L.gt_coupling_rev(_lib.ptr(out), _lib.ptr(z), _lib.ptr(x), _lib.ptr(rc.rowmask), R, C, int(cb.sigmoid_scale),

@@ -41,35 +41,85 @@ class FlowSpecDecoder(nn.Module):
 
     def forward(self, x, x_mask, g=None, emo=None, pitch=None, energy=None, reverse=False, prepared=False):
         """x: [b, 80, t] (t even after the caller's preprocess, models.py:1248-1253; an odd trailing
-        frame is dropped like commons.squeeze does), x_mask: [b, 1, t].  Returns (z, logdet_tot)."""
-        if pitch is not None or energy is not None:
-            raise NotImplementedError("pitch/energy conditioning (cfg 5) is out of the round-1 scope")
+        frame is dropped like commons.squeeze does), x_mask: [b, 1, t].  Returns (z, logdet_tot).
+        pitch / energy: [b, 1, t] (or [b, t], attentions.py:137-141) contours at the un-squeezed frame rate, or None:
+        per-frame conditioning of every block's wn_pitch / wn_energy (cfg 5; needs with_prosody_wn=True)."""
+        if (pitch is not None or energy is not None) and not hasattr(self.flows[2], "wn_pitch"):
+            raise ValueError("pitch / energy conditioning needs FlowSpecDecoder(with_prosody_wn=True)")
+        pitch = pitch.unsqueeze(1) if (pitch is not None and pitch.dim() == 2) else pitch
+        energy = energy.unsqueeze(1) if (energy is not None and energy.dim() == 2) else energy
         if not prepared:
             prepare_all(self)
+        wns = [self.flows[3 * b + 2].wn for b in range(self.n_blocks)]
         if reverse:                                  # inference direction (models.py:769-770,781-782): no log-det, no autograd
             with torch.no_grad():
-                conds = _wn_cond_all([self.flows[3 * b + 2].wn for b in range(self.n_blocks)], g)
-                return _DecoderRunner(self, x_mask, g is not None, False, 0).reverse(x.detach(), conds), None
+                conds = _wn_cond_all(wns, g)
+                runner = _DecoderRunner(self, x_mask, g is not None, False, 0, energy, pitch)
+                return runner.reverse(x.detach(), conds, self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)), None
         self._step += 1
-        runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed=(self._step * 7919) & 0x7fffffff)
-        conds = []
-        if g is not None:
-            conds = _wn_cond_all([self.flows[3 * b + 2].wn for b in range(self.n_blocks)], g)
-        z, logdet = _RowsFn.apply(runner, 2, x, *conds, *runner.params)
+        runner = _DecoderRunner(self, x_mask, g is not None, self.training, (self._step * 7919) & 0x7fffffff, energy, pitch)
+        extra = list(_wn_cond_all(wns, g)) if g is not None else []
+        extra += [a for a in (self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)) if a is not None]
+        z, logdet = _RowsFn.apply(runner, 2, x, *extra, *runner.params)
         return z, logdet
+
+    def _prosody_affine(self, which, contour):
+        """cond_layer1 of every block's wn_energy / wn_pitch as (effective weight, bias) pairs [n_blocks, 2, 2*H*n/n_sqz]:
+        with one input channel the weight-normed 1x1 conv (modules.py:289-291,320) is the per-frame affine map
+        w[c] * contour + b[c]; the runner applies it to the squeezed contour.  Differentiable w.r.t. the parameters."""
+        if contour is None:
+            return None
+        cls = [getattr(self.flows[3 * b + 2], which).cond_layer1 for b in range(self.n_blocks)]
+        v = torch.stack([c.weight_v.reshape(c.out_channels, -1) for c in cls])        # [nb, O, 1]
+        gg = torch.stack([c.weight_g.reshape(-1) for c in cls])                       # [nb, O]
+        w = (v * (gg / v.norm(dim=2)).unsqueeze(-1)).squeeze(-1)
+        return torch.stack([w, torch.stack([c.bias for c in cls])], dim=1)
 
 
 class _DecoderRunner:
-    def __init__(self, dec, x_mask, has_cond, train, seed):
+    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None):
         self.dec, self.has_cond, self.train, self.seed = dec, has_cond, train, seed
         self.x_mask = x_mask
-        self.params = [p for n, p in dec.named_parameters() if ".wn.cond_layer." not in n]
+        self.energy, self.pitch = energy, pitch                                   # [b,1,t] contours (no gradient) or None
+        self.params = [p for n, p in dec.named_parameters() if ".wn.cond_layer." not in n and "cond_layer1" not in n]
+
+    def _contour_rows(self, rc, c, B, T):
+        """[b,1,t] contour -> [R, 2] fp32 rows (column = frame parity), the squeeze of modules.py:353-362 for one channel."""
+        if c is None:
+            return None
+        L = _lib.lib()
+        cc = c.detach().float().reshape(B, 1, -1)[:, :, :T].contiguous()
+        assert cc.shape[2] == T, "pitch / energy must cover the mel frames"
+        rows = torch.empty(rc.R, 2, dtype=torch.float32, device=cc.device)
+        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(cc), _lib.ptr(rows), _lib.ptr(rc.lengths), B, 1, T, rc.Tp, _lib.ptr(rc.row0),
+                                         _lib.current_stream(cc.device)), "gt_squeeze_rows_f32")
+        return rows
+
+    @staticmethod
+    def _cond_rows(sig, aff_b):
+        """per-frame conditioning rows [R, 2*O] = w * contour + b, laid out like the squeezed cond_layer1 output
+        (channel = parity * O + c); layer i of the WNP reads columns [2*H*i, 2*H*(i+1))."""
+        if sig is None:
+            return None
+        w, b = aff_b[0].detach().float(), aff_b[1].detach().float()
+        return torch.addcmul(b[None, None, :], sig[:, :, None], w[None, None, :]).reshape(sig.shape[0], -1)
+
+    def _split_inputs(self, rest):
+        nb = self.dec.n_blocks
+        k = nb if self.has_cond else 0
+        conds = rest[:k] if self.has_cond else [None] * nb
+        eaff = paff = None
+        if self.energy is not None:
+            eaff = rest[k]; k += 1
+        if self.pitch is not None:
+            paff = rest[k]; k += 1
+        return conds, eaff, paff
 
     def forward(self, x, *rest):
         L = _lib.lib()
         dec = self.dec
         nb = dec.n_blocks
-        conds = rest[:nb] if self.has_cond else [None] * nb
+        conds, eaff, paff = self._split_inputs(rest)
         B, C, T = x.shape
         dev = x.device
         T2 = T // 2
@@ -80,18 +130,21 @@ class _DecoderRunner:
         st = _lib.current_stream(dev)
         _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         logdet = ops.zeros_small(B, torch.float32, dev)
+        esig, psig = self._contour_rows(rc, self.energy, B, T2 * 2), self._contour_rows(rc, self.pitch, B, T2 * 2)
         saved = []
         cur = rows
         for b in range(nb):
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
             y1, x0, s1 = flow_impl.actnorm_invconv_fwd(rc, cur, an.logs, an.bias, ic.weight, logdet)
-            cur, s2 = flow_impl.coupling_fwd(rc, cb, y1, x0, conds[b], logdet, self.train, self.seed + 16 * b)
+            cur, s2 = flow_impl.coupling_fwd(rc, cb, y1, x0, conds[b], logdet, self.train, self.seed + 16 * b,
+                                             econd=self._cond_rows(esig, None if eaff is None else eaff[b]),
+                                             pcond=self._cond_rows(psig, None if paff is None else paff[b]))
             saved.append((s1, s2))
         z = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
         _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(z), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
-        return (z.to(x.dtype), logdet), (rc, saved, (B, C, T))
+        return (z.to(x.dtype), logdet), (rc, saved, (B, C, T), esig, psig)
 
-    def reverse(self, z, conds):
+    def reverse(self, z, conds, eaff=None, paff=None):
         """z [B, C, T] -> x: flows in reverse order (coupling^-1, InvConvNear^-1, ActNorm^-1 per block)."""
         L = _lib.lib()
         dec = self.dec
@@ -106,9 +159,11 @@ class _DecoderRunner:
         _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(zin), _lib.ptr(cur), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         x0 = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
         _lib.check(L.gt_rows_f32_to_bf16(_lib.ptr(cur), 2 * C, _lib.ptr(x0), C, None, rc.R, C, st), "gt_rows_f32_to_bf16")
+        esig, psig = self._contour_rows(rc, self.energy, B, T2 * 2), self._contour_rows(rc, self.pitch, B, T2 * 2)
         for b in reversed(range(dec.n_blocks)):
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
-            cur = flow_impl.coupling_rev(rc, cb, cur, x0, conds[b])
+            cur = flow_impl.coupling_rev(rc, cb, cur, x0, conds[b], econd=self._cond_rows(esig, None if eaff is None else eaff[b]),
+                                         pcond=self._cond_rows(psig, None if paff is None else paff[b]))
             cur, x0 = flow_impl.actnorm_invconv_rev(rc, cur, an.logs, an.bias, ic.weight, want_x0=b > 0)
         x = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
         _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(x), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
@@ -116,7 +171,7 @@ class _DecoderRunner:
 
     def backward(self, saved_all, dz, dlogdet):
         L = _lib.lib()
-        rc, saved, (B, C, T) = saved_all
+        rc, saved, (B, C, T), esig, psig = saved_all
         dec = self.dec
         nb = dec.n_blocks
         dev = rc.device
@@ -131,6 +186,9 @@ class _DecoderRunner:
             dzc = dz.float().contiguous()
             _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         dconds = [None] * nb
+        O = 2 * dec.hidden_channels * dec.n_layers // 2
+        deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None
+        dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None
         cur = drows
         # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
         # side stream, beside the rest of the chain)
@@ -141,7 +199,17 @@ class _DecoderRunner:
                 for b in reversed(range(b0, b1)):
                     an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
                     s1, s2 = saved[b]
-                    cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
+                    if esig is None and psig is None:
+                        cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
+                    else:
+                        cur, g2, dconds[b], dpros = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond,
+                                                                           econd=esig is not None, pcond=psig is not None)
+                        # cond = w * contour + b per (frame, parity, channel): d w = sum dcond * contour, d b = sum dcond
+                        for dc, sig, dst in ((dpros[0], esig, deaff), (dpros[1], psig, dpaff)):
+                            if dc is not None:
+                                d3 = dc.view(rc.R, 2, O)
+                                dst[b, 0] = (d3 * sig[:, :, None]).sum((0, 1))
+                                dst[b, 1] = d3.sum((0, 1))
                     grads.update(g2)
                     cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
                     grads.update(g1)
@@ -155,6 +223,7 @@ class _DecoderRunner:
         out = [dx]
         if self.has_cond:
             out += dconds
+        out += [d for d in (deaff, dpaff) if d is not None]
         return out + [grads.get(p) for p in self.params]
 
 

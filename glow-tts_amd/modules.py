@@ -277,6 +277,21 @@ class WN(nn.Module):
             self.skip_bias = torch.stack([rs.bias[-H:] for rs in self.res_skip_layers]).sum(0)
 
 
+class WNP(WN):
+    """reference modules.WNP (modules.py:272-362): WN's gated conv stack with PER-FRAME conditioning — cond_layer1
+    (weight-normed 1x1 conv, gin_channels1 -> 2*hidden*n_layers/n_sqz) is applied to the un-squeezed pitch / energy
+    contour and squeezed like the mel (modules.py:353-362); the identity when the contour is None (modules.py:323-324).
+    The loop itself is WN's (flow_impl.wn_fwd with cond_per_row)."""
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout=0, gin_channels1=0, n_sqz=2):
+        super().__init__(0, hidden_channels, kernel_size, dilation_rate, n_layers, 0, p_dropout)
+        assert n_sqz == 2 and gin_channels1 in (0, 1), "the reference builds WNP(…, 1, n_sqz=2) (attentions.py:113-114)"
+        self.n_sqz, self.gin_channels1 = n_sqz, gin_channels1
+        if gin_channels1 != 0:
+            self.cond_layer1 = WNConvP(gin_channels1, 2 * hidden_channels * n_layers // n_sqz, 1)
+            self.cond_layer1.no_pack = True          # C_in = 1: an outer product, applied in the decoder runner
+
+
 class ConvReluNorm(nn.Module):
     """reference modules.ConvReluNorm (modules.py:70-102): the text-encoder prenet."""
 

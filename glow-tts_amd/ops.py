@@ -380,7 +380,8 @@ class PackedConv:
 
 
 def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=None, out_f32=False,
-              addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None, tag=None):
+              addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None, tag=None,
+              cond_per_row=False):
     """Y = epilogue(conv(x)) in the rows layout via gt_conv_gemm_bf16.  x: [R, >=Cin] bf16.
     `out`/`addend` may be column-slices of wider row buffers (row stride taken from .stride(0))."""
     L = _lib.lib()
@@ -408,7 +409,8 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
                              _lib.ptr(seed_word(x.device)) if drop_p > 0 else None,
-                             _lib.ptr(ctx.row0) if cond is not None else None, ctx.B, _lib.current_stream(x.device))
+                             _lib.ptr(ctx.row0) if (cond is not None and not cond_per_row) else None,
+                             0 if cond_per_row else ctx.B, _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
     _lib.check(rc, "gt_conv_gemm2_bf16" if fn is L.gt_conv_gemm2_bf16 else "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate == 1 else out

@@ -104,7 +104,9 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
 /* 1-D convolution (odd k <= 5, dilation 1) as implicit GEMM on bf16 MFMA, fp32 accumulate.
  * Replaces the conv1d calls of modules.py:152,165 / attentions.py:144,172,232-238,365-371 /
  * modules.py:97 / models.py:710 and, with dgrad-packed weights, their data gradients.
- *   Y[m,n] = epi( sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci] + bias[n] + cond[m/Tp][n] )
+ *   Y[m,n] = epi( sum_tap sum_ci X[m + tap - k/2, ci] * W[tap][n][ci] + bias[n] + cond[u(m)][n] )
+ *   cond (may be NULL): [B, ldc] fp32 with u(m) = utterance of row m when B > 0 (WN.cond_layer(g), modules.py:148-156);
+ *        [R, ldc] fp32 with u(m) = m when B == 0 (per-frame conditioning: WNP.cond_layer1(pitch), modules.py:316-334).
  *   epi: optional relu, optional dropout (drop_p, counter-based on (m,n)), optional + addend[m,n],
  *        optional * rowmask[m]; output bf16 or fp32.
  *   gate == 1 (WaveNet gate, commons.py:61-68; N = 2*half, packed with the gate interleave):

@@ -120,14 +120,46 @@ def wn_fwd(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, dil
     return output * x_mask
 
 
-def coupling_fwd(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, sigmoid_scale=False):
-    """attentions.CouplingBlock.forward (attentions.py:132-186) with pitch=energy=None, for which
+def wnp_fwd(P, pre, x, x_mask, g1=None, n_layers=4, hidden=192, kernel_size=5, dilation_rate=1, n_sqz=2):
+    """modules.WNP.forward (modules.py:316-343) + WNP.squeeze (modules.py:353-362), eval mode: the identity when the
+    contour g1 [b,1,t_unsqueezed] is None; else WN's loop with per-frame conditioning cond_layer1(g1), squeezed."""
+    if g1 is None:
+        return x
+    g = conv1d(P, pre + "cond_layer1", g1)
+    b, c, t = g.shape
+    t = (t // n_sqz) * n_sqz
+    g = g[:, :, :t].view(b, c, t // n_sqz, n_sqz).permute(0, 3, 1, 2).contiguous().view(b, c * n_sqz, t // n_sqz)
+    output = torch.zeros_like(x)
+    for i in range(n_layers):
+        d = dilation_rate ** i
+        pad = int((kernel_size * d - d) / 2)
+        x_in = conv1d(P, pre + f"in_layers.{i}", x, padding=pad, dilation=d)
+        acts = gate(x_in, g[:, i * 2 * hidden:(i + 1) * 2 * hidden], hidden)
+        rs = conv1d(P, pre + f"res_skip_layers.{i}", acts)
+        if i < n_layers - 1:
+            x = (x + rs[:, :hidden]) * x_mask
+            output = output + rs[:, hidden:]
+        else:
+            output = output + rs
+    return output * x_mask
+
+
+def _coupling_net(P, pre, x0, x_mask, g, pitch, energy, n_layers, hidden, kernel_size):
+    """start -> wn -> wn_energy -> wn_pitch -> end (attentions.py:144-155)"""
+    h = conv1d(P, pre + "start", x0) * x_mask
+    h = wn_fwd(P, pre + "wn.", h, x_mask, g, n_layers, hidden, kernel_size)
+    h = wnp_fwd(P, pre + "wn_energy.", h, x_mask, energy, n_layers, hidden, kernel_size)
+    h = wnp_fwd(P, pre + "wn_pitch.", h, x_mask, pitch, n_layers, hidden, kernel_size)
+    return conv1d(P, pre + "end", h)
+
+
+def coupling_fwd(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, sigmoid_scale=False,
+                 pitch=None, energy=None):
+    """attentions.CouplingBlock.forward (attentions.py:132-186); with pitch=energy=None
     wn_energy / wn_pitch return their input (modules.WNP.forward, modules.py:323-324)."""
     c = x.shape[1]
     x0, x1 = x[:, :c // 2], x[:, c // 2:]
-    h = conv1d(P, pre + "start", x0) * x_mask
-    h = wn_fwd(P, pre + "wn.", h, x_mask, g, n_layers, hidden, kernel_size)
-    out = conv1d(P, pre + "end", h)
+    out = _coupling_net(P, pre, x0, x_mask, g, pitch, energy, n_layers, hidden, kernel_size)
     m, logs = out[:, :c // 2], out[:, c // 2:]
     if sigmoid_scale:
         logs = torch.log(1e-6 + torch.sigmoid(logs + 2))
@@ -137,14 +169,16 @@ def coupling_fwd(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=
 
 
 def decoder_fwd(P, pre, x, x_mask, g=None, n_blocks=12, n_layers=4, hidden=192, kernel_size=5,
-                n_split=4, n_sqz=2, sigmoid_scale=False):
-    """models.FlowSpecDecoder.forward (models.py:765-785), reverse=False."""
+                n_split=4, n_sqz=2, sigmoid_scale=False, pitch=None, energy=None):
+    """models.FlowSpecDecoder.forward (models.py:765-785), reverse=False.  pitch / energy: [b,1,t] contours at the
+    un-squeezed frame rate (cfg 5) or None."""
     x, m = squeeze(x, x_mask, n_sqz)
     logdet_tot = 0
     for b in range(n_blocks):
         x, ld = actnorm_fwd(P, pre + f"flows.{3 * b}.", x, m); logdet_tot = logdet_tot + ld
         x, ld = invconv_fwd(P, pre + f"flows.{3 * b + 1}.", x, m, n_split); logdet_tot = logdet_tot + ld
-        x, ld = coupling_fwd(P, pre + f"flows.{3 * b + 2}.", x, m, g, n_layers, hidden, kernel_size, sigmoid_scale)
+        x, ld = coupling_fwd(P, pre + f"flows.{3 * b + 2}.", x, m, g, n_layers, hidden, kernel_size, sigmoid_scale,
+                             pitch, energy)
         logdet_tot = logdet_tot + ld
     x, _ = unsqueeze(x, m, n_sqz)
     return x, logdet_tot
@@ -166,13 +200,12 @@ def invconv_rev(P, pre, x, x_mask, n_split=4):
     return zg.view(b, 2, h, c // n_split, t).permute(0, 1, 3, 2, 4).reshape(b, c, t) * x_mask
 
 
-def coupling_rev(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, sigmoid_scale=False):
+def coupling_rev(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=5, sigmoid_scale=False,
+                 pitch=None, energy=None):
     """attentions.CouplingBlock.forward with reverse=True (attentions.py:178-180)."""
     c = x.shape[1]
     x0, x1 = x[:, :c // 2], x[:, c // 2:]
-    h = conv1d(P, pre + "start", x0) * x_mask
-    h = wn_fwd(P, pre + "wn.", h, x_mask, g, n_layers, hidden, kernel_size)
-    out = conv1d(P, pre + "end", h)
+    out = _coupling_net(P, pre, x0, x_mask, g, pitch, energy, n_layers, hidden, kernel_size)
     m, logs = out[:, :c // 2], out[:, c // 2:]
     if sigmoid_scale:
         logs = torch.log(1e-6 + torch.sigmoid(logs + 2))
@@ -181,11 +214,11 @@ def coupling_rev(P, pre, x, x_mask, g=None, n_layers=4, hidden=192, kernel_size=
 
 
 def decoder_rev(P, pre, z, z_mask, g=None, n_blocks=12, n_layers=4, hidden=192, kernel_size=5,
-                n_split=4, n_sqz=2, sigmoid_scale=False):
+                n_split=4, n_sqz=2, sigmoid_scale=False, pitch=None, energy=None):
     """models.FlowSpecDecoder.forward with reverse=True (models.py:765-785): flows in reverse order, no log-det."""
     x, m = squeeze(z, z_mask, n_sqz)
     for b in reversed(range(n_blocks)):
-        x = coupling_rev(P, pre + f"flows.{3 * b + 2}.", x, m, g, n_layers, hidden, kernel_size, sigmoid_scale)
+        x = coupling_rev(P, pre + f"flows.{3 * b + 2}.", x, m, g, n_layers, hidden, kernel_size, sigmoid_scale, pitch, energy)
         x = invconv_rev(P, pre + f"flows.{3 * b + 1}.", x, m, n_split)
         x = actnorm_rev(P, pre + f"flows.{3 * b}.", x, m)
     x, _ = unsqueeze(x, m, n_sqz)

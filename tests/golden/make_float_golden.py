@@ -189,6 +189,24 @@ def main():
         xrg, _ = decg(zr, ym[:, :, :24], g=spk, reverse=True)
     out.update(decg_z=zg, decg_logdet=ldg, decg_gy=gyg, decg_gg=gsd, decg_rev_x=xrg)
 
+    # ---- per-frame pitch / energy conditioning (cfg 5): WNP (modules.py:272-362) inside every coupling block
+    # (attentions.py:153-154), contours [b,1,t] at the un-squeezed frame rate — appended last again
+    pit = rnd(2, 1, 24) * ym[:, :, :24]; ene = rnd(2, 1, 24).abs() * ym[:, :, :24]
+    decp = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, n_split=4, n_sqz=2, gin_channels=256),
+                       "decoder.").eval()
+    yp = (y[:, :, :24] * ym[:, :, :24]).requires_grad_(True)
+    zp, ldp = decp(yp, ym[:, :, :24], g=spk, pitch=pit, energy=ene)
+    prm = dict(decp.named_parameters())
+    names = ["decoder.flows.2.wn_pitch.cond_layer1.weight_g", "decoder.flows.2.wn_pitch.cond_layer1.weight_v",
+             "decoder.flows.2.wn_pitch.cond_layer1.bias", "decoder.flows.5.wn_energy.cond_layer1.weight_v",
+             "decoder.flows.5.wn_energy.cond_layer1.bias", "decoder.flows.2.wn_energy.in_layers.1.weight_v"]
+    gyp, *gps = grads_of([(zp, 9), (ldp, 10)], [yp] + [prm[n[len("decoder."):]] for n in names])
+    with torch.no_grad():
+        xrp, _ = decp(zr, ym[:, :, :24], g=spk, pitch=pit, energy=ene, reverse=True)
+        zpo, _ = decp(yp, ym[:, :, :24], g=spk, pitch=pit, energy=None)      # pitch only: wn_energy is the identity
+    out.update(pros_pitch=pit, pros_energy=ene, decp_z=zp, decp_logdet=ldp, decp_gy=gyp, decp_rev_x=xrp, decp_z_pitch_only=zpo)
+    out.update({"decp_g_" + n: v for n, v in zip(names, gps)})
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

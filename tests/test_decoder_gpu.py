@@ -217,3 +217,63 @@ def test_infer_generates_mel_through_the_reverse_flow(built):
     assert torch.allclose(z_m.cpu(), zm_want, atol=1e-5)
     y_want = R.decoder_rev(P, "decoder.", zm_want * z_mask.cpu(), z_mask.cpu(), n_blocks=2)
     assert relerr(y.cpu(), y_want) < 3e-2
+
+
+@pytest.mark.parametrize("ragged,pitch_only", [(False, False), (True, False), (False, True)])
+def test_decoder_pitch_energy_speaker_conditioning(built, ragged, pitch_only):
+    """cfg 5's decoder: every coupling block runs wn(g) -> wn_energy(energy) -> wn_pitch(pitch) (attentions.py:152-154),
+    the latter two modules.WNP with per-frame conditioning (the gate kernel's per-row cond).  Forward, log-det, input
+    gradient, EVERY parameter gradient (cond_layer1 affine maps included), the gradient of g, and the reverse direction
+    against the oracle (pinned to the imported reference: decp_* in float_golden.npz); pitch alone leaves wn_energy the
+    identity."""
+    from glow_tts_amd import models, ops
+    n_blocks, B, T, lens = 2, 3, 50, [50, 27, 12]
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, n_blocks, 4, p_dropout=0.05, gin_channels=256, with_prosody_wn=True),
+                      "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    for v in P.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(21)
+    m = lens_mask(lens, T)
+    y = torch.randn(B, 80, T, generator=g) * m
+    spk = torch.randn(B, 256, 1, generator=g)
+    pit = torch.randn(B, 1, T, generator=g) * m
+    ene = None if pitch_only else torch.randn(B, 1, T, generator=g).abs() * m
+    yy, gg = y.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+    z, ld = R.decoder_fwd(P, "decoder.", yy, m, gg, n_blocks=n_blocks, pitch=pit, energy=ene)
+    z0, _ = R.decoder_fwd(P, "decoder.", y, m, spk, n_blocks=n_blocks)
+    assert relerr(z0.detach(), z.detach()) > 1e-2                     # the contours matter at these weights
+    rz = torch.randn(z.shape, generator=g) * m[:, :, :z.shape[2]]; rl = torch.randn(B, generator=g) * 0.1
+    ((z * rz).sum() + (ld * rl).sum()).backward()
+
+    dec = dec.to(dev())
+    yd, gd = y.to(dev()).requires_grad_(True), spk.to(dev()).requires_grad_(True)
+    ops.RAGGED = ragged
+    try:
+        zd, ldd = dec(yd, m.to(dev()), g=gd, pitch=pit.to(dev()), energy=None if ene is None else ene.to(dev()))
+        assert relerr(zd.detach().cpu(), z.detach()) < 3e-2, relerr(zd.detach().cpu(), z.detach())
+        nvalid = torch.tensor(lens, dtype=torch.float32) // 2 * 160
+        assert ((ldd.detach().cpu() - ld.detach()).abs() < 2e-3 * nvalid + 1e-2).all(), (ldd.cpu(), ld)
+        ((zd * rz.to(dev())).sum() + (ldd * rl.to(dev())).sum()).backward()
+        zrev = torch.randn(B, 80, T, generator=g) * m
+        xr, _ = dec(zrev.to(dev()), m.to(dev()), g=spk.to(dev()), pitch=pit.to(dev()),
+                    energy=None if ene is None else ene.to(dev()), reverse=True)
+    finally:
+        ops.RAGGED = False
+    assert relerr(yd.grad.cpu(), yy.grad) < 3e-2, relerr(yd.grad.cpu(), yy.grad)
+    assert relerr(gd.grad.cpu(), gg.grad) < 6e-2, relerr(gd.grad.cpu(), gg.grad)
+    for name, p in dec.named_parameters():
+        ref = P["decoder." + name].grad
+        if pitch_only and ".wn_energy." in name:
+            assert p.grad is None or p.grad.abs().max().item() == 0, name
+            continue
+        assert p.grad is not None, name
+        if name.endswith("cond_layer1.weight_v"):
+            # one input channel: w = g * v / |v| depends on v's sign only — a mathematically zero gradient, rounding noise on both sides
+            scale = P["decoder." + name[:-1] + "g"].grad.abs().max().item()
+            assert p.grad.abs().max().item() <= 1e-3 * scale and ref.abs().max().item() <= 1e-3 * scale, name
+            continue
+        e = relerr(p.grad.cpu(), ref)
+        assert e < 6e-2, (name, e)
+    want = R.decoder_rev(P, "decoder.", zrev, m, spk, n_blocks=n_blocks, pitch=pit, energy=ene)
+    assert relerr(xr.cpu(), want.detach()) < 3e-2

@@ -180,3 +180,35 @@ def test_speaker_conditioning_matches_reference_golden(built):
     assert close(gy, t("decg_gy"), 2e-4) and close(g_g, t("decg_gg"), 2e-4)
     xr = R.decoder_rev(P, "decoder.", t("dec_rev_z"), t("dec_mask"), spk, n_blocks=2)
     assert close(xr, t("decg_rev_x"), 2e-4)
+
+
+PROS_GRADS = ["decoder.flows.2.wn_pitch.cond_layer1.weight_g", "decoder.flows.2.wn_pitch.cond_layer1.weight_v",
+              "decoder.flows.2.wn_pitch.cond_layer1.bias", "decoder.flows.5.wn_energy.cond_layer1.weight_v",
+              "decoder.flows.5.wn_energy.cond_layer1.bias", "decoder.flows.2.wn_energy.in_layers.1.weight_v"]
+
+
+def test_pitch_energy_conditioning_matches_reference_golden(built):
+    """cfg 5's per-frame conditioning: modules.WNP (modules.py:272-362) as wn_energy / wn_pitch of every coupling block
+    (attentions.py:153-154), next to the speaker vector — forward, log-det, input gradient, parameter gradients of the
+    cond_layer1 affine maps and of a WNP conv, reverse; pitch alone (wn_energy the identity).  Oracle restatement vs the
+    imported reference; the state_dict comes from the product's module (key / shape contract)."""
+    from glow_tts_amd import models
+    dec = models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, gin_channels=256, with_prosody_wn=True)
+    P = module_state(dec, "decoder.")
+    for n in PROS_GRADS:
+        assert n in P, n
+        P[n].requires_grad_(True)
+    spk, pit, ene, mask = t("spk_g"), t("pros_pitch"), t("pros_energy"), t("dec_mask")
+    y = t("dec_y").clone().requires_grad_(True)
+    z, ld = R.decoder_fwd(P, "decoder.", y, mask, spk, n_blocks=2, pitch=pit, energy=ene)
+    assert close(z, t("decp_z"), 1e-4) and close(ld, t("decp_logdet"), 1e-4)
+    tot = (z * torch.randn(z.shape, generator=torch.Generator().manual_seed(9))).sum() + \
+          (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(10))).sum()
+    gy, *gp = torch.autograd.grad(tot, [y] + [P[n] for n in PROS_GRADS])
+    assert close(gy, t("decp_gy"), 2e-4)
+    for n, g_ in zip(PROS_GRADS, gp):
+        assert close(g_, t("decp_g_" + n), 5e-4), n
+    with torch.no_grad():
+        assert close(R.decoder_rev(P, "decoder.", t("dec_rev_z"), mask, spk, n_blocks=2, pitch=pit, energy=ene), t("decp_rev_x"), 2e-4)
+        zo, _ = R.decoder_fwd(P, "decoder.", y, mask, spk, n_blocks=2, pitch=pit, energy=None)
+        assert close(zo, t("decp_z_pitch_only"), 1e-4)
