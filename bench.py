@@ -207,7 +207,7 @@ def main():
         # (same process, same stream, same data), with HIP events around each of its 48 launches per step.
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")
         for _ in range(3):
-            tr._step_impl(ids, t_x, y, t_y, lh, g=spk)
+            tr._step_impl(ids, t_x, y, t_y, lh, cond={"g": spk} if spk is not None else None)
     kt = ops.KERNEL_TIMER.collect()
     if world > 1:
         t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)

@@ -311,7 +311,8 @@ class FlowGenerator(nn.Module):
     def __init__(self, n_vocab, hidden_channels, filter_channels, filter_channels_dp, out_channels, kernel_size=3, n_heads=2,
                  n_layers_enc=6, p_dropout=0., n_blocks_dec=12, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                  p_dropout_dec=0., n_speakers=0, gin_channels=0, n_split=4, n_sqz=1, sigmoid_scale=False, window_size=None,
-                 block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False, **kwargs):
+                 block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False,
+                 with_prosody_wn=False, **kwargs):
         super().__init__()
         from .models import FlowSpecDecoder
         # Multi-speaker configs (cfg 4, configs/base_blank_ms.json: gin_channels=256): the speaker vector enters
@@ -325,7 +326,10 @@ class FlowGenerator(nn.Module):
                                    gin_channels=gin_channels)
         self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec, dilation_rate,
                                        n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec, n_split=n_split, n_sqz=n_sqz,
-                                       sigmoid_scale=sigmoid_scale, gin_channels=gin_channels)
+                                       sigmoid_scale=sigmoid_scale, gin_channels=gin_channels, with_prosody_wn=with_prosody_wn)
+        # with_prosody_wn: the fork's wn_pitch / wn_energy in every coupling block (attentions.py:113-114); forward() then
+        # takes the raw pitch / energy contours.  Their LOSSES (l_pitch / l_energy) come from the stochastic predictors of
+        # SURVEY §8 f1, which are not built: those two entries of the return tuple stay None.
         self._step = 0
 
     @torch.no_grad()
@@ -386,6 +390,16 @@ class FlowGenerator(nn.Module):
         prepare_all(self)
         self.encoder.proj_w.prepare_extra()
 
+    @staticmethod
+    def _contour(c, y_max_length):
+        """models.py:1054-1071: raw pitch / energy [b,1,t] (or [b,t]) -> log, with zeros (unvoiced / silent frames) kept 0."""
+        if c is None:
+            return None
+        c = (c.squeeze(1) if c.dim() == 3 else c)[:, :y_max_length]
+        zero = c == 0.0
+        n = torch.log(torch.clamp(c, min=torch.finfo(c.dtype).tiny))
+        return n.masked_fill(zero, 0.0).unsqueeze(1)
+
     def preprocess(self, y, y_lengths, y_max_length):
         """reference models.py:1248-1253"""
         if y_max_length is not None:
@@ -401,8 +415,8 @@ class FlowGenerator(nn.Module):
         defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
         decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
         data-parallel trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs."""
-        assert emo is None and emo_cartesian is None and pitch is None and energy is None and l is None, \
-            "emotion / pitch / energy / language inputs (cfg 5) are not on the round-1 path"
+        assert emo is None and emo_cartesian is None and l is None, \
+            "emotion / language inputs (cfg 5) are not on the round-1 path"
         assert (g is None) == (self.gin_channels == 0), "g [b, gin_channels, 1] is required exactly when gin_channels != 0"
         self.prepare()
         self._step += 1
@@ -421,7 +435,8 @@ class FlowGenerator(nn.Module):
                 self._deferred.append((x_logs, leaf)); x_logs = leaf
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
-        z, logdet = self.decoder(y, z_mask, g=g, prepared=True)
+        z, logdet = self.decoder(y, z_mask, g=g, pitch=self._contour(pitch, y_max_length), energy=self._contour(energy, y_max_length),
+                                 prepared=True)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             attn = mas.path.unsqueeze(1)

@@ -274,7 +274,7 @@ class Trainer:
         ops.RAGGED = os.environ.get("GT_RAGGED", "1") != "0"
         self.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
 
-    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, g=None):
+    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
         from . import ops
         m = self.model
         ops.bump_seed(ids.device)
@@ -282,7 +282,7 @@ class Trainer:
         self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
-        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, g=g, lengths_host=lengths_host)
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {}))
         l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
         loss = l_mle + torch.sum(l_length)
         loss.backward()
@@ -296,7 +296,7 @@ class Trainer:
         self.grad_norm = torch.sqrt(self.opt.step())
         ops.arena_end(device)
 
-    def _phase1(self, ids, t_x, y, t_y, lengths_host=None, g=None):
+    def _phase1(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
         """forward + the backward of everything but the text encoder; the decoder's gradients are then in the flat buffer."""
         from . import ops
         m = self.model
@@ -305,8 +305,8 @@ class Trainer:
         self.buckets.zero_accum()
         for p in self.buckets.params:
             p.grad = None
-        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, g=g, lengths_host=lengths_host,
-                                                                           defer_encoder_backward=True)
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host,
+                                                                           defer_encoder_backward=True, **(cond or {}))
         l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
         loss = l_mle + torch.sum(l_length)
         loss.backward()
@@ -317,21 +317,21 @@ class Trainer:
         self.model.backward_encoder()
         self.buckets.gather(0, self.dec0)
 
-    def _step_impl(self, ids, t_x, y, t_y, lengths_host=None, g=None):
+    def _step_impl(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
         if not self.split:
-            out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host, g)
+            out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host, cond)
             self.buckets.allreduce()
         else:
-            out = self._phase1(ids, t_x, y, t_y, lengths_host, g)
+            out = self._phase1(ids, t_x, y, t_y, lengths_host, cond)
             self.buckets.allreduce(self.dec0_off, None, wait=False)      # on the wire while the encoder's backward runs
             self._phase2()
             self.buckets.allreduce(0, self.dec0_off, wait=True)
         self._optim(ids.device)
         return out
 
-    def _capture(self, ids, t_x, y, t_y, lh, g=None):
+    def _capture(self, ids, t_x, y, t_y, lh, cond=None):
         from . import ops
-        static = [t.clone() for t in (ids, t_x, y, t_y)] + ([g.clone()] if g is not None else [])
+        static = [t.clone() for t in (ids, t_x, y, t_y)] + [{k: v.clone() for k, v in (cond or {}).items()}]
         ctxs = {}
         if ops.RAGGED:                               # row contexts live outside the graph; replays refresh them in place
             ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0])
@@ -345,14 +345,14 @@ class Trainer:
     def _capture_with(self, static, lh, ctxs):
         from . import ops
         ids = static[0]
-        g = static[4] if len(static) > 4 else None
+        cond = static[4]
         static = static[:4]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(3):                       # warm-up: one-time attribute calls, scratch growth, optimizer state
-                self._step_impl(*static, lengths_host=lh, g=g)
+                self._step_impl(*static, lengths_host=lh, cond=cond)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
@@ -360,11 +360,11 @@ class Trainer:
         g1 = torch.cuda.CUDAGraph()
         if not self.split:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
-                out = self._step_impl(*static, lengths_host=lh, g=g)
+                out = self._step_impl(*static, lengths_host=lh, cond=cond)
             graphs = (g1,)
         else:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
-                out = self._phase1(*static, lengths_host=lh, g=g)
+                out = self._phase1(*static, lengths_host=lh, cond=cond)
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
                 self._phase2()
@@ -372,7 +372,7 @@ class Trainer:
             with torch.cuda.graph(g3, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
                 self._optim(ids.device)
             graphs = (g1, g2, g3)
-        return graphs, static + ([g] if g is not None else []), out, ctxs
+        return graphs, static + [cond], out, ctxs
 
     def _rows_key(self, ids, y, lh):
         from . import ops
@@ -382,8 +382,10 @@ class Trainer:
         _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], y.shape[2] // 2, ops.ROW_ROUND)
         return (rx, ry)
 
-    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None):
-        """One optimizer step.  g [b, gin_channels, 1]: speaker vectors of the multi-speaker configs (cfg 4)."""
+    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None):
+        """One optimizer step.  g [b, gin_channels, 1]: speaker vectors of the multi-speaker configs (cfg 4);
+        pitch / energy [b, 1, t_y]: raw contours of cfg 5 (FlowGenerator.forward normalises them, models.py:1054-1071)."""
+        cond = {k: v for k, v in (("g", g), ("pitch", pitch), ("energy", energy)) if v is not None}
         from . import ops
         ops.ROW_ROUND = self.row_round
         if self.total_steps:
@@ -393,19 +395,19 @@ class Trainer:
         if ops.RAGGED and lh is None:
             lh = (t_x.tolist(), t_y.tolist())        # device sync: pass lengths_host to avoid it
         if not self.graph_mode:
-            return self._step_impl(ids, t_x, y, t_y, lh, g=g)
+            return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
         key = self._rows_key(ids, y, lh) + (tuple(ids.shape), tuple(y.shape))
         cap = self._captured.get(key)
         if cap is None:
             try:
-                cap = self._captured[key] = self._capture(ids, t_x, y, t_y, lh, g)
+                cap = self._captured[key] = self._capture(ids, t_x, y, t_y, lh, cond)
             except Exception as e:                   # e.g. a collective that refuses capture: keep training, eagerly
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({e!r}); continuing with eager launches")
                 self.graph_mode = False
-                return self._step_impl(ids, t_x, y, t_y, lh, g=g)
+                return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
         graphs, static, out, ctxs = cap
-        for dst, src in zip(static, (ids, t_x, y, t_y) + ((g,) if g is not None else ())):
+        for dst, src in list(zip(static[:4], (ids, t_x, y, t_y))) + [(static[4][k], v) for k, v in cond.items()]:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)

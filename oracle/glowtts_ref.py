@@ -349,14 +349,26 @@ def mle_loss(z, m, logs, logdet, mask):
     return l + 0.5 * math.log(2 * math.pi)
 
 
-def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None):
+def contour_norm(c, y_max):
+    """models.py:1054-1071: raw pitch / energy [b,1,t] -> log(clamp(., tiny)) with zeros kept at 0, [b,1,y_max]."""
+    if c is None:
+        return None
+    c = c.squeeze(1)[:, :y_max]
+    zero = c == 0.0
+    n = torch.log(torch.clamp(c, min=torch.finfo(c.dtype).tiny)).clone()
+    n[zero] = 0.0
+    return n.unsqueeze(1)
+
+
+def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pitch=None, energy=None):
     """The upstream-equivalent live sub-graph of models.FlowGenerator.forward
     (models.py:1050-1119) for the base configs (the fork's FlowGenerator does not
     construct for them): TextEncoder -> FlowSpecDecoder -> logp -> MAS -> duration loss
     (deterministic DurationPredictor, models.py:1089-1092) -> prior expansion -> mle loss.
     `maximum_path(value, mask) -> path` is the MAS implementation to use (tests pass the oracle).
     g [b,gin,1]: the speaker vector of the multi-speaker configs as it reaches the encoder / duration predictor /
-    decoder (models.py:1046,1075,1090)."""
+    decoder (models.py:1046,1075,1090).  pitch / energy: raw contours [b,1,t_y] of cfg 5 into the decoder's WNPs (their
+    predictor losses, SURVEY §8 f1, are not part of this sub-graph)."""
     n_sqz = hp.get("n_sqz", 2)
     x, x_m, x_logs, x_mask = text_encoder_fwd(P, "encoder.", ids, x_lengths, g, hp["hidden_channels"],
                                               hp["n_layers_enc"], hp["n_heads"], hp["window_size"],
@@ -367,7 +379,8 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None):
     z_mask = sequence_mask(y_lengths, y_max).unsqueeze(1).to(x_mask.dtype)
     attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
     z, logdet = decoder_fwd(P, "decoder.", y, z_mask, g, hp["n_blocks_dec"], hp["n_block_layers"],
-                            hp["hidden_channels"], hp["kernel_size_dec"], 4, n_sqz)
+                            hp["hidden_channels"], hp["kernel_size_dec"], 4, n_sqz,
+                            pitch=contour_norm(pitch, y_max), energy=contour_norm(energy, y_max))
     with torch.no_grad():
         logp = logp_lattice(x_m, x_logs, z)
         attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1).detach()

@@ -154,12 +154,12 @@ HP = dict(hidden_channels=192, n_layers_enc=2, n_heads=2, window_size=4, kernel_
           n_blocks_dec=2, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
 
 
-def _make_generator(n_layers_enc=2, gin_channels=0):
+def _make_generator(n_layers_enc=2, gin_channels=0, with_prosody_wn=False):
     from glow_tts_amd import models
     return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=n_layers_enc, p_dropout=0.1,
                                             n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                                             p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True,
-                                            gin_channels=gin_channels), "").eval()
+                                            gin_channels=gin_channels, with_prosody_wn=with_prosody_wn), "").eval()
 
 
 def test_text_encoder_fwd(built):
@@ -180,7 +180,8 @@ def test_text_encoder_fwd(built):
                                                      (300, 640, [300, 131], [640, 402], True, 0),       # cfg3-like (T_x > 256)
                                                      (300, 640, [300, 131], [640, 402], False, 0),
                                                      (45, 130, [45, 20], [130, 64], False, 256),        # cfg4-like: speaker vector g
-                                                     (45, 130, [45, 20], [130, 64], True, 256)])
+                                                     (45, 130, [45, 20], [130, 64], True, 256),
+                                                     (45, 130, [45, 20], [130, 64], True, -256)])       # cfg5-like: g + pitch + energy into the decoder
 def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     """Whole hot path: TextEncoder -> decoder -> logp -> MAS -> losses, forward and backward.  The
     alignment is compared on the HIP path's own lattice (bit-exact), then injected into the oracle so
@@ -188,11 +189,19 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     with gin: the multi-speaker form (cfg 4), g [b,256,1] into the encoder (3 layers, so that cond_g is reached),
     the duration predictor and every coupling block."""
     from glow_tts_amd import models, ops
-    gen = _make_generator(3 if gin else 2, gin)
+    prosody = gin < 0                       # negative gin: also the decoder's per-frame pitch / energy WaveNets (with 30 % unvoiced frames)
+    gin = abs(gin)
+    gen = _make_generator(3 if gin else 2, gin, with_prosody_wn=prosody)
     P = cpu_state(gen)
     g = torch.Generator().manual_seed(7)
     B = 2
     spk = torch.randn(B, gin, 1, generator=g) if gin else None
+    pitch = energy = None
+    if prosody:
+        # raw contours whose LOG (models.py:1054-1071) is O(1), so that the closed-form cond_layer1 weights keep the decoder
+        # in the numeric regime of the other cases (Hz-scale values saturate every gate and amplify z's bf16 error)
+        pitch = torch.exp(torch.randn(B, 1, Ty, generator=g)) * (torch.rand(B, 1, Ty, generator=g) > 0.3)
+        energy = torch.exp(0.5 * torch.randn(B, 1, Ty, generator=g))
     hp = dict(HP, n_layers_enc=3) if gin else HP
     ids = torch.randint(1, 148, (B, Tx), generator=g); xl = torch.tensor(xl)
     yl = torch.tensor(yl)
@@ -203,7 +212,8 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     ops.RAGGED = ragged
     try:
         (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
-            gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=None if spk is None else spk.to(dev()))
+            gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=None if spk is None else spk.to(dev()),
+                pitch=None if pitch is None else pitch.to(dev()), energy=None if energy is None else energy.to(dev()))
     finally:
         ops.RAGGED = False
     l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
@@ -215,7 +225,7 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     p = omas.oracle_maximum_path(gen.last_logp.cpu().numpy(), amask.cpu().numpy())
     assert np.array_equal(attn.squeeze(1).cpu().numpy().astype(np.int32), p)
 
-    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), hp, g=spk)
+    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), hp, g=spk, pitch=pitch, energy=energy)
     out["loss"].backward()
     assert relerr(gen.last_logp.cpu(), out["logp"]) < 3e-2
     assert relerr(z.detach().cpu(), out["z"].detach()) < 3e-2
@@ -229,11 +239,16 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
             assert prm.grad is None or prm.grad.abs().max().item() == 0, name
             continue
         assert prm.grad is not None, name
+        if name.endswith("cond_layer1.weight_v"):           # one input channel: w = g*v/|v| — a mathematically zero gradient
+            assert prm.grad.abs().max().item() <= 1e-3 * P[name[:-1] + "g"].grad.abs().max().item(), name
+            continue
         e = relerr(prm.grad.cpu(), ref)
         worst.append((e, name))
         # prenet convs sit under three conv -> LayerNorm -> ReLU stages: bf16 ReLU flips (see grad_ok) compound, and their
         # relative-L2 error sits at 0.08-0.12 whatever the sequence length; everything else stays below 0.1
-        tol = 0.15 if ".pre.conv_layers." in name else 0.1
+        # emb_rel_k / emb_rel_v gradients are sums of signed band entries over every (query, key) pair — heavy cancellation,
+        # so bf16 noise weighs more (0.05-0.15 depending on the case)
+        tol = 0.15 if ".pre.conv_layers." in name else (0.2 if "emb_rel_" in name else 0.1)
         if not grad_ok(prm.grad.cpu(), ref, tol, name=name):
             bad.append((name, round(e, 3)))
     worst.sort(reverse=True)

@@ -235,3 +235,40 @@ def test_speaker_conditioned_graph_step_matches_eager(built):
     for key in ("encoder.encoder.cond_g.weight", "encoder.proj_w.cond.weight", "decoder.flows.2.wn.cond_layer.weight_v",
                 "decoder.flows.5.wn.cond_layer.bias"):
         assert key in moved, key
+
+
+def test_prosody_conditioned_graph_step_matches_eager(built):
+    """cfg 5's decoder inputs through the trainer: g, pitch and energy are static inputs of the captured graph; the
+    captured and the eager step give the same updates and the WNP parameters (cond_layer1 included) move."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=3, p_dropout=0.0, p_dropout_dec=0.0, gin_channels=512,
+               with_prosody_wn=True)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    before = {n: p.detach().clone() for n, p in m1.named_parameters()}
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    spk = torch.randn(4, 512, 1, device=dev())
+    pitch = (80 + 200 * torch.rand(4, 1, 120, device=dev())) * (torch.rand(4, 1, 120, device=dev()) > 0.3)
+    energy = 1 + 10 * torch.rand(4, 1, 120, device=dev())
+    lh = (batch[1].tolist(), batch[3].tolist())
+    t1, t2 = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+    for _ in range(4):
+        l1, _ = t1.step(*batch, lengths_host=lh, g=spk, pitch=pitch, energy=energy)
+    l2, _ = t2.step(*batch, lengths_host=lh, g=spk, pitch=pitch, energy=energy)      # 3 warm-ups + 1 replay
+    torch.cuda.synchronize()
+    assert t2.graph_mode and len(t2._captured) == 1
+    assert math.isfinite(l1.item()) and abs(l1.item() - l2.item()) <= 2e-2 * max(1.0, abs(l1.item())), (l1.item(), l2.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst
+    moved = {n for n, p in m1.named_parameters() if (p.detach() - before[n]).abs().max().item() > 0}
+    for key in ("decoder.flows.2.wn_pitch.cond_layer1.weight_g", "decoder.flows.5.wn_energy.cond_layer1.bias",
+                "decoder.flows.2.wn_energy.in_layers.0.weight_v", "decoder.flows.5.wn_pitch.res_skip_layers.3.bias"):
+        assert key in moved, key
