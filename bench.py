@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — Glow-TTS training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5dec]
 
 One "step" = one full training step of the hot path (zero_grad, TextEncoder + FlowSpecDecoder
 forward, logp + MAS, mle + duration loss, backward, gradient all-reduce, grad-norm, AdamW) on
@@ -39,6 +39,10 @@ WORKLOADS = {
     "cfg4": dict(B=20, T_x=235, T_y=500, gin=256,
                  desc="configs/base_blank_ms.json-shaped synthetic batch (multi-speaker, gin_channels=256, g ~ N(0,1) [B,256,1]), "
                       "B=20/GPU, T_x<=235, T_y<=500, bf16 GEMMs"),
+    "cfg5dec": dict(B=32, T_x=127, T_y=400, gin=512, n_layers_enc=10, prosody=True,
+                    desc="configs/base_blank_emo_lang_pitch.json-shaped synthetic batch, B=32/GPU, T_x<=127, T_y<=400, gin_channels=512, "
+                         "10 encoder layers, 3 WaveNets per coupling block (wn + wn_energy + wn_pitch) with g, pitch, energy inputs; "
+                         "WITHOUT the emotion / language embeddings and the stochastic duration / pitch / energy predictors (SURVEY §8 f1)"),
 }
 
 
@@ -115,7 +119,7 @@ def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
     return e0.elapsed_time(e1) / (replays * launches), rc.R
 
 
-def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None):
+def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None, n_layers_enc=6, pitch=None, energy=None):
     """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
     from oracle import glowtts_ref as R
     from oracle import mas as omas
@@ -127,7 +131,7 @@ def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None):
         return torch.from_numpy(p).float()
     n = min(budget_utts, ids.shape[0])
     P = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    hp = dict(hidden_channels=192, n_layers_enc=6, n_heads=2, window_size=4, kernel_size=3, prenet=True, mean_only=True,
+    hp = dict(hidden_channels=192, n_layers_enc=n_layers_enc, n_heads=2, window_size=4, kernel_size=3, prenet=True, mean_only=True,
               n_blocks_dec=12, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
     ids_c, tx_c, y_c, ty_c = ids[:n].cpu(), t_x[:n].cpu().long(), y[:n].cpu(), t_y[:n].cpu().long()
     Tx, Ty = int(tx_c.max()), int(ty_c.max())
@@ -136,7 +140,8 @@ def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None):
     times = []
     for it in range(2):
         t0 = time.perf_counter()
-        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=None if g is None else g[:n].cpu())
+        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=None if g is None else g[:n].cpu(),
+                              pitch=None if pitch is None else pitch[:n, :, :Ty].cpu(), energy=None if energy is None else energy[:n, :, :Ty].cpu())
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
         for v in P.values():
@@ -174,7 +179,8 @@ def main():
     wl = WORKLOADS[args.workload]
     torch.manual_seed(1234)                          # identical initial weights on every rank
     gin = wl.get("gin", 0)
-    model = train.build_model(dict(train.BASE_MODEL, gin_channels=gin) if gin else None, device=dev).train()
+    cfg = dict(train.BASE_MODEL, gin_channels=gin, n_layers_enc=wl.get("n_layers_enc", 6), with_prosody_wn=bool(wl.get("prosody")))
+    model = train.build_model(cfg if (gin or wl.get("prosody")) else None, device=dev).train()
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
@@ -182,6 +188,11 @@ def main():
     tr = train.Trainer(model, world=world, graph=use_graph)
     ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
     spk = torch.randn(wl["B"], gin, 1, generator=torch.Generator().manual_seed(4321 + rank)).to(dev) if gin else None
+    cond = {"g": spk} if spk is not None else {}
+    if wl.get("prosody"):                            # pitch ~ U[80,280) Hz with 30 % unvoiced zeros, energy ~ U[1,11)
+        gp = torch.Generator().manual_seed(977 + rank)
+        cond["pitch"] = ((80 + 200 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)) * (torch.rand(wl["B"], 1, wl["T_y"], generator=gp) > 0.3)).to(dev)
+        cond["energy"] = (1 + 10 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)).to(dev)
     lh = (t_x.tolist(), t_y.tolist())                # host copy of the lengths (a data loader has them): no per-step sync
     valid_frames = int(t_y.sum().item())
     padded_frames = wl["B"] * wl["T_y"]
@@ -192,13 +203,13 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        tr.step(ids, t_x, y, t_y, lengths_host=lh, g=spk)
+        tr.step(ids, t_x, y, t_y, lengths_host=lh, **cond)
     barrier()
     if not use_graph:
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")  # HIP events around every launch of the dominant kernel
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh, g=spk)
+        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh, **cond)
     barrier()
     wall = time.perf_counter() - t0
     if use_graph:
@@ -207,7 +218,7 @@ def main():
         # (same process, same stream, same data), with HIP events around each of its 48 launches per step.
         ops.KERNEL_TIMER.enable("in_layer_gate_conv")
         for _ in range(3):
-            tr._step_impl(ids, t_x, y, t_y, lh, cond={"g": spk} if spk is not None else None)
+            tr._step_impl(ids, t_x, y, t_y, lh, cond=cond)
     kt = ops.KERNEL_TIMER.collect()
     if world > 1:
         t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)
@@ -269,7 +280,8 @@ def main():
                                     "frac": m["hbm_frac"], "traffic": None, "kernel": "gt_mas_dp_kernel + gt_mas_expand_kernel",
                                     "algorithmic_bytes_per_launch": m["algorithmic_bytes"]}}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model, g=spk)
+            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model, g=spk, n_layers_enc=wl.get("n_layers_enc", 6),
+                                                pitch=cond.get("pitch"), energy=cond.get("energy"))
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
