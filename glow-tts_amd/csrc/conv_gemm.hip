@@ -364,6 +364,20 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
+  // Short tiles: when 128-row tiles give fewer workgroups than the chip has CUs (one wave per SIMD, nothing to hide the
+  // LDS / L2 latency behind), 64-row tiles double the resident waves at the price of streaming the weights twice as often.
+  static int bm64 = -1;
+  if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 0; }
+  const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
+  if (bm64 && bnsel == 128 && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np >= N) {
+    const dim3 grid(8 * (((R + 63) / 64 + 7) / 8) * (Np / bnsel));
+    if (gate == 1) {
+      if (!gate_t || !gate_s || out_f32) return GT_E_INVAL;
+      if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
+      hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, true>), grid, block, 0, st, a);
+    } else hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, false>), grid, block, 0, st, a);
+    return gt_launch_status(__func__);
+  }
   if (gate == 1) {
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
     if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;

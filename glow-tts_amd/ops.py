@@ -223,13 +223,6 @@ class RowsCtx:
                    "gt_rows_utt_sum")
         return out
 
-    def batch_sum(self, rows):
-        """[R, C] -> [B, C]: sum over the rows of each utterance."""
-        if not self.ragged:
-            return rows.reshape(self.B, self.Tp, rows.shape[1]).sum(1)
-        out = torch.zeros(self.B, rows.shape[1], dtype=rows.dtype, device=rows.device)
-        return out.index_add_(0, self.rowbatch.long(), rows)
-
     @staticmethod
     def row_starts(lengths_host, T, rnd):
         """(starts [B+1] with starts[B] = R rounded up, R) of the ragged layout for these lengths."""

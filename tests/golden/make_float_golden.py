@@ -207,6 +207,13 @@ def main():
     out.update(pros_pitch=pit, pros_energy=ene, decp_z=zp, decp_logdet=ldp, decp_gy=gyp, decp_rev_x=xrp, decp_z_pitch_only=zpo)
     out.update({"decp_g_" + n: v for n, v in zip(names, gps)})
 
+    # ---- CouplingBlock with sigmoid_scale=True (attentions.py:172-173): logs = log(1e-6 + sigmoid(logs + 2))
+    cbs = fill_module(attentions.CouplingBlock(160, 192, 5, 1, 4, gin_channels=0, p_dropout=0.05, sigmoid_scale=True, n_sqz=2), "cb.").eval()
+    xs_ = xc.detach().clone().requires_grad_(True)
+    zs_, lds_ = cbs(xs_, m)
+    (gxs_,) = grads_of([(zs_, 11), (lds_, 12)], [xs_])
+    out.update(cbs_z=zs_, cbs_logdet=lds_, cbs_gx=gxs_)
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

@@ -96,10 +96,10 @@ def test_actnorm_invconv_fwd_bwd(built):
     assert relerr(grads[Wd].cpu(), W.grad) < 1e-4
 
 
-def _run_decoder_case(n_blocks, B, T, lens, seed, check_params):
+def _run_decoder_case(n_blocks, B, T, lens, seed, check_params, sigmoid_scale=False):
     from glow_tts_amd import models
     torch.manual_seed(seed)
-    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, n_blocks, 4, p_dropout=0.05), "decoder.").eval()
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, n_blocks, 4, p_dropout=0.05, sigmoid_scale=sigmoid_scale), "decoder.").eval()
     P = cpu_state(dec, "decoder.")
     for v in P.values():
         v.requires_grad_(True)
@@ -107,7 +107,7 @@ def _run_decoder_case(n_blocks, B, T, lens, seed, check_params):
     m = lens_mask(lens, T)
     y = torch.randn(B, 80, T, generator=g) * m
     yy = y.clone().requires_grad_(True)
-    z, ld = R.decoder_fwd(P, "decoder.", yy, m, n_blocks=n_blocks)
+    z, ld = R.decoder_fwd(P, "decoder.", yy, m, n_blocks=n_blocks, sigmoid_scale=sigmoid_scale)
     rz = torch.randn(z.shape, generator=g) * m[:, :, :z.shape[2]]; rl = torch.randn(B, generator=g) * 0.1
     ((z * rz).sum() + (ld * rl).sum()).backward()
 
@@ -133,6 +133,11 @@ def _run_decoder_case(n_blocks, B, T, lens, seed, check_params):
 
 def test_decoder_two_blocks_fwd_bwd(built):
     _run_decoder_case(2, 2, 48, [48, 26], seed=3, check_params=True)
+
+
+def test_decoder_sigmoid_scale(built):
+    """sigmoid_scale=True (attentions.py:172-173; oracle pinned by cbs_* in float_golden.npz): forward, log-det, gradients."""
+    _run_decoder_case(2, 2, 48, [48, 26], seed=5, check_params=True, sigmoid_scale=True)
 
 
 def test_decoder_odd_length_and_ragged(built):

@@ -212,3 +212,16 @@ def test_pitch_energy_conditioning_matches_reference_golden(built):
         assert close(R.decoder_rev(P, "decoder.", t("dec_rev_z"), mask, spk, n_blocks=2, pitch=pit, energy=ene), t("decp_rev_x"), 2e-4)
         zo, _ = R.decoder_fwd(P, "decoder.", y, mask, spk, n_blocks=2, pitch=pit, energy=None)
         assert close(zo, t("decp_z_pitch_only"), 1e-4)
+
+
+def test_coupling_sigmoid_scale_matches_reference_golden(built):
+    """sigmoid_scale=True (attentions.py:172-173): logs = log(1e-6 + sigmoid(logs + 2)) — forward, log-det, input gradient."""
+    from glow_tts_amd import attentions
+    P = module_state(attentions.CouplingBlock(160, 192, 5, 1, 4, p_dropout=0.05, sigmoid_scale=True), "cb.")
+    x = t("cb_x").clone().requires_grad_(True)
+    z, ld = R.coupling_fwd(P, "cb.", x, t("an_mask"), sigmoid_scale=True)
+    assert close(z, t("cbs_z")) and close(ld, t("cbs_logdet"))
+    tot = (z * torch.randn(z.shape, generator=torch.Generator().manual_seed(11))).sum() + \
+          (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(12))).sum()
+    (gx,) = torch.autograd.grad(tot, [x])
+    assert close(gx, t("cbs_gx"), 1e-4)
