@@ -197,7 +197,9 @@ class FlatAdamW:
         self.m = torch.zeros_like(gb.flat)
         self.v = torch.zeros_like(gb.flat)
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 0.0], dtype=torch.float32, device=dev)
-        self._host = torch.empty(2, dtype=torch.float32).pin_memory()
+        self._host = torch.empty(2, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._host = self._host.pin_memory()
         self.gnorm_sq = None
 
     def set_schedule(self, lr, beta1):
