@@ -8,6 +8,7 @@
                       round-1 scope).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -303,6 +304,17 @@ def mle_loss(z, m, logs, logdet, mask):
     return _MleLossFn.apply(z, m, logs, logdet, mask)
 
 
+ENCODER_STREAM = os.environ.get("GT_ENC_STREAM", "1") != "0"
+_ENC_STREAMS = {}
+
+
+def _encoder_stream(dev):
+    key = str(dev)
+    if key not in _ENC_STREAMS:
+        _ENC_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _ENC_STREAMS[key]
+
+
 class FlowGenerator(nn.Module):
     """Training forward of Glow-TTS for the base configs (configs/base.json, base_blank.json):
     TextEncoder -> FlowSpecDecoder -> logp -> MAS -> durations / prior expansion, with the return
@@ -378,6 +390,15 @@ class FlowGenerator(nn.Module):
         y, logdet = self.decoder(z, z_mask, g=g, reverse=True, prepared=True)
         return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
 
+    def _predict_logw(self, g):
+        """logw = proj_w(x.detach(), x_mask, g) (models.py:1090) on the rows the text encoder just produced."""
+        rc, xb = self.encoder._last_rows
+        dvec = self.encoder.proj_w.cond_vec(g)
+        runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff,
+                                 has_cond=dvec is not None)
+        (logw,) = _RowsFn.apply(runner, 1, *([dvec] if dvec is not None else []), *runner.params)
+        return logw
+
     def backward_encoder(self):
         """Second half of a backward started with defer_encoder_backward=True."""
         pend = [(src, leaf.grad) for src, leaf in self._deferred if leaf.grad is not None]
@@ -425,7 +446,21 @@ class FlowGenerator(nn.Module):
             ops._HOST_LENGTHS["x"], ops._HOST_LENGTHS["y"] = list(lh[0]), list(lh[1])
         else:
             ops._HOST_LENGTHS.clear()
-        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
+        # The text encoder (needs the text only) and the decoder (needs the mel only) are independent until the likelihood
+        # lattice, and so are their backward passes: the encoder runs on its own stream (a parallel branch of the step's HIP
+        # graph) — autograd replays each node's backward on the stream of its forward, so the encoder's backward overlaps
+        # the decoder's too.  Both are chains of latency-bound kernels on a fraction of the CUs.
+        fork = ENCODER_STREAM and x.is_cuda
+        if fork:
+            main = torch.cuda.current_stream(x.device)
+            enc_stream = _encoder_stream(x.device)
+            enc_stream.wait_stream(main)
+            with torch.cuda.stream(enc_stream):
+                xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
+                logw = self._predict_logw(g)      # needs the encoder's output only (x is detached, models.py:586): same branch
+        else:
+            xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
+            logw = None
         self._deferred = []
         if defer_encoder_backward:
             leaf = x_m.detach().requires_grad_(True)
@@ -437,16 +472,17 @@ class FlowGenerator(nn.Module):
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
         z, logdet = self.decoder(y, z_mask, g=g, pitch=self._contour(pitch, y_max_length), energy=self._contour(energy, y_max_length),
                                  prepared=True)
+        if fork:
+            main.wait_stream(enc_stream)
+            for t_ in (xo, x_m, x_logs, x_mask, logw):
+                t_.record_stream(main)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             attn = mas.path.unsqueeze(1)
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         logw_ = torch.log(w + 1e-8) * x_mask
-        rc, xb = self.encoder._last_rows
-        dvec = self.encoder.proj_w.cond_vec(g)
-        runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff,
-                                 has_cond=dvec is not None)
-        (logw,) = _RowsFn.apply(runner, 1, *([dvec] if dvec is not None else []), *runner.params)
+        if logw is None:
+            logw = self._predict_logw(g)
         l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)  # models.py:1089-1092
         z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
         z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)

@@ -68,12 +68,15 @@ def active():
 
 
 def _scratch(dev, nbytes):
-    buf = _SCRATCH.get(str(dev))
+    """Partial-sum workspace of a flush, one per (device, stream the flush runs on): flushes on different streams (the
+    decoder's and the text encoder's backward run concurrently, text_models.ENCODER_STREAM) must not share it."""
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None and buf.is_cuda:
             buf.record_stream(torch.cuda.current_stream(dev))       # kernels of an earlier flush may still read it
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        _SCRATCH[str(dev)] = buf
+        _SCRATCH[key] = buf
     return buf
 
 
