@@ -57,10 +57,46 @@ class FlowSpecDecoder(nn.Module):
                 runner = _DecoderRunner(self, x_mask, g is not None, False, 0, energy, pitch)
                 return runner.reverse(x.detach(), conds, self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)), None
         self._step += 1
-        runner = _DecoderRunner(self, x_mask, g is not None, self.training, (self._step * 7919) & 0x7fffffff, energy, pitch)
-        extra = list(_wn_cond_all(wns, g)) if g is not None else []
-        extra += [a for a in (self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)) if a is not None]
-        z, logdet = _RowsFn.apply(runner, 2, x, *extra, *runner.params)
+        seed = (self._step * 7919) & 0x7fffffff
+        conds = list(_wn_cond_all(wns, g)) if g is not None else []
+        affs = [a for a in (self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)) if a is not None]
+        G = decoder_groups(x)
+        if G == 1:
+            runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed, energy, pitch)
+            z, logdet = _RowsFn.apply(runner, 2, x, *conds, *affs, *runner.params)
+            return z, logdet
+        # Utterances are independent through the decoder and its kernels are latency-bound at <= 1 workgroup per CU: run G
+        # interleaved utterance groups as G autograd nodes on G streams (parallel branches of the step's HIP graph; the
+        # backward of each node replays on its stream).  Their weight gradients go out group after group on the wgrad side
+        # stream, the first one writing and the others adding (WgradQueue(accumulate=...)).
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        streams = _group_streams(dev, G)
+        self._wgrad_round = 0
+        lh = ops._HOST_LENGTHS.get("y")
+        B = x.shape[0]
+        parts = []
+        for gi in range(G):
+            sl = slice(gi, None, G)
+            st = main if gi == 0 else streams[gi]
+            if gi:
+                st.wait_stream(main)
+            if lh is not None:
+                ops._HOST_LENGTHS[f"y{gi}"] = list(lh[sl])
+            with torch.cuda.stream(st):
+                runner = _DecoderRunner(self, x_mask[sl].contiguous(), g is not None, self.training, seed + 1009 * gi,
+                                        None if energy is None else energy[sl].contiguous(),
+                                        None if pitch is None else pitch[sl].contiguous(), ctx_key=f"y{gi}", group=gi)
+                zg, ldg = _RowsFn.apply(runner, 2, x[sl].contiguous(), *[c[sl].contiguous() for c in conds], *affs, *runner.params)
+            parts.append((zg, ldg))
+        for gi in range(1, G):
+            main.wait_stream(streams[gi])
+            parts[gi][0].record_stream(main); parts[gi][1].record_stream(main)
+        z = torch.empty((B,) + tuple(parts[0][0].shape[1:]), dtype=parts[0][0].dtype, device=dev)
+        logdet = torch.empty(B, dtype=parts[0][1].dtype, device=dev)
+        for gi, (zg, ldg) in enumerate(parts):
+            z[gi::G] = zg
+            logdet[gi::G] = ldg
         return z, logdet
 
     def _prosody_affine(self, which, contour):
@@ -76,10 +112,39 @@ class FlowSpecDecoder(nn.Module):
         return torch.stack([w, torch.stack([c.bias for c in cls])], dim=1)
 
 
+DECODER_GROUPS = int(os.environ.get("GT_DECODER_GROUPS", "1"))
+_GROUP_STREAMS = {}
+
+
+def decoder_groups(x):
+    """number of concurrent utterance groups the decoder forward / backward is split into for this input"""
+    G = DECODER_GROUPS
+    return G if (G > 1 and x.is_cuda and x.shape[0] >= 2 * G) else 1
+
+
+def _group_streams(dev, G):
+    lst = _GROUP_STREAMS.setdefault(str(dev), [None])
+    while len(lst) < G:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst
+
+
+class _Site:
+    pass
+
+
+def _group_site(dec, gi):
+    sites = dec.__dict__.setdefault("_group_sites", {})
+    if gi not in sites:
+        sites[gi] = _Site()
+    return sites[gi]
+
+
 class _DecoderRunner:
-    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None):
+    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None, ctx_key="y", group=None):
         self.dec, self.has_cond, self.train, self.seed = dec, has_cond, train, seed
         self.x_mask = x_mask
+        self.ctx_key, self.group = ctx_key, group       # utterance group of models.DECODER_GROUPS (None: the whole batch)
         self.energy, self.pitch = energy, pitch                                   # [b,1,t] contours (no gradient) or None
         self.params = [p for n, p in dec.named_parameters() if ".wn.cond_layer." not in n and "cond_layer1" not in n]
 
@@ -124,7 +189,7 @@ class _DecoderRunner:
         dev = x.device
         T2 = T // 2
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)          # mask[:, :, 1::2] (commons.py:348)
-        rc = ops.make_ctx(len_sq, T2, "y", div=2)
+        rc = ops.make_ctx(len_sq, T2, self.ctx_key, div=2)
         xin = x.detach().float().contiguous()
         rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
@@ -152,7 +217,7 @@ class _DecoderRunner:
         dev = z.device
         T2 = T // 2
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)
-        rc = ops.make_ctx(len_sq, T2, "y", div=2)
+        rc = ops.make_ctx(len_sq, T2, self.ctx_key, div=2)
         zin = z.float().contiguous()
         cur = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
@@ -193,9 +258,20 @@ class _DecoderRunner:
         # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
         # side stream, beside the rest of the chain)
         chunk = int(os.environ.get("GT_WGRAD_CHUNK", "12"))
+        site, acc, side = dec, False, False
+        if self.group is not None:
+            # concurrent groups write the same flat gradient slices: order their flushes on the wgrad side stream, the
+            # first of the step writes, the rest add.  (Without a flat buffer every flush has its own outputs and
+            # autograd adds them up.)
+            flat = hasattr(self.params[0], "_gt_flat_grad")
+            side = flat
+            acc = flat and dec._wgrad_round > 0
+            dec._wgrad_round += 1
+            site = _group_site(dec, self.group)
+            chunk = nb
         for b1 in range(nb, 0, -chunk):
             b0 = max(0, b1 - chunk)
-            with wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else dec):
+            with wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else site, accumulate=acc, side_stream=side):
                 for b in reversed(range(b0, b1)):
                     an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
                     s1, s2 = saved[b]

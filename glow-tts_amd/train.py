@@ -337,7 +337,9 @@ class Trainer:
         ctxs = {}
         if ops.RAGGED:                               # row contexts live outside the graph; replays refresh them in place
             ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0])
-            ctxs["y"] = ops.RowsCtx((static[3] // 2).to(torch.int32), y.shape[2] // 2, lengths_host=[int(v) // 2 for v in lh[1]])
+            for key, sl in self._y_groups(y):        # one context per concurrent utterance group of the decoder
+                ctxs[key] = ops.RowsCtx((static[3][sl] // 2).to(torch.int32), y.shape[2] // 2,
+                                        lengths_host=[int(v) // 2 for v in lh[1][sl]])
         ops._PREBUILT.update(ctxs)
         try:
             return self._capture_with(static, lh, ctxs)
@@ -376,13 +378,20 @@ class Trainer:
             graphs = (g1, g2, g3)
         return graphs, static + [cond], out, ctxs
 
+    @staticmethod
+    def _y_groups(y):
+        """[(context key, batch slice)] of the decoder's utterance groups (models.DECODER_GROUPS; one group: the batch)"""
+        G = models.decoder_groups(y)
+        return [("y", slice(None))] if G == 1 else [(f"y{gi}", slice(gi, None, G)) for gi in range(G)]
+
     def _rows_key(self, ids, y, lh):
         from . import ops
         if not ops.RAGGED:
             return (0, 0)
         _, rx = ops.RowsCtx.row_starts(lh[0], ids.shape[1], ops.ROW_ROUND)
-        _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], y.shape[2] // 2, ops.ROW_ROUND)
-        return (rx, ry)
+        rys = tuple(ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1][sl]], y.shape[2] // 2, ops.ROW_ROUND)[1]
+                    for _, sl in self._y_groups(y))
+        return (rx,) + rys
 
     def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None):
         """One optimizer step.  g [b, gin_channels, 1]: speaker vectors of the multi-speaker configs (cfg 4);
@@ -413,7 +422,9 @@ class Trainer:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)
-            ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
+            ok = ctxs["x"].refresh(static[1], lh[0])
+            for key, sl in self._y_groups(y):
+                ok = ok and ctxs[key].refresh(static[3][sl] // 2, [int(v) // 2 for v in lh[1][sl]])
             assert ok, "row count of the batch does not match the captured graph"
         graphs[0].replay()
         if len(graphs) > 1:                          # collectives sit BETWEEN the graphs, never inside one

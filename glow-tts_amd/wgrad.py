@@ -94,10 +94,14 @@ class WgradQueue:
     """`with WgradQueue(dev) as q:` — conv_param_grads() inside only records (conv, x, dy) and hands back the
     (still unwritten) gradient tensors; leaving the block launches the batched kernels that fill them."""
 
-    def __init__(self, device, site=None):
+    def __init__(self, device, site=None, accumulate=False, side_stream=False):
         self.dev = device
         self.site = site            # object that owns the cached tables (the runner's module)
         self.items = []             # (conv, R, parts[(x, dy, co_begin, co_count)], dv, dg, db)
+        # accumulate: the gradients are ADDED to what their destinations hold (a second utterance group of the same step:
+        # models.DECODER_GROUPS); side_stream: flush on the wgrad side stream even without ASYNC, so that the flushes of
+        # concurrent groups are ordered among themselves
+        self.accumulate, self.force_side = accumulate, side_stream
 
     def __enter__(self):
         _ACTIVE.append(self)
@@ -147,7 +151,7 @@ class WgradQueue:
             v = conv.weight_v if conv.weight_norm else conv.weight
             wnbs.append((part_off, pb_off, v.data_ptr(), conv.weight_g.data_ptr() if dg is not None else 0,
                          pc.inv_norm.data_ptr() if dg is not None else 0, dv.data_ptr(), dg.data_ptr() if dg is not None else 0,
-                         db.data_ptr() if db is not None else 0, S, Cout, Cin, taps, row, 0, 0, 0))
+                         db.data_ptr() if db is not None else 0, S, Cout, Cin, taps, row, int(self.accumulate), 0, 0))
             row += Cout
             max_n = max(max_n, Cin * taps)
         return jobs, tiles, wnbs, row, max_n, off
@@ -156,7 +160,7 @@ class WgradQueue:
         if not self.items:
             return
         dev = self.dev
-        if ASYNC and dev.type == "cuda":
+        if (ASYNC or self.force_side) and dev.type == "cuda":
             cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
             side.wait_stream(cur)
             for conv, R, parts, dv, dg, db in self.items:          # these outlive the backward node on the side stream
@@ -234,7 +238,7 @@ class WgradQueue:
             ta = np.concatenate(tl) if tl else np.zeros(1, dtype=TILE)
             cache["skey"], cache["tiles"], cache["counts"] = skey, upload(ta), counts
             cache["pkey"] = None
-        pkey = (base, tuple(j[:4] for j in jobs), tuple(w[2:8] for w in wnbs))
+        pkey = (base, tuple(j[:4] for j in jobs), tuple(w[2:8] for w in wnbs), self.accumulate)
         if cache.get("pkey") != pkey:
             ja = np.array([(j[0], j[1], base + j[2], (base + j[3]) if j[3] >= 0 else 0) + j[4:] for j in jobs], dtype=JOB)
             wa = np.array([(base + w[0], base + w[1]) + w[2:] for w in wnbs], dtype=WNB)

@@ -282,3 +282,38 @@ def test_decoder_pitch_energy_speaker_conditioning(built, ragged, pitch_only):
         assert e < 6e-2, (name, e)
     want = R.decoder_rev(P, "decoder.", zrev, m, spk, n_blocks=n_blocks, pitch=pit, energy=ene)
     assert relerr(xr.cpu(), want.detach()) < 3e-2
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_decoder_utterance_groups_match_the_single_chain(built, ragged):
+    """models.DECODER_GROUPS: the decoder run as 2 interleaved utterance groups on 2 streams (uneven: 3 + 2 utterances)
+    gives the same outputs and gradients as one chain over the batch (evaluation mode: dropout masks are indexed by row)."""
+    from glow_tts_amd import models, ops
+    B, T, lens = 5, 50, [50, 27, 12, 44, 31]
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, gin_channels=256), "decoder.").eval().to(dev())
+    g = torch.Generator().manual_seed(31)
+    m = lens_mask(lens, T).to(dev())
+    y = (torch.randn(B, 80, T, generator=g)).to(dev()) * m
+    spk = torch.randn(B, 256, 1, generator=g).to(dev())
+    rz = torch.randn(B, 80, T, generator=g).to(dev()) * m; rl = (torch.randn(B, generator=g) * 0.1).to(dev())
+    res = []
+    ops.RAGGED = ragged
+    try:
+        for G in (1, 2):
+            models.DECODER_GROUPS = G
+            for p in dec.parameters():
+                p.grad = None
+            yy, gg = y.clone().requires_grad_(True), spk.clone().requires_grad_(True)
+            z, ld = dec(yy, m, g=gg)
+            ((z * rz).sum() + (ld * rl).sum()).backward()
+            torch.cuda.synchronize()
+            res.append((z.detach().clone(), ld.detach().clone(), yy.grad.clone(), gg.grad.clone(),
+                        {n: p.grad.clone() for n, p in dec.named_parameters()}))
+    finally:
+        models.DECODER_GROUPS = 1
+        ops.RAGGED = False
+    (z1, l1, gy1, gg1, p1), (z2, l2, gy2, gg2, p2) = res
+    assert torch.equal(z1, z2) and torch.allclose(l1, l2, rtol=1e-5, atol=1e-4)
+    assert relerr(gy2, gy1) < 1e-5 and relerr(gg2, gg1) < 1e-3
+    for n in p1:
+        assert relerr(p2[n], p1[n]) < 2e-3, (n, relerr(p2[n], p1[n]))         # slab / atomic summation order differs

@@ -272,3 +272,41 @@ def test_prosody_conditioned_graph_step_matches_eager(built):
     for key in ("decoder.flows.2.wn_pitch.cond_layer1.weight_g", "decoder.flows.5.wn_energy.cond_layer1.bias",
                 "decoder.flows.2.wn_energy.in_layers.0.weight_v", "decoder.flows.5.wn_pitch.res_skip_layers.3.bias"):
         assert key in moved, key
+
+
+def test_graph_step_with_decoder_utterance_groups(built):
+    """models.DECODER_GROUPS = 2 under the trainer: the groups are parallel branches of the captured graph, each with its
+    own prebuilt row context, and their weight gradients accumulate into the flat buffer — same updates as the eager,
+    ungrouped trainer (dropout off), also after a replay on a different batch of the same row bucket."""
+    from glow_tts_amd import models, train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    bA, bB = train.synth_batch(6, 40, 120, 0, dev()), train.synth_batch(6, 40, 120, 7, dev())
+    te = train.Trainer(m1, graph=False)
+    te.row_round = 1024
+    seq = [bA, bA, bA, bA, bB, bA]
+    for b in seq:
+        le, _ = te.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))
+    models.DECODER_GROUPS = 2
+    try:
+        tg = train.Trainer(m2, graph=True)
+        tg.row_round = 1024
+        lg, _ = tg.step(*bA, lengths_host=(bA[1].tolist(), bA[3].tolist()))        # 3 warm-ups + 1 replay
+        for b in seq[4:]:
+            lg, _ = tg.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))
+        torch.cuda.synchronize()
+    finally:
+        models.DECODER_GROUPS = 1
+    assert tg.graph_mode and len(tg._captured) == 1
+    assert abs(le.item() - lg.item()) <= 2e-2 * max(1.0, abs(le.item())), (le.item(), lg.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst
