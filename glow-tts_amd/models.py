@@ -86,7 +86,7 @@ class FlowSpecDecoder(nn.Module):
             with torch.cuda.stream(st):
                 runner = _DecoderRunner(self, x_mask[sl].contiguous(), g is not None, self.training, seed + 1009 * gi,
                                         None if energy is None else energy[sl].contiguous(),
-                                        None if pitch is None else pitch[sl].contiguous(), ctx_key=f"y{gi}", group=gi)
+                                        None if pitch is None else pitch[sl].contiguous(), ctx_key=f"y{gi}", group=gi, n_groups=G)
                 zg, ldg = _RowsFn.apply(runner, 2, x[sl].contiguous(), *[c[sl].contiguous() for c in conds], *affs, *runner.params)
             parts.append((zg, ldg))
         for gi in range(1, G):
@@ -141,10 +141,10 @@ def _group_site(dec, gi):
 
 
 class _DecoderRunner:
-    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None, ctx_key="y", group=None):
+    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None, ctx_key="y", group=None, n_groups=1):
         self.dec, self.has_cond, self.train, self.seed = dec, has_cond, train, seed
         self.x_mask = x_mask
-        self.ctx_key, self.group = ctx_key, group       # utterance group of models.DECODER_GROUPS (None: the whole batch)
+        self.ctx_key, self.group, self.n_groups = ctx_key, group, n_groups   # utterance group of models.DECODER_GROUPS (None: the whole batch)
         self.energy, self.pitch = energy, pitch                                   # [b,1,t] contours (no gradient) or None
         self.params = [p for n, p in dec.named_parameters() if ".wn.cond_layer." not in n and "cond_layer1" not in n]
 
@@ -258,7 +258,7 @@ class _DecoderRunner:
         # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
         # side stream, beside the rest of the chain)
         chunk = int(os.environ.get("GT_WGRAD_CHUNK", "12"))
-        site, acc, side = dec, False, False
+        site, acc, side, hand_over = dec, False, False, True
         if self.group is not None:
             # concurrent groups write the same flat gradient slices: order their flushes on the wgrad side stream, the
             # first of the step writes, the rest add.  (Without a flat buffer every flush has its own outputs and
@@ -267,6 +267,9 @@ class _DecoderRunner:
             side = flat
             acc = flat and dec._wgrad_round > 0
             dec._wgrad_round += 1
+            # every group's kernels write the SAME flat slices: autograd must see each parameter's gradient once (from the
+            # group whose backward runs last), not G aliases of one buffer that it would add to each other
+            hand_over = (not flat) or dec._wgrad_round == self.n_groups
             site = _group_site(dec, self.group)
             chunk = nb
         for b1 in range(nb, 0, -chunk):
@@ -300,7 +303,18 @@ class _DecoderRunner:
         if self.has_cond:
             out += dconds
         out += [d for d in (deaff, dpaff) if d is not None]
-        return out + [grads.get(p) for p in self.params]
+        if self.group is not None and dec._wgrad_round == self.n_groups:
+            # last group of the step's backward (the others are already enqueued on their streams): tie them to this
+            # stream, which autograd joins with its caller through the parameter gradients handed over below
+            cur = torch.cuda.current_stream(dev)
+            for st in _group_streams(dev, self.n_groups)[1:]:
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+        if hand_over:
+            return out + [grads.get(p) for p in self.params]
+        flat_store = self.params[0]._gt_flat_grad[0].untyped_storage().data_ptr()
+        keep = lambda t: t if (t is not None and t.untyped_storage().data_ptr() != flat_store) else None   # noqa: E731
+        return out + [keep(grads.get(p)) for p in self.params]
 
 
 from .text_models import DurationPredictor, FlowGenerator, TextEncoder, mle_loss  # noqa: E402,F401
