@@ -157,9 +157,30 @@ class _PackPlan:
 
 def prepare_all(module):
     """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step."""
+    wns, mhas = [], []
     for m in module.modules():
-        if hasattr(m, "_refresh_padded"):
+        if isinstance(m, WN):
+            wns.append(m)
+        elif hasattr(m, "conv_q") and hasattr(m, "qkv_bias"):
+            mhas.append(m)
+        elif hasattr(m, "_refresh_padded"):
             m._refresh_padded()
+    with torch.no_grad():
+        # derived biases of every WN (sum of the layers' skip biases) and every attention layer (q | k | v): ONE
+        # gather + ONE reduction for the whole model instead of two small launches per module
+        if wns and all(w.n_layers == wns[0].n_layers and w.hidden_channels == wns[0].hidden_channels for w in wns):
+            H, n = wns[0].hidden_channels, wns[0].n_layers
+            sb = torch.cat([rs.bias[-H:] for w in wns for rs in w.res_skip_layers]).view(len(wns), n, H).sum(1)
+            for w, row in zip(wns, sb):
+                w.skip_bias = row
+        else:
+            for w in wns:
+                w._refresh_padded()
+        if mhas:
+            C = mhas[0].channels
+            qb = torch.cat([c.bias for a in mhas for c in (a.conv_q, a.conv_k, a.conv_v)]).view(len(mhas), 3 * C)
+            for a, row in zip(mhas, qb):
+                a.qkv_bias = row
     plan = getattr(module, "_pack_plan", None)
     if plan is not None:
         cur = tuple(e[0].data_ptr() for e in plan.keep)
