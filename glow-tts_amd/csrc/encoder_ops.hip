@@ -472,6 +472,20 @@ __global__ __launch_bounds__(1024) void gt_rows_utt_sum_kernel(const void* __res
   }
 }
 
+// ragged rows layout: row -> (utterance, frame, valid) tables from the row offsets, one launch (was a dozen host-side ops)
+__global__ __launch_bounds__(256) void gt_rows_ctx_fill_kernel(const int32_t* __restrict__ row0, const int32_t* __restrict__ lens,
+                                                               int64_t* __restrict__ rowbatch, int32_t* __restrict__ rowframe,
+                                                               float* __restrict__ rowmask, int B, int R)
+{
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= R) return;
+  const int b = gt_row_batch(row0, B, m, 0);
+  const int t = m - row0[b] - HALO;
+  rowbatch[m] = b;
+  rowframe[m] = t;
+  rowmask[m] = (t >= 0 && t < lens[b]) ? 1.f : 0.f;
+}
+
 // ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
 // logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
 //               + sum_d -0.5 m_id^2 e^{-2 s_id}
@@ -746,6 +760,13 @@ extern "C" int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* 
   const dim3 grid(B, (C + 63) / 64);
   if (is_f32) hipLaunchKernelGGL(gt_rows_utt_sum_kernel<true>, grid, dim3(1024), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
   else        hipLaunchKernelGGL(gt_rows_utt_sum_kernel<false>, grid, dim3(1024), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
+  GT_RET();
+}
+extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask,
+                               int B, int R, void* stream)
+{
+  if (!row0 || !lens || !rowbatch || !rowframe || !rowmask || B <= 0 || R <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_ctx_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, GT_ST(stream), row0, lens, rowbatch, rowframe, rowmask, B, R);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

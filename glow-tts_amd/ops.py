@@ -205,11 +205,10 @@ class RowsCtx:
 
     def _fill(self, starts):
         """row0 (host list) -> device row0, row -> utterance, row -> frame, rowmask; all in place."""
-        self.row0.copy_(torch.tensor(starts, dtype=torch.int32).pin_memory(), non_blocking=True)
-        m = torch.arange(self.R, device=self.device, dtype=torch.int32)
-        self.rowbatch.copy_(torch.searchsorted(self.row0[1:].contiguous(), m, right=True).clamp_(max=self.B - 1))
-        self.rowframe.copy_(m - self.row0[:-1][self.rowbatch] - HALO)
-        self.rowmask.copy_(((self.rowframe >= 0) & (self.rowframe < self.lengths[self.rowbatch])).to(torch.float32))
+        self.row0.copy_(torch.tensor(starts, dtype=torch.int32))       # pageable source: the copy is staged before returning
+        _lib.check(_lib.lib().gt_rows_ctx_fill(_lib.ptr(self.row0), _lib.ptr(self.lengths), _lib.ptr(self.rowbatch),
+                                               _lib.ptr(self.rowframe), _lib.ptr(self.rowmask), self.B, self.R,
+                                               _lib.current_stream(self.device)), "gt_rows_ctx_fill")
 
     def utt_sum(self, rows, out, accumulate=False, masked=True):
         """out[b, :] (+)= sum of the (valid) rows of utterance b; rows bf16 or fp32 [R, C] (a column slice is fine),
