@@ -268,7 +268,8 @@ def main():
                             "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                             "traffic_source": "profiles/r01_gate_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
                                               "FETCH_SIZE x2 per the gfx950 correction; tools/gate_conv_pmc.py)",
-                            "kernel": "gt_conv_gemm_kernel<128,true> (WN in_layer k=5 conv + gate, 48 launches/step)",
+                            "kernel": "gt_conv_gemm_kernel<64|128,128,true> (WN in_layer k=5 conv + gate, 48 launches/step; 64-row tiles when "
+                                      "128-row tiles would give <= 256 workgroups, as on this workload)",
                             "algorithmic_flops_per_launch": flops_launch, "launch_ms": avg_ms,
                             "how": "20 launches on the step's shapes and weights captured in one HIP graph, HIP events around 20 replays",
                             "rows_per_launch": rows_launched,

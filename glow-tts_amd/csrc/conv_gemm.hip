@@ -364,10 +364,11 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 block(256);
-  // Short tiles: when 128-row tiles give fewer workgroups than the chip has CUs (one wave per SIMD, nothing to hide the
-  // LDS / L2 latency behind), 64-row tiles double the resident waves at the price of streaming the weights twice as often.
+  // Short tiles: when 128-row tiles give no more workgroups than the chip has CUs (one wave per SIMD, nothing to hide the
+  // LDS / L2 latency behind), 64-row tiles double the resident waves at the price of streaming the weights twice as often
+  // (cfg2 step 9.00 -> 8.76 ms; with the threshold at 512 workgroups the gain is gone).  GT_CONV_BM64=0 turns it off.
   static int bm64 = -1;
-  if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 0; }
+  if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 256; }
   const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
   if (bm64 && bnsel == 128 && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np >= N) {
     const dim3 grid(8 * (((R + 63) / 64 + 7) / 8) * (Np / bnsel));
