@@ -41,9 +41,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
 {
   constexpr int XROWS = BM + MAXTAPS - 1;
   constexpr int XCH = (XROWS * 8 + 255) / 256;                      // activation 16-B chunks per thread per slice (5 or 9)
-  constexpr int WN = BN / 64;                 // waves along channels
+  // wave tiling: 4 waves; a wave owns NB 32-channel blocks x MB 32-row blocks.  64 x 64 tiles: 2 x 2 waves of 32 x 32
+  constexpr int NB = (BM == 64 && BN == 64) ? 1 : 2;   // 32-channel MFMA blocks per wave
+  constexpr int WN = BN / (32 * NB);          // waves along channels
   constexpr int WM = 4 / WN;                  // waves along rows
   constexpr int MB = BM / (32 * WM);          // 32-row MFMA blocks per wave
+  static_assert(WN * WM == 4 && MB >= 1, "tile does not split over 4 waves");
   constexpr int WCH = BN / 32;                // weight 16-B chunks per thread per tile
 
   constexpr int XS_HALFS = XROWS * LDP, WS_HALFS = BN * LDP;
@@ -101,9 +104,9 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
 #define store_X(bf) do { stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); stx1(bf, 3, x3); stx1(bf, 4, x4); \
                           if (XCH > 5) { stx1(bf, 5, x5); stx1(bf, 6, x6); stx1(bf, 7, x7); stx1(bf, 8, x8); } } while (0)
 
-  f32x16_t acc[2][MB];
+  f32x16_t acc[NB][MB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < MB; ++j)
 #pragma unroll
@@ -120,17 +123,17 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
     const bool newslice = has && (tap == taps - 1);
     if (has && !(a.exp_ & 2)) { load_W(nxt); if (newslice) load_X(slice + 1); }
 
-    const bf16_t* wsb = &Ws[it & 1][(64 * wn + r) * LDP + 8 * h];
+    const bf16_t* wsb = &Ws[it & 1][(32 * NB * wn + r) * LDP + 8 * h];
     const bf16_t* xsb = &Xs[slice & 1][(mrow0 + r + tap) * LDP + 8 * h];
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[2], bfm[MB];
+      bf16x8_t af[NB], bfm[MB];
 #pragma unroll
-      for (int bn = 0; bn < 2; ++bn) af[bn] = *reinterpret_cast<const bf16x8_t*>(wsb + bn * 32 * LDP + ks * 16);
+      for (int bn = 0; bn < NB; ++bn) af[bn] = *reinterpret_cast<const bf16x8_t*>(wsb + bn * 32 * LDP + ks * 16);
 #pragma unroll
       for (int bm = 0; bm < MB; ++bm) bfm[bm] = *reinterpret_cast<const bf16x8_t*>(xsb + bm * 32 * LDP + ks * 16);
 #pragma unroll
-      for (int bn = 0; bn < 2; ++bn)
+      for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
         for (int bm = 0; bm < MB; ++bm)
           acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[bn], bfm[bm], acc[bn][bm], 0, 0, 0);
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
   if (a.exp_ & 1) {
     float sacc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
       for (int j = 0; j < MB; ++j)
 #pragma unroll
@@ -164,10 +167,10 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
 #pragma unroll
   for (int bm = 0; bm < MB; ++bm)
 #pragma unroll
-    for (int bn = 0; bn < 2; ++bn)
+    for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(&es[(mrow0 + 32 * bm + r) * EP + 64 * wn + 32 * bn + 8 * g + 4 * h]) =
+        *reinterpret_cast<float4*>(&es[(mrow0 + 32 * bm + r) * EP + 32 * NB * wn + 32 * bn + 8 * g + 4 * h]) =
             make_float4(acc[bn][bm][4 * g], acc[bn][bm][4 * g + 1], acc[bn][bm][4 * g + 2], acc[bn][bm][4 * g + 3]);
   __syncthreads();
 
@@ -370,13 +373,14 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   static int bm64 = -1;
   if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 256; }
   const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
-  if (bm64 && bnsel == 128 && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np >= N) {
+  if (bm64 && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np % 64 == 0 && Np >= N) {
     const dim3 grid(8 * (((R + 63) / 64 + 7) / 8) * (Np / bnsel));
     if (gate == 1) {
       if (!gate_t || !gate_s || out_f32) return GT_E_INVAL;
       if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
       hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, true>), grid, block, 0, st, a);
-    } else hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, false>), grid, block, 0, st, a);
+    } else if (bnsel == 128) hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, false>), grid, block, 0, st, a);
+    else                     hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 64, false>), grid, block, 0, st, a);
     return gt_launch_status(__func__);
   }
   if (gate == 1) {
