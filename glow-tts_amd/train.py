@@ -416,6 +416,10 @@ class Trainer:
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({e!r}); continuing with eager launches")
                 self.graph_mode = False
+                # auxiliary streams that had joined the aborted capture may be left in capture state: start over with fresh ones
+                from . import text_models, wgrad
+                text_models._ENC_STREAMS.clear(); models._GROUP_STREAMS.clear(); wgrad._SIDE.clear(); wgrad._PENDING.clear()
+                ops._PREBUILT.clear()
                 return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
         graphs, static, out, ctxs = cap
         for dst, src in list(zip(static[:4], (ids, t_x, y, t_y))) + [(static[4][k], v) for k, v in cond.items()]:

@@ -310,3 +310,34 @@ def test_graph_step_with_decoder_utterance_groups(built):
     assert abs(le.item() - lg.item()) <= 2e-2 * max(1.0, abs(le.item())), (le.item(), lg.item())
     worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
     assert worst < 5e-3, worst
+
+
+def test_failed_capture_falls_back_to_eager_steps(built, monkeypatch):
+    """If the step cannot be captured (e.g. a collective that refuses capture), the trainer warns and keeps training with
+    eager launches — same updates as a trainer that never tried."""
+    import warnings
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=1, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    lh = (batch[1].tolist(), batch[3].tolist())
+    t1, t2 = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+
+    def boom(self, *a, **k):
+        raise RuntimeError("capture refused")
+    monkeypatch.setattr(train.Trainer, "_capture", boom)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(2):
+            l1, _ = t1.step(*batch, lengths_host=lh)
+            l2, _ = t2.step(*batch, lengths_host=lh)
+    torch.cuda.synchronize()
+    assert not t2.graph_mode and any("capture of the training step failed" in str(x.message) for x in w)
+    assert abs(l1.item() - l2.item()) <= 1e-3 * max(1.0, abs(l1.item()))
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst

@@ -32,10 +32,20 @@ class Mode(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 
+from glow_tts_amd import modules as _m
+_orig_bwd = _m._RowsFn.backward
+
+
+def _bwd(ctx, *grads):            # the runners' backward runs on the autograd engine's thread: enter the mode there too
+    with Mode():
+        return _orig_bwd(ctx, *grads)
+
+
+_m._RowsFn.backward = staticmethod(_bwd)
 with Mode():
     tr.step(ids, t_x, y, t_y, lengths_host=lh)
 torch.cuda.synchronize()
 tot = sum(cnt.values())
 print("device-launching torch ops in one step:", tot)
-for (name, site), c in cnt.most_common(70):
+for (name, site), c in cnt.most_common(int(os.environ.get('TOP', 70))):
     print(f"{c:4d}  {name:34s} {site}")
