@@ -27,7 +27,7 @@ def timeit(fn, n=20):
 shapes = [(192, 384, 5, True, 0.05, "gate p=.05"), (192, 384, 5, True, 0.0, "gate p=0"), (192, 384, 5, False, 0.0, "plain N=384"),
           (384, 192, 5, False, 0.0, "dgrad-like"), (192, 192, 1, False, 0.0, "1x1 K=192"), (384, 192, 1, False, 0.0, "1x1 K=384"),
           (192, 384, 1, False, 0.0, "1x1 N=384")]
-for B, T in [(32, 400), (21, 400), (64, 400)] if len(sys.argv) < 2 else [(32, 400)]:
+for B, T in [(int(os.environ.get("B", 23)), 400)]:
     rc = ops.RowsCtx(torch.full((B,), T, dtype=torch.int32, device=dev), T)
     R = rc.R
     for (Cin, Cout, k, gate, p, name) in shapes:
