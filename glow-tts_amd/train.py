@@ -268,7 +268,10 @@ class Trainer:
         self.dec0_off = self.buckets.offsets[self.dec0] if self.dec0 < len(names) else self.buckets.total
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
         from . import wgrad
-        wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "1") != "0"      # weight-gradient batches on a side stream
+        # Weight-gradient batches on their own side stream (GT_WGRAD_ASYNC=1) paid while the step was one chain (12.7 ->
+        # 12.2 ms); now that the text encoder is a parallel branch of the graph, a third concurrent stream costs more in
+        # cross-queue dependencies than it hides (8.54 vs 7.24 ms/step): off by default.
+        wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "0") != "0"
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
         self._captured = {}                       # (text rows, mel rows) -> (graphs, static inputs, outputs, row contexts)
