@@ -73,6 +73,8 @@ class FlowSpecDecoder(nn.Module):
         main = torch.cuda.current_stream(dev)
         streams = _group_streams(dev, G)
         self._wgrad_round = 0
+        self._group_main = main
+        self.__dict__.pop("_parked_wgrads", None)
         lh = ops._HOST_LENGTHS.get("y")
         B = x.shape[0]
         parts = []
@@ -260,13 +262,9 @@ class _DecoderRunner:
         chunk = int(os.environ.get("GT_WGRAD_CHUNK", "12"))
         site, acc, side, hand_over = dec, False, False, True
         if self.group is not None:
-            # concurrent groups write the same flat gradient slices: order their flushes on the wgrad side stream, the
-            # first of the step writes, the rest add.  (Without a flat buffer every flush has its own outputs and
-            # autograd adds them up.)
             flat = hasattr(self.params[0], "_gt_flat_grad")
-            side = flat
-            acc = flat and dec._wgrad_round > 0
             dec._wgrad_round += 1
+            last = dec._wgrad_round == self.n_groups
             # every group's kernels write the SAME flat slices: autograd must see each parameter's gradient once (from the
             # group whose backward runs last), not G aliases of one buffer that it would add to each other
             hand_over = (not flat) or dec._wgrad_round == self.n_groups
@@ -274,7 +272,12 @@ class _DecoderRunner:
             chunk = nb
         for b1 in range(nb, 0, -chunk):
             b0 = max(0, b1 - chunk)
-            with wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else site, accumulate=acc, side_stream=side):
+            q = wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else site)
+            if self.group is not None and flat and not last:
+                # the groups write the SAME flat gradient slices: park this group's batch; the last group of the step's
+                # backward flushes its own (writing) and then the parked ones (adding), all on its stream — no extra stream
+                q.defer_to = dec.__dict__.setdefault("_parked_wgrads", [])
+            with q:
                 for b in reversed(range(b0, b1)):
                     an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
                     s1, s2 = saved[b]
@@ -307,9 +310,15 @@ class _DecoderRunner:
             # last group of the step's backward (the others are already enqueued on their streams): tie them to this
             # stream, which autograd joins with its caller through the parameter gradients handed over below
             cur = torch.cuda.current_stream(dev)
-            for st in _group_streams(dev, self.n_groups)[1:]:
+            for st in [dec._group_main] + _group_streams(dev, self.n_groups)[1:]:
                 if st is not None and st != cur:
                     cur.wait_stream(st)
+            for pq in dec.__dict__.pop("_parked_wgrads", []):          # the other groups' weight gradients, added to ours
+                for _, _, parts, dv, dg, db in pq.items:
+                    for x_, dy_, _, _ in parts:
+                        x_.record_stream(cur); dy_.record_stream(cur)
+                pq.defer_to, pq.accumulate = None, True
+                pq.flush()
         if hand_over:
             return out + [grads.get(p) for p in self.params]
         flat_store = self.params[0]._gt_flat_grad[0].untyped_storage().data_ptr()

@@ -102,6 +102,7 @@ class WgradQueue:
         # models.DECODER_GROUPS); side_stream: flush on the wgrad side stream even without ASYNC, so that the flushes of
         # concurrent groups are ordered among themselves
         self.accumulate, self.force_side = accumulate, side_stream
+        self.defer_to = None        # a list: leaving the block parks the queue there instead of flushing (the owner flushes later)
 
     def __enter__(self):
         _ACTIVE.append(self)
@@ -110,7 +111,10 @@ class WgradQueue:
     def __exit__(self, et, ev, tb):
         _ACTIVE.pop()
         if et is None:
-            self.flush()
+            if self.defer_to is not None:
+                self.defer_to.append(self)
+            else:
+                self.flush()
         return False
 
     def add(self, conv, R, parts, want_bias=True):
