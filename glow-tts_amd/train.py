@@ -165,9 +165,12 @@ class GradBuckets:
         if self.on_gpu:
             cur = torch.cuda.current_stream()
             self.comm.wait_stream(cur)
+            avg = dist.get_backend() == "nccl"                                  # gloo (tests) has no AVG: SUM, then scale
             with torch.cuda.stream(self.comm):
                 for s, e in pieces:
-                    dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG)       # RCCL over xGMI
+                    dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM)   # RCCL over xGMI
+                    if not avg:
+                        self.flat[s:e].mul_(1.0 / self.world)
             if wait:
                 cur.wait_stream(self.comm)
         else:                                                                   # gloo (CPU tests): SUM then scale
