@@ -239,8 +239,8 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
     dh0, g2, dcond = wn_bwd(rc, cb.wn, wn_saved, dskip, want_dcond)
     grads.update(g2)
     grads.update(conv_param_grads(cb.start, x0_bf16, dh0, R))                    # dh0 is already masked
-    dx0 = conv_rows(dh0, cb.start.pc, rc, dgrad=True)
-    _lib.check(L.gt_rows_add_bf16(_lib.ptr(dx), C, _lib.ptr(dx0), dx0.stride(0), R, C // 2, _st(dev)), "gt_rows_add_bf16")
+    # d x0 = (identity path, already in dx[:, :C/2]) + dgrad(start): added in the GEMM's epilogue, in place
+    conv_rows(dh0, cb.start.pc, rc, dgrad=True, addend=dx[:, :C // 2], out=dx[:, :C // 2])
     if econd or pcond:
         return dx, grads, dcond, [dpros.get(id(getattr(cb, "wn_energy", None))) if econd else None,
                                   dpros.get(id(getattr(cb, "wn_pitch", None))) if pcond else None]
