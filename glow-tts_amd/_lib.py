@@ -66,8 +66,8 @@ PROTOTYPES = {
     "gt_attn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
-    "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
-    "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "gt_embedding_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "gt_embedding_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_rows_add_cond": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_rows_ctx_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

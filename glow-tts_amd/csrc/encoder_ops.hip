@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void gt_attn_bwd_kv_kernel(
 __global__ __launch_bounds__(256) void gt_embedding_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ emb,
                                                                const int32_t* __restrict__ lens, float* __restrict__ out_f32,
                                                                bf16_t* __restrict__ out_bf16, int B, int T, int Tp, int C, float scale,
-                                                               const int32_t* __restrict__ row0, int R)
+                                                               const int32_t* __restrict__ row0, int R, int ld)
 {
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= R) return;
@@ -398,21 +398,21 @@ __global__ __launch_bounds__(256) void gt_embedding_fwd_kernel(const int64_t* __
   const int64_t id = valid ? ids[(size_t)b * T + t] : 0;
   for (int c = lane; c < C; c += 64) {
     const float v = valid ? emb[(size_t)id * C + c] * scale : 0.f;
-    if (out_f32) out_f32[(size_t)m * C + c] = v;
-    if (out_bf16) out_bf16[(size_t)m * C + c] = f2bf(v);
+    if (out_f32) out_f32[(size_t)m * ld + c] = v;
+    if (out_bf16) out_bf16[(size_t)m * ld + c] = f2bf(v);
   }
 }
 __global__ __launch_bounds__(256) void gt_embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dx,
                                                                const int32_t* __restrict__ lens, float* __restrict__ demb,
                                                                int B, int T, int Tp, int C, float scale,
-                                                               const int32_t* __restrict__ row0, int R)
+                                                               const int32_t* __restrict__ row0, int R, int ld)
 {
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (m >= R) return;
   const int b = gt_row_batch(row0, B, m, Tp), t = m - gt_row_base(row0, b, Tp) - HALO;
   if (t < 0 || t >= T || t >= lens[b]) return;
   const int64_t id = ids[(size_t)b * T + t];
-  for (int c = lane; c < C; c += 64) atomicAdd(demb + (size_t)id * C + c, dx[(size_t)m * C + c] * scale);
+  for (int c = lane; c < C; c += 64) atomicAdd(demb + (size_t)id * C + c, dx[(size_t)m * ld + c] * scale);
 }
 
 // ------------------------------------------------------------------ per-utterance vector added to every valid row
@@ -735,12 +735,12 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
 }
 
 extern "C" int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
-                                int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream)
+                                int B, int T, int Tp, const int32_t* row0, int R, int C, int ld, float scale, void* stream)
 {
-  if (!ids || !emb || !lens || (!out_f32 && !out_bf16) || B <= 0 || T <= 0 || C <= 0 || R <= 0) return GT_E_INVAL;
+  if (!ids || !emb || !lens || (!out_f32 && !out_bf16) || B <= 0 || T <= 0 || C <= 0 || R <= 0 || ld < C) return GT_E_INVAL;
   if (!row0 && R != B * Tp) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_embedding_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, emb, lens, out_f32,
-                     static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale, row0, R);
+                     static_cast<bf16_t*>(out_bf16), B, T, Tp, C, scale, row0, R, ld);
   GT_RET();
 }
 extern "C" int gt_rows_add_cond(const float* x, int ldx, const void* xb, int ldxb, const float* cond, const float* rowmask,
@@ -770,11 +770,11 @@ extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
-                                int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream)
+                                int B, int T, int Tp, const int32_t* row0, int R, int C, int ld, float scale, void* stream)
 {
-  if (!ids || !dx || !lens || !demb || B <= 0 || T <= 0 || C <= 0 || R <= 0) return GT_E_INVAL;
+  if (!ids || !dx || !lens || !demb || B <= 0 || T <= 0 || C <= 0 || R <= 0 || ld < C) return GT_E_INVAL;
   if (!row0 && R != B * Tp) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_embedding_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, dx, lens, demb, B, T, Tp, C, scale, row0, R);
+  hipLaunchKernelGGL(gt_embedding_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, GT_ST(stream), ids, dx, lens, demb, B, T, Tp, C, scale, row0, R, ld);
   GT_RET();
 }
 

@@ -46,9 +46,9 @@ class _PaddedConv:
 class DurationPredictor(nn.Module):
     def __init__(self, in_channels, filter_channels, kernel_size, p_dropout, gin_channels=0, lin_channels=0, emoin_channels=0):
         super().__init__()
-        assert lin_channels == 0 and emoin_channels == 0, "language / emotion conditioned predictor: cfg 5, not on the round-1 path"
+        assert emoin_channels == 0, "emotion conditioned predictor: the reference never builds it (models.py:671)"
         self.in_channels, self.filter_channels, self.kernel_size, self.p_dropout = in_channels, filter_channels, kernel_size, p_dropout
-        self.gin_channels = gin_channels
+        self.gin_channels, self.lin_channels = gin_channels, lin_channels
         self.conv_1 = ConvP(in_channels, filter_channels, kernel_size)
         self.norm_1 = LayerNorm(filter_channels)
         self.conv_2 = ConvP(filter_channels, filter_channels, kernel_size)
@@ -58,12 +58,20 @@ class DurationPredictor(nn.Module):
         self.proj_pad = _PaddedConv(self.proj)
         if gin_channels != 0:
             self.cond = nn.Conv1d(gin_channels, in_channels, 1)          # models.py:579-580; B rows: host-side plumbing
+        if lin_channels != 0:
+            self.cond_lang = nn.Conv1d(lin_channels, in_channels, 1)     # models.py:582-583
 
-    def cond_vec(self, g):
-        """cond(detach(g)) (models.py:587-589) for g [b,gin,1] -> [B, in_channels]; the kernels add it to the rows."""
-        if g is None:
-            return None
-        return torch.nn.functional.linear(g.detach().squeeze(-1), self.cond.weight.squeeze(-1), self.cond.bias)
+    def cond_vec(self, g, l=None):
+        """cond(detach(g)) + cond_lang(detach(l)) (models.py:587-597) for g [b,gin,1], l [b,lin,1] -> [B, in_channels];
+        the kernels add it to the rows."""
+        F = torch.nn.functional
+        v = None
+        if g is not None:
+            v = F.linear(g.detach().squeeze(-1), self.cond.weight.squeeze(-1), self.cond.bias)
+        if l is not None:
+            vl = F.linear(l.detach().squeeze(-1), self.cond_lang.weight.squeeze(-1), self.cond_lang.bias)
+            v = vl if v is None else v + vl
+        return v
 
     def _refresh_padded(self):
         self.proj_pad.refresh()
@@ -81,14 +89,16 @@ class TextEncoder(nn.Module):
                  gin_channels=0, lin_channels=0, emoin_channels=0):
         super().__init__()
         assert not use_sdp, "StochasticDurationPredictor is SURVEY §8 (f1): next round"
-        assert lin_channels == 0, "language conditioning (cfg 5) is not on the round-1 path"
-        self.gin_channels = gin_channels
+        self.gin_channels, self.lin_channels = gin_channels, lin_channels
         self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
         self.filter_channels, self.filter_channels_dp, self.n_heads, self.n_layers = filter_channels, filter_channels_dp, n_heads, n_layers
         self.kernel_size, self.p_dropout, self.window_size, self.mean_only, self.prenet = kernel_size, p_dropout, window_size, mean_only, prenet
-        self.emb = nn.Embedding(n_vocab, hidden_channels)
-        nn.init.normal_(self.emb.weight, 0.0, hidden_channels ** -0.5)
-        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout, gin_channels=gin_channels)
+        # multi-language models: the token embedding is lin_channels narrower and the language embedding fills the rest
+        # of every position (models.py:654-664, 698-699)
+        self.emb = nn.Embedding(n_vocab, hidden_channels - lin_channels)
+        nn.init.normal_(self.emb.weight, 0.0, (hidden_channels - lin_channels) ** -0.5)
+        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout, gin_channels=gin_channels,
+                                        lin_channels=lin_channels)
         if prenet:
             self.pre = ConvReluNorm(hidden_channels, hidden_channels, hidden_channels, kernel_size=5, n_layers=3, p_dropout=0.5)
         self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
@@ -101,25 +111,27 @@ class TextEncoder(nn.Module):
     def forward(self, x, x_lengths, l=None, g=None, emo=None, prepared=False):
         """ids [b, t] int64, lengths [b] -> (x [b,H,t], x_m [b,80,t], x_logs [b,80,t], x_mask [b,1,t])
         exactly as reference models.py:692-716."""
-        assert l is None and emo is None, "language / emotion conditioning (cfg 5) is not on the round-1 path"
+        assert emo is None, "emotion conditioning is commented out in the reference encoder (models.py:695-696)"
+        assert (l is None) == (self.lin_channels == 0), "l [b, lin_channels, 1] is required exactly when lin_channels != 0"
         if not prepared:
             prepare_all(self)
         self._step += 1
         T = x.shape[1]
         x_mask = (torch.arange(T, device=x.device)[None, :] < x_lengths[:, None]).unsqueeze(1).to(torch.float32)
         vec = self.encoder.cond_vec(g)                # speaker vector, added before encoder layer index 2
+        lvec = None if l is None else l.squeeze(-1)     # [b, lin]: a differentiable input of the node (emb_l upstream)
         runner = _TextEncoderRunner(self, x, x_lengths, self.training, seed=(self._step * 104729) & 0x7fffffff,
-                                    has_cond=vec is not None)
-        outs = _RowsFn.apply(runner, 3, *([vec] if vec is not None else []), *runner.params)
+                                    has_cond=vec is not None, has_lang=lvec is not None)
+        outs = _RowsFn.apply(runner, 3, *([vec] if vec is not None else []), *([lvec] if lvec is not None else []), *runner.params)
         xo, x_m, x_logs = outs[0], outs[1], outs[2]
         self._last_rows = runner.last            # (rc, xb_final) for the duration predictor
         return xo, x_m, x_logs, x_mask
 
 
 class _TextEncoderRunner:
-    def __init__(self, te, ids, lengths, train, seed, has_cond=False):
+    def __init__(self, te, ids, lengths, train, seed, has_cond=False, has_lang=False):
         self.te, self.ids, self.lengths, self.train, self.seed = te, ids.contiguous(), lengths, train, seed
-        self.has_cond = has_cond
+        self.has_cond, self.has_lang = has_cond, has_lang
         self.params = [p for n, p in te.named_parameters() if not n.startswith("proj_w.") and not n.startswith("encoder.cond_g.")]
         self.last = None
 
@@ -127,15 +139,23 @@ class _TextEncoderRunner:
         L = _lib.lib()
         te = self.te
         vec = rest[0] if self.has_cond else None
+        lvec = rest[int(self.has_cond)] if self.has_lang else None
         B, T = self.ids.shape
         dev = self.ids.device
         C = te.hidden_channels
+        Ce = C - te.lin_channels                         # token-embedding channels; the language vector fills [Ce, C)
         rc = ops.make_ctx(self.lengths.to(torch.int32), T, "x")
         x = torch.empty(rc.R, C, dtype=torch.float32, device=dev)
         xb = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
         emb = te.emb.weight.detach()
         _lib.check(L.gt_embedding_fwd(_lib.ptr(self.ids), _lib.ptr(emb), _lib.ptr(rc.lengths), _lib.ptr(x), _lib.ptr(xb),
-                                      B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C, math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_fwd")
+                                      B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, Ce, C, math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_fwd")
+        if lvec is not None:                             # x = cat(emb * sqrt(H), l expanded over time) (models.py:698-699)
+            lc = lvec.detach().float().contiguous()
+            zero = ops.zeros_small((rc.R, te.lin_channels), torch.float32, dev)
+            _lib.check(L.gt_rows_add_cond(_lib.ptr(zero), te.lin_channels, None, 0, _lib.ptr(lc), _lib.ptr(rc.rowmask),
+                                          x.data_ptr() + 4 * Ce, C, xb.data_ptr() + 2 * Ce, C, B, rc.R, te.lin_channels, rc.Tp,
+                                          _lib.ptr(rc.row0), _lib.current_stream(dev)), "gt_rows_add_cond")
         s_pre = None
         if te.prenet:
             x, xb, s_pre = encoder_impl.crn_fwd(rc, te.pre, x, xb, self.train, self.seed)
@@ -166,7 +186,7 @@ class _TextEncoderRunner:
         dxb = None
         dvec = None
         if dxo is None and dx_m is None and (te.mean_only or dx_logs is None):
-            return [None] * (len(self.params) + int(self.has_cond))
+            return [None] * (len(self.params) + int(self.has_cond) + int(self.has_lang))
         from . import wgrad
         with wgrad.WgradQueue(dev, site=te):
             if dx_m is not None:
@@ -189,10 +209,14 @@ class _TextEncoderRunner:
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
         demb = ops.grad_accumulator(te.emb.weight)
         B, T = self.ids.shape
-        _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, C,
+        Ce = C - te.lin_channels
+        _lib.check(L.gt_embedding_bwd(_lib.ptr(self.ids), _lib.ptr(tot), _lib.ptr(rc.lengths), _lib.ptr(demb), B, T, rc.Tp, _lib.ptr(rc.row0), rc.R, Ce, C,
                                       math.sqrt(C), _lib.current_stream(dev)), "gt_embedding_bwd")
         grads[te.emb.weight] = demb
-        return ([dvec] if self.has_cond else []) + [grads.get(p) for p in self.params]
+        dl = []
+        if self.has_lang:                                # the language vector was broadcast over time: its gradient is the row sum
+            dl = [rc.utt_sum(tot[:, Ce:], torch.empty(B, te.lin_channels, dtype=torch.float32, device=dev))]
+        return ([dvec] if self.has_cond else []) + dl + [grads.get(p) for p in self.params]
 
 
 class _DurationRunner:
@@ -324,7 +348,7 @@ class FlowGenerator(nn.Module):
                  n_layers_enc=6, p_dropout=0., n_blocks_dec=12, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                  p_dropout_dec=0., n_speakers=0, gin_channels=0, n_split=4, n_sqz=1, sigmoid_scale=False, window_size=None,
                  block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False,
-                 with_prosody_wn=False, **kwargs):
+                 with_prosody_wn=False, n_lang=0, lin_channels=0, **kwargs):
         super().__init__()
         from .models import FlowSpecDecoder
         # Multi-speaker configs (cfg 4, configs/base_blank_ms.json: gin_channels=256): the speaker vector enters
@@ -335,7 +359,11 @@ class FlowGenerator(nn.Module):
         self.encoder = TextEncoder(n_vocab, out_channels, hidden_channels_enc or hidden_channels, filter_channels,
                                    filter_channels_dp, n_heads, n_layers_enc, kernel_size, p_dropout, window_size=window_size,
                                    block_length=block_length, mean_only=mean_only, prenet=prenet, use_sdp=False,
-                                   gin_channels=gin_channels)
+                                   gin_channels=gin_channels, lin_channels=lin_channels)
+        self.n_lang, self.lin_channels = n_lang, lin_channels
+        if n_lang > 1:                                               # models.py:914-916
+            self.emb_l = nn.Embedding(n_lang, lin_channels)
+            nn.init.xavier_uniform_(self.emb_l.weight)
         self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec, dilation_rate,
                                        n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec, n_split=n_split, n_sqz=n_sqz,
                                        sigmoid_scale=sigmoid_scale, gin_channels=gin_channels, with_prosody_wn=with_prosody_wn)
@@ -345,16 +373,18 @@ class FlowGenerator(nn.Module):
         self._step = 0
 
     @torch.no_grad()
-    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0, g=None):
+    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0, g=None, l=None):
         """Synthesis (reference FlowGenerator.infer, models.py:1122-1232, on the live sub-graph: no speaker / emotion /
         pitch / energy inputs): text -> durations -> expanded prior -> z = z_m + noise -> decoder(reverse=True) -> mel.
         Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)).  The output length is data
         dependent, so this reads the predicted lengths back from the device once."""
         self.prepare()
         ops._HOST_LENGTHS.clear()
-        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
+        if l is not None:
+            l = self.emb_l(l).unsqueeze(-1)
+        xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
         rc, xb = self.encoder._last_rows
-        dvec = self.encoder.proj_w.cond_vec(g)
+        dvec = self.encoder.proj_w.cond_vec(g, l)
         runner = _DurationRunner(self.encoder.proj_w, rc, xb, False, 0, has_cond=dvec is not None)
         (logw,), _ = runner.forward(*([dvec] if dvec is not None else []))
         w = torch.exp(logw) * x_mask * length_scale
@@ -390,10 +420,10 @@ class FlowGenerator(nn.Module):
         y, logdet = self.decoder(z, z_mask, g=g, reverse=True, prepared=True)
         return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
 
-    def _predict_logw(self, g):
-        """logw = proj_w(x.detach(), x_mask, g) (models.py:1090) on the rows the text encoder just produced."""
+    def _predict_logw(self, g, l=None):
+        """logw = proj_w(x.detach(), x_mask, g=g, l=l) (models.py:1090) on the rows the text encoder just produced."""
         rc, xb = self.encoder._last_rows
-        dvec = self.encoder.proj_w.cond_vec(g)
+        dvec = self.encoder.proj_w.cond_vec(g, l)
         runner = _DurationRunner(self.encoder.proj_w, rc, xb, self.training, seed=(self._step * 31337) & 0x7fffffff,
                                  has_cond=dvec is not None)
         (logw,) = _RowsFn.apply(runner, 1, *([dvec] if dvec is not None else []), *runner.params)
@@ -436,8 +466,9 @@ class FlowGenerator(nn.Module):
         defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
         decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
         data-parallel trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs."""
-        assert emo is None and emo_cartesian is None and l is None, \
-            "emotion / language inputs (cfg 5) are not on the round-1 path"
+        assert emo is None and emo_cartesian is None, "emotion inputs (cfg 5's front end) are not on the round-1 path"
+        if l is not None:
+            l = self.emb_l(l).unsqueeze(-1)                          # language ids [b] -> [b, lin_channels, 1] (models.py:1011-1012)
         assert (g is None) == (self.gin_channels == 0), "g [b, gin_channels, 1] is required exactly when gin_channels != 0"
         self.prepare()
         self._step += 1
@@ -456,10 +487,10 @@ class FlowGenerator(nn.Module):
             enc_stream = _encoder_stream(x.device)
             enc_stream.wait_stream(main)
             with torch.cuda.stream(enc_stream):
-                xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
-                logw = self._predict_logw(g)      # needs the encoder's output only (x is detached, models.py:586): same branch
+                xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
+                logw = self._predict_logw(g, l)   # needs the encoder's output only (x is detached, models.py:586): same branch
         else:
-            xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, g=g, prepared=True)
+            xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
             logw = None
         self._deferred = []
         if defer_encoder_backward:
@@ -482,7 +513,7 @@ class FlowGenerator(nn.Module):
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         logw_ = torch.log(w + 1e-8) * x_mask
         if logw is None:
-            logw = self._predict_logw(g)
+            logw = self._predict_logw(g, l)
         l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)  # models.py:1089-1092
         z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
         z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)

@@ -275,11 +275,13 @@ int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, const float
                 int B, int T, int Tp, const int32_t* row0, int H, int D, int win, float drop_p, uint32_t drop_seed,
                 const uint32_t* seed_dev, void* stream);
 
-/* Embedding * scale into rows (models.py:693): fp32 and/or bf16 output, zero halo / padded rows. */
+/* Embedding * scale into rows (models.py:693): fp32 and/or bf16 output, zero halo / padded rows.  emb [n_vocab, C];
+ * the rows have stride ld >= C (ld > C: the language embedding of models.py:698-699 fills channels [C, ld) — written by
+ * gt_rows_add_cond on that column window); the backward ACCUMULATES into demb. */
 int gt_embedding_fwd(const int64_t* ids, const float* emb, const int32_t* lens, float* out_f32, void* out_bf16,
-                     int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream);
+                     int B, int T, int Tp, const int32_t* row0, int R, int C, int ld, float scale, void* stream);
 int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,
-                     int B, int T, int Tp, const int32_t* row0, int R, int C, float scale, void* stream);
+                     int B, int T, int Tp, const int32_t* row0, int R, int C, int ld, float scale, void* stream);
 
 /* Ragged rows layout (see GT_HALO above): from the row offsets row0[B+1] and the lengths, fill the per-row tables the
  * host side keeps next to them — rowbatch[m] (utterance of row m, int64), rowframe[m] (m - row0[b] - GT_HALO) and

@@ -303,9 +303,12 @@ def conv_relu_norm_fwd(P, pre, x, x_mask, n_layers=3, kernel_size=5):
 
 
 def text_encoder_fwd(P, pre, ids, x_lengths, g=None, hidden=192, n_layers=6, n_heads=2, window_size=4,
-                     kernel_size=3, prenet=True, mean_only=True):
-    """models.TextEncoder.forward (models.py:692-716), l=None, eval mode."""
+                     kernel_size=3, prenet=True, mean_only=True, l=None):
+    """models.TextEncoder.forward (models.py:692-716), eval mode.  l [b, lin, 1]: language vector concatenated to every
+    position of the (lin channels narrower) token embedding (models.py:698-699)."""
     x = F.embedding(ids, P[pre + "emb.weight"]) * math.sqrt(hidden)
+    if l is not None:
+        x = torch.cat((x, l.transpose(2, 1).expand(x.size(0), x.size(1), -1)), dim=-1)
     x = x.transpose(1, -1)
     x_mask = sequence_mask(x_lengths, x.size(2)).unsqueeze(1).to(x.dtype)
     if prenet:
@@ -316,12 +319,14 @@ def text_encoder_fwd(P, pre, ids, x_lengths, g=None, hidden=192, n_layers=6, n_h
     return x, x_m, x_logs, x_mask
 
 
-def duration_predictor_fwd(P, pre, x, x_mask, kernel_size=3, g=None):
+def duration_predictor_fwd(P, pre, x, x_mask, kernel_size=3, g=None, l=None):
     """models.DurationPredictor.forward (models.py:585-612), l=emo=None, eval mode; g [b,gin,1] is detached and
     added through the 1x1 `cond` conv (models.py:587-589)."""
     x = x.detach()
     if g is not None:
         x = x + conv1d(P, pre + "cond", g.detach())
+    if l is not None:                                     # models.py:595-597
+        x = x + conv1d(P, pre + "cond_lang", l.detach())
     x = conv1d(P, pre + "conv_1", x * x_mask, padding=kernel_size // 2)
     x = layer_norm_c(torch.relu(x), P[pre + "norm_1.gamma"], P[pre + "norm_1.beta"])
     x = conv1d(P, pre + "conv_2", x * x_mask, padding=kernel_size // 2)
@@ -360,7 +365,7 @@ def contour_norm(c, y_max):
     return n.unsqueeze(1)
 
 
-def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pitch=None, energy=None):
+def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pitch=None, energy=None, l=None):
     """The upstream-equivalent live sub-graph of models.FlowGenerator.forward
     (models.py:1050-1119) for the base configs (the fork's FlowGenerator does not
     construct for them): TextEncoder -> FlowSpecDecoder -> logp -> MAS -> duration loss
@@ -368,11 +373,12 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pit
     `maximum_path(value, mask) -> path` is the MAS implementation to use (tests pass the oracle).
     g [b,gin,1]: the speaker vector of the multi-speaker configs as it reaches the encoder / duration predictor /
     decoder (models.py:1046,1075,1090).  pitch / energy: raw contours [b,1,t_y] of cfg 5 into the decoder's WNPs (their
-    predictor losses, SURVEY §8 f1, are not part of this sub-graph)."""
+    predictor losses, SURVEY §8 f1, are not part of this sub-graph).  l [b, lin, 1]: the language vector emb_l(lang id)
+    (models.py:1011-1012) into the text encoder and the duration predictor."""
     n_sqz = hp.get("n_sqz", 2)
     x, x_m, x_logs, x_mask = text_encoder_fwd(P, "encoder.", ids, x_lengths, g, hp["hidden_channels"],
                                               hp["n_layers_enc"], hp["n_heads"], hp["window_size"],
-                                              hp["kernel_size"], hp["prenet"], hp["mean_only"])
+                                              hp["kernel_size"], hp["prenet"], hp["mean_only"], l=l)
     y_max = (y.size(2) // n_sqz) * n_sqz                                     # models.py:1248-1253
     y = y[:, :, :y_max]
     y_lengths = (y_lengths // n_sqz) * n_sqz
@@ -386,7 +392,7 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pit
         attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1).detach()
     w = attn.squeeze(1).sum(2).unsqueeze(1)
     logw_ = torch.log(w + 1e-8) * x_mask
-    logw = duration_predictor_fwd(P, "encoder.proj_w.", x, x_mask, hp["kernel_size"], g)
+    logw = duration_predictor_fwd(P, "encoder.proj_w.", x, x_mask, hp["kernel_size"], g, l)
     l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
     z_m = torch.matmul(attn.squeeze(1).transpose(1, 2), x_m.transpose(1, 2)).transpose(1, 2)
     z_logs = torch.matmul(attn.squeeze(1).transpose(1, 2), x_logs.transpose(1, 2)).transpose(1, 2)

@@ -214,6 +214,17 @@ def main():
     (gxs_,) = grads_of([(zs_, 11), (lds_, 12)], [xs_])
     out.update(cbs_z=zs_, cbs_logdet=lds_, cbs_gx=gxs_)
 
+    # ---- language vector (cfg 5, lin_channels=4): TextEncoder concatenates it to the (4 channels narrower) token
+    # embedding at every position (models.py:654-664, 698-699); DurationPredictor.cond_lang (models.py:582-583, 595-597)
+    lng = rnd(2, 4, 1)
+    tel = fill_module(models.TextEncoder(148, 80, 192, 768, 256, 2, 2, 3, 0.1, window_size=4, mean_only=True, prenet=True,
+                                         use_sdp=False, lin_channels=4), "encoder.").eval()
+    ll = lng.clone().requires_grad_(True)
+    lx, lm, _, _ = tel(ids, xl, l=ll)
+    (gl,) = grads_of([(lx, 13), (lm, 14)], [ll])
+    dpl = fill_module(models.DurationPredictor(192, 256, 3, 0.1, gin_channels=256, lin_channels=4), "dpl.").eval()
+    out.update(lang_l=lng, tel_x=lx, tel_m=lm, tel_gl=gl, dpl_out=dpl(xe, xm, g=spk, l=lng))
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")

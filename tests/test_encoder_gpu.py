@@ -132,6 +132,55 @@ def test_encoder_speaker_conditioning_fwd_bwd(built):
         assert grad_ok(prm.grad.cpu(), P["enc." + name].grad, 8e-2, name=name), name
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_train_forward_backward_with_language_and_speaker(built, ragged):
+    """cfg 5's text side: language id -> emb_l -> concatenated to the 188-channel token embedding at every position
+    (models.py:654-664, 698-699, 1011-1012) and added through DurationPredictor.cond_lang; together with the speaker
+    vector.  Whole training forward / backward against the oracle (language path pinned by tel_* / dpl_* goldens),
+    including the gradients of emb_l, the narrower emb and cond_lang."""
+    from glow_tts_amd import models, ops
+    gen = _make_generator(3, 256, n_lang=3, lin_channels=4)
+    P = cpu_state(gen)
+    g = torch.Generator().manual_seed(17)
+    B, Tx, Ty = 3, 33, 96
+    xl, yl = torch.tensor([33, 20, 9]), torch.tensor([96, 60, 30])
+    ids = torch.randint(1, 148, (B, Tx), generator=g) * (torch.arange(Tx)[None, :] < xl[:, None])
+    y = torch.randn(B, 80, Ty, generator=g) * lens_mask(yl.tolist(), Ty)
+    spk = torch.randn(B, 256, 1, generator=g)
+    lid = torch.tensor([2, 0, 1])
+    gen = gen.to(dev())
+    ops.RAGGED = ragged
+    try:
+        (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
+            gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=spk.to(dev()), l=lid.to(dev()))
+    finally:
+        ops.RAGGED = False
+    l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
+    (l_mle + l_length.sum()).backward()
+    lvec = torch.nn.functional.embedding(lid, P["emb_l.weight"]).unsqueeze(-1)
+    hp = dict(HP, n_layers_enc=3)
+    out = R.train_forward(P, ids, xl, y, yl, lambda logp, mask: attn.squeeze(1).cpu().float(), hp, g=spk, l=lvec)
+    out["loss"].backward()
+    assert relerr(x_m.detach().cpu(), out["x_m"].detach()) < 3e-2
+    assert relerr(z_m.detach().cpu(), out["z_m"].detach()) < 3e-2
+    assert relerr(l_length.detach().cpu(), out["l_length"].detach()) < 5e-2
+    bad = []
+    for name, prm in gen.named_parameters():
+        ref = P[name].grad
+        if ref is None:
+            assert prm.grad is None or prm.grad.abs().max().item() == 0, name
+            continue
+        assert prm.grad is not None, name
+        # the duration predictor's input gradient only exists as the bf16 output of a data-gradient GEMM; cond / cond_lang
+        # gradients are per-utterance sums of it times a 256- / 4-vector: 0.08-0.12 in relative L2
+        tol = 0.15 if (".pre.conv_layers." in name or "proj_w.cond" in name) else (0.2 if "emb_rel_" in name else 0.1)
+        if not grad_ok(prm.grad.cpu(), ref, tol, name=name):
+            bad.append((name, round(relerr(prm.grad.cpu(), ref), 3)))
+    assert not bad, bad
+    for key in ("emb_l.weight", "encoder.emb.weight", "encoder.proj_w.cond_lang.weight"):
+        assert dict(gen.named_parameters())[key].grad.abs().max().item() > 0, key
+
+
 def test_logp_kernel(built):
     from glow_tts_amd.text_models import _LogpMasFn
     g = torch.Generator().manual_seed(4)
@@ -154,12 +203,13 @@ HP = dict(hidden_channels=192, n_layers_enc=2, n_heads=2, window_size=4, kernel_
           n_blocks_dec=2, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
 
 
-def _make_generator(n_layers_enc=2, gin_channels=0, with_prosody_wn=False):
+def _make_generator(n_layers_enc=2, gin_channels=0, with_prosody_wn=False, n_lang=0, lin_channels=0):
     from glow_tts_amd import models
     return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=n_layers_enc, p_dropout=0.1,
                                             n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                                             p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True,
-                                            gin_channels=gin_channels, with_prosody_wn=with_prosody_wn), "").eval()
+                                            gin_channels=gin_channels, with_prosody_wn=with_prosody_wn, n_lang=n_lang,
+                                            lin_channels=lin_channels), "").eval()
 
 
 def test_text_encoder_fwd(built):

@@ -225,3 +225,24 @@ def test_coupling_sigmoid_scale_matches_reference_golden(built):
           (ld * torch.randn(ld.shape, generator=torch.Generator().manual_seed(12))).sum()
     (gx,) = torch.autograd.grad(tot, [x])
     assert close(gx, t("cbs_gx"), 1e-4)
+
+
+def test_language_vector_matches_reference_golden():
+    """cfg 5's multi-language inputs: TextEncoder(lin_channels=4) concatenates the language vector to the narrower token
+    embedding (models.py:654-664, 698-699) and DurationPredictor adds cond_lang(l) (models.py:582-583, 595-597)."""
+    shapes = {"emb.weight": (148, 188), "proj_m.weight": (80, 192, 1), "proj_m.bias": (80,)}
+    shapes.update({"pre." + k: v for k, v in PRE_SHAPES.items()})
+    shapes.update({"encoder." + k: v for k, v in enc_shapes(2).items()})
+    dps = dict(DP_SHAPES); dps.update({"cond_lang.weight": (192, 4, 1), "cond_lang.bias": (192,)})
+    shapes.update({"proj_w." + k: v for k, v in dps.items()})
+    P = filled_state(shapes, "encoder.")
+    l = t("lang_l").clone().requires_grad_(True)
+    x, xm_, _, _ = R.text_encoder_fwd(P, "encoder.", torch.from_numpy(G["te_ids"]), torch.from_numpy(G["te_len"]), n_layers=2, l=l)
+    assert close(x, t("tel_x"), 1e-4) and close(xm_, t("tel_m"), 1e-4)
+    tot = (x * torch.randn(x.shape, generator=torch.Generator().manual_seed(13))).sum() + \
+          (xm_ * torch.randn(xm_.shape, generator=torch.Generator().manual_seed(14))).sum()
+    (gl,) = torch.autograd.grad(tot, [l])
+    assert close(gl, t("tel_gl"), 2e-4)
+    sh = dict(DP_SHAPES); sh.update({"cond.weight": (192, 256, 1), "cond.bias": (192,), "cond_lang.weight": (192, 4, 1), "cond_lang.bias": (192,)})
+    out = R.duration_predictor_fwd(filled_state(sh, "dpl."), "dpl.", t("enc_x"), t("enc_mask"), g=t("spk_g"), l=t("lang_l"))
+    assert close(out, t("dpl_out"), 1e-4)
