@@ -399,10 +399,11 @@ class Trainer:
                     for _, sl in self._y_groups(y))
         return (rx,) + rys
 
-    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None):
+    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None, l=None):
         """One optimizer step.  g [b, gin_channels, 1]: speaker vectors of the multi-speaker configs (cfg 4);
-        pitch / energy [b, 1, t_y]: raw contours of cfg 5 (FlowGenerator.forward normalises them, models.py:1054-1071)."""
-        cond = {k: v for k, v in (("g", g), ("pitch", pitch), ("energy", energy)) if v is not None}
+        pitch / energy [b, 1, t_y]: raw contours of cfg 5 (FlowGenerator.forward normalises them, models.py:1054-1071);
+        l [b]: language ids (cfg 5)."""
+        cond = {k: v for k, v in (("g", g), ("pitch", pitch), ("energy", energy), ("l", l)) if v is not None}
         from . import ops
         ops.ROW_ROUND = self.row_round
         if self.total_steps:
