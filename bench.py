@@ -39,10 +39,11 @@ WORKLOADS = {
     "cfg4": dict(B=20, T_x=235, T_y=500, gin=256,
                  desc="configs/base_blank_ms.json-shaped synthetic batch (multi-speaker, gin_channels=256, g ~ N(0,1) [B,256,1]), "
                       "B=20/GPU, T_x<=235, T_y<=500, bf16 GEMMs"),
-    "cfg5dec": dict(B=32, T_x=127, T_y=400, gin=512, n_layers_enc=10, prosody=True,
+    "cfg5dec": dict(B=32, T_x=127, T_y=400, gin=512, n_layers_enc=10, prosody=True, n_lang=10, lin=4,
                     desc="configs/base_blank_emo_lang_pitch.json-shaped synthetic batch, B=32/GPU, T_x<=127, T_y<=400, gin_channels=512, "
-                         "10 encoder layers, 3 WaveNets per coupling block (wn + wn_energy + wn_pitch) with g, pitch, energy inputs; "
-                         "WITHOUT the emotion / language embeddings and the stochastic duration / pitch / energy predictors (SURVEY §8 f1)"),
+                         "10 encoder layers, language embedding (10 languages, 4 channels), 3 WaveNets per coupling block (wn + wn_energy + "
+                         "wn_pitch) with g, l, pitch, energy inputs; WITHOUT the emotion embeddings and the stochastic duration / pitch / "
+                         "energy predictors (SURVEY §8 f1)"),
 }
 
 
@@ -119,7 +120,7 @@ def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
     return e0.elapsed_time(e1) / (replays * launches), rc.R
 
 
-def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None, n_layers_enc=6, pitch=None, energy=None):
+def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None, n_layers_enc=6, pitch=None, energy=None, lang=None):
     """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
     from oracle import glowtts_ref as R
     from oracle import mas as omas
@@ -141,7 +142,8 @@ def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None, n_layers_enc=6,
     for it in range(2):
         t0 = time.perf_counter()
         out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=None if g is None else g[:n].cpu(),
-                              pitch=None if pitch is None else pitch[:n, :, :Ty].cpu(), energy=None if energy is None else energy[:n, :, :Ty].cpu())
+                              pitch=None if pitch is None else pitch[:n, :, :Ty].cpu(), energy=None if energy is None else energy[:n, :, :Ty].cpu(),
+                              l=None if lang is None else torch.nn.functional.embedding(lang[:n].cpu(), P["emb_l.weight"]).unsqueeze(-1))
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
         for v in P.values():
@@ -179,7 +181,8 @@ def main():
     wl = WORKLOADS[args.workload]
     torch.manual_seed(1234)                          # identical initial weights on every rank
     gin = wl.get("gin", 0)
-    cfg = dict(train.BASE_MODEL, gin_channels=gin, n_layers_enc=wl.get("n_layers_enc", 6), with_prosody_wn=bool(wl.get("prosody")))
+    cfg = dict(train.BASE_MODEL, gin_channels=gin, n_layers_enc=wl.get("n_layers_enc", 6), with_prosody_wn=bool(wl.get("prosody")),
+               n_lang=wl.get("n_lang", 0), lin_channels=wl.get("lin", 0))
     model = train.build_model(cfg if (gin or wl.get("prosody")) else None, device=dev).train()
     if world > 1:
         for p in model.parameters():
@@ -193,6 +196,8 @@ def main():
         gp = torch.Generator().manual_seed(977 + rank)
         cond["pitch"] = ((80 + 200 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)) * (torch.rand(wl["B"], 1, wl["T_y"], generator=gp) > 0.3)).to(dev)
         cond["energy"] = (1 + 10 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)).to(dev)
+        if wl.get("n_lang"):
+            cond["l"] = torch.randint(0, 3, (wl["B"],), generator=gp).to(dev)
     lh = (t_x.tolist(), t_y.tolist())                # host copy of the lengths (a data loader has them): no per-step sync
     valid_frames = int(t_y.sum().item())
     padded_frames = wl["B"] * wl["T_y"]
@@ -282,7 +287,7 @@ def main():
                                     "algorithmic_bytes_per_launch": m["algorithmic_bytes"]}}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model, g=spk, n_layers_enc=wl.get("n_layers_enc", 6),
-                                                pitch=cond.get("pitch"), energy=cond.get("energy"))
+                                                pitch=cond.get("pitch"), energy=cond.get("energy"), lang=cond.get("l"))
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
