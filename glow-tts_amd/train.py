@@ -358,7 +358,9 @@ class Trainer:
         cond = static[4]
         static = static[:4]
         cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
+        if getattr(self, "_cap_stream", None) is None:   # ONE capture stream per trainer: the parameters' AccumulateGrad
+            self._cap_stream = torch.cuda.Stream()       # nodes stay bound to the stream of the first warm-up
+        side = self._cap_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(3):                       # warm-up: one-time attribute calls, scratch growth, optimizer state

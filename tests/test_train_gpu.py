@@ -341,3 +341,36 @@ def test_failed_capture_falls_back_to_eager_steps(built, monkeypatch):
     assert abs(l1.item() - l2.item()) <= 1e-3 * max(1.0, abs(l1.item()))
     worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
     assert worst < 5e-3, worst
+
+
+def test_graph_trainer_alternates_between_row_buckets(built):
+    """Two batches whose rounded row counts differ get one captured graph each; replays may alternate between them in
+    any order.  (A bucket's first call runs 3 warm-up steps + 1 replay on its batch — the eager trainer mirrors that.)"""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m1 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m1.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    m1.encoder.pre.p_dropout = 0.0
+    m2 = train.build_model(cfg, device=dev())
+    m2.load_state_dict(m1.state_dict())
+    m2.encoder.pre.p_dropout = 0.0
+    bA, bC = train.synth_batch(4, 40, 120, 0, dev()), train.synth_batch(4, 40, 120, 3, dev())
+    te, tg = train.Trainer(m1, graph=False), train.Trainer(m2, graph=True)
+    te.row_round = tg.row_round = 32                        # small buckets: the two batches land in different ones
+    lh = lambda b: (b[1].tolist(), b[3].tolist())           # noqa: E731
+    from glow_tts_amd import ops
+    ops.ROW_ROUND = 32                                      # (Trainer.step sets it from row_round on every call)
+    assert tg._rows_key(bA[0], bA[2], lh(bA)) != tg._rows_key(bC[0], bC[2], lh(bC))
+    for b in [bA] * 4 + [bC] * 4 + [bA, bC, bA, bA, bC]:
+        le, _ = te.step(*b, lengths_host=lh(b))
+    for b in [bA, bC, bA, bC, bA, bA, bC]:
+        lg, _ = tg.step(*b, lengths_host=lh(b))
+    torch.cuda.synchronize()
+    assert tg.graph_mode and len(tg._captured) == 2
+    assert abs(le.item() - lg.item()) <= 2e-2 * max(1.0, abs(le.item())), (le.item(), lg.item())
+    worst = max((a - b).abs().max().item() for a, b in zip(m1.parameters(), m2.parameters()))
+    assert worst < 5e-3, worst
