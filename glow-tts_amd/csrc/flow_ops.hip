@@ -93,9 +93,16 @@ __global__ void gt_flow_scalars_kernel(const float* __restrict__ logs, int C, co
 __global__ __launch_bounds__(256) void gt_actnorm_invconv_fwd_kernel(
     const float* __restrict__ x, float* __restrict__ y, bf16_t* __restrict__ y0_bf16, int ld0,
     const float* __restrict__ logs, const float* __restrict__ bias, const float* __restrict__ W,
-    const float* __restrict__ rowmask, int R, int C)
+    const float* __restrict__ rowmask, int R, int C,
+    const float* __restrict__ scal, const int32_t* __restrict__ len, float* __restrict__ logdet, int B)
 {
   const int G = C >> 2, half = C >> 1;
+  // log-det bookkeeping of this flow pair rides along in workgroup 0 (it used to be a launch of its own on the
+  // decoder's dependent chain): logdet[b] += (sum logs + G * logdet W) * len_b
+  if (logdet && blockIdx.x == 0) {
+    const float per_frame = scal[0] + (float)G * scal[1];
+    for (int b = threadIdx.x; b < B; b += 256) logdet[b] += per_frame * (float)len[b];
+  }
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= R * G) return;
   const int m = idx / G, g = idx - m * G;
@@ -146,10 +153,24 @@ __global__ __launch_bounds__(256) void gt_actnorm_invconv_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
     const float* __restrict__ logs, const float* __restrict__ bias, const float* __restrict__ W,
     const float* __restrict__ rowmask, float* __restrict__ dlogs, float* __restrict__ dbias, float* __restrict__ dW,
-    int R, int C, int rows_per_block)
+    int R, int C, int rows_per_block,
+    const float* __restrict__ scal, const int32_t* __restrict__ len, const float* __restrict__ dlogdet, int B)
 {
   // block: 256 threads = 4 row phases x 64 "group lanes" (G = C/4 <= 64); loops over its row slab
   __shared__ float sW[4][16];
+  // backward of the log-det bookkeeping, in workgroup 0 (formerly its own launch): with s = sum_b dlogdet[b] * len_b,
+  // dlogs[c] += s and dW += (C/4) * s * W^{-T}; atomics, because every workgroup accumulates into dlogs / dW
+  if (dlogdet && blockIdx.x == 0) {
+    __shared__ float sred[4];
+    float sv = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) sv += dlogdet[b] * (float)len[b];
+    sv = wave_sum(sv);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = sv;
+    __syncthreads();
+    sv = sred[0] + sred[1] + sred[2] + sred[3];
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dlogs + c, sv);
+    if (threadIdx.x < 16) atomicAdd(dW + threadIdx.x, (float)(C >> 2) * sv * scal[2 + threadIdx.x]);
+  }
   const int G = C >> 2, half = C >> 1;
   const int g = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int m0 = blockIdx.x * rows_per_block, m1 = min(R, m0 + rows_per_block);
@@ -206,29 +227,6 @@ __global__ __launch_bounds__(256) void gt_actnorm_invconv_bwd_kernel(
     }
   }
   if (threadIdx.x < 16) atomicAdd(dW + threadIdx.x, sW[0][threadIdx.x] + sW[1][threadIdx.x] + sW[2][threadIdx.x] + sW[3][threadIdx.x]);
-}
-
-// log-det bookkeeping: logdet[b] += (sum logs + G*logdet W) * len_b ; backward adds the matching
-// terms: dlogs[c] += s, dW += G * s * W^{-T} with s = sum_b dlogdet[b]*len_b.
-__global__ void gt_flow_logdet_kernel(const float* __restrict__ scal, const int32_t* __restrict__ len, float* __restrict__ logdet,
-                                      int B, int G)
-{
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b < B) logdet[b] += (scal[0] + (float)G * scal[1]) * (float)len[b];
-}
-__global__ void gt_flow_logdet_bwd_kernel(const float* __restrict__ scal, const int32_t* __restrict__ len,
-                                          const float* __restrict__ dlogdet, float* __restrict__ dlogs, float* __restrict__ dW,
-                                          int B, int C)
-{
-  float s = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) s += dlogdet[b] * (float)len[b];
-  __shared__ float red[4];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  s = red[0] + red[1] + red[2] + red[3];
-  for (int c = threadIdx.x; c < C; c += 256) dlogs[c] += s;
-  if (threadIdx.x < 16) dW[threadIdx.x] += (float)(C >> 2) * s * scal[2 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------ affine coupling
@@ -408,12 +406,9 @@ extern "C" int gt_actnorm_invconv_fwd(const float* x, float* y, void* y0_bf16, i
 {
   if (!x || !y || !logs || !bias || !W || !rowmask || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
   const int G = C >> 2;
+  if (logdet && (!scal || !len || B <= 0)) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_actnorm_invconv_fwd_kernel, dim3((R * G + 255) / 256), dim3(256), 0, GT_ST(stream),
-                     x, y, static_cast<bf16_t*>(y0_bf16), ld0, logs, bias, W, rowmask, R, C);
-  if (logdet) {
-    if (!scal || !len) return GT_E_INVAL;
-    hipLaunchKernelGGL(gt_flow_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, GT_ST(stream), scal, len, logdet, B, G);
-  }
+                     x, y, static_cast<bf16_t*>(y0_bf16), ld0, logs, bias, W, rowmask, R, C, scal, len, logdet, B);
   GT_RET();
 }
 extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx, const float* logs, const float* bias,
@@ -423,12 +418,9 @@ extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx
   if (!x || !dy || !dx || !logs || !bias || !W || !rowmask || !dlogs || !dbias || !dW || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
   static int rows_per_block = 0;                          // dev knob GT_ANB_ROWS
   if (!rows_per_block) { const char* e = getenv("GT_ANB_ROWS"); rows_per_block = e ? atoi(e) : 128; if (rows_per_block < 4) rows_per_block = 128; }
+  if (dlogdet && (!scal || !len || B <= 0)) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_actnorm_invconv_bwd_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(256), 0, GT_ST(stream),
-                     x, dy, dx, logs, bias, W, rowmask, dlogs, dbias, dW, R, C, rows_per_block);
-  if (dlogdet) {
-    if (!scal || !len) return GT_E_INVAL;
-    hipLaunchKernelGGL(gt_flow_logdet_bwd_kernel, dim3(1), dim3(256), 0, GT_ST(stream), scal, len, dlogdet, dlogs, dW, B, C);
-  }
+                     x, dy, dx, logs, bias, W, rowmask, dlogs, dbias, dW, R, C, rows_per_block, scal, len, dlogdet, B);
   GT_RET();
 }
 extern "C" int gt_actnorm_invconv_rev(const float* y, float* x, void* x0_bf16, int ld0, const float* logs, const float* bias,
