@@ -1,0 +1,43 @@
+"""Dev tool: idle time inside one replayed step, from a rocprofv3 --kernel-trace database.
+usage: timeline.py <dir> — takes the last full step (between two gt_pack_conv_weights_multi launches) and reports the span,
+the time during which NO kernel was running, and the largest idle gaps with the kernels around them."""
+import glob, sqlite3, sys
+
+db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
+packs = [i for i, r in enumerate(rows) if "gt_pack_conv_weights_multi" in r[0]]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(packs) // 2
+i0, i1 = packs[k], packs[k + 1]                     # default: a step in the middle of the run (the replayed ones)
+step = rows[i0:i1]
+t0, t1 = step[0][1], max(r[2] for r in step)
+print(f"step span {(t1 - t0) / 1e6:.3f} ms, {len(step)} kernels, kernel time {sum(r[2] - r[1] for r in step) / 1e6:.3f} ms, "
+      f"queues {sorted({r[3] for r in step})}, streams {sorted({r[4] for r in step})}")
+# union of busy intervals
+busy, cur_s, cur_e = 0, None, None
+gaps = []
+prev = None
+for r in sorted(step, key=lambda r: r[1]):
+    s, e = r[1], r[2]
+    if cur_e is None:
+        cur_s, cur_e, last = s, e, r
+    elif s <= cur_e:
+        if e > cur_e:
+            cur_e, last = e, r
+    else:
+        busy += cur_e - cur_s
+        gaps.append((s - cur_e, last[0][:60], r[0][:60]))
+        cur_s, cur_e, last = s, e, r
+busy += cur_e - cur_s
+print(f"busy (any kernel running) {busy / 1e6:.3f} ms, idle {(t1 - t0 - busy) / 1e6:.3f} ms in {len(gaps)} gaps "
+      f"(mean {sum(g[0] for g in gaps) / max(1, len(gaps)) / 1e3:.2f} us)")
+for g in sorted(gaps, reverse=True)[:12]:
+    print(f"  {g[0] / 1e3:7.1f} us  after {g[1]}  before {g[2]}")
+# overlap: time with >= 2 kernels running
+ev = sorted([(r[1], 1) for r in step] + [(r[2], -1) for r in step])
+n, last_t, over = 0, None, 0
+for t, d in ev:
+    if n >= 2:
+        over += t - last_t
+    n += d; last_t = t
+print(f"time with >= 2 kernels running: {over / 1e6:.3f} ms")
