@@ -373,7 +373,10 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   static int bm64 = -1;
   if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 256; }
   const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
-  if (bm64 && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np % 64 == 0 && Np >= N) {
+  static int nit64 = -1;                     // 64 x 64 tiles only for short K loops (dev knob GT_CONV_NIT64; 0 = no limit)
+  if (nit64 < 0) { const char* e = getenv("GT_CONV_NIT64"); nit64 = e ? atoi(e) : 0; }
+  const bool short_k = bnsel == 128 || nit64 == 0 || (Kp / BK) * taps <= nit64;
+  if (bm64 && short_k && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np % 64 == 0 && Np >= N) {
     const dim3 grid(8 * (((R + 63) / 64 + 7) / 8) * (Np / bnsel));
     if (gate == 1) {
       if (!gate_t || !gate_s || out_f32) return GT_E_INVAL;
