@@ -83,7 +83,7 @@ def mas_leg(dev, wl, rank, iters=100):
             "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes, "logp": logp, "t_x": t_x, "t_y": t_y}
 
 
-def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
+def gate_conv_leg(dev, model, lh, T_y, p_drop, ragged, row_round, launches=20, replays=20):
     """The dominant kernel alone, on the step's own shapes and weights: the WN in_layer k=5 conv + gate of the first
     coupling block, `launches` back-to-back launches captured in ONE HIP graph (no host launch gaps, as in the step's own
     graph) and timed with HIP events on the stream they run on.  -> average launch duration in ms."""
@@ -91,7 +91,7 @@ def gate_conv_leg(dev, model, lh, T_y, p_drop, launches=20, replays=20):
     wn = model.decoder.flows[2].wn
     conv = wn.in_layers[0]
     lens = torch.tensor([v // 2 for v in lh[1]], dtype=torch.int32, device=dev)
-    rc = ops.RowsCtx(lens, T_y // 2, lengths_host=[v // 2 for v in lh[1]]) if ops.RAGGED else ops.RowsCtx(lens, T_y // 2)
+    rc = ops.RowsCtx(lens, T_y // 2, lengths_host=[v // 2 for v in lh[1]], round_to=row_round) if ragged else ops.RowsCtx(lens, T_y // 2)
     H = wn.hidden_channels
     x = (torch.randn(rc.R, H, device=dev) * rc.rowmask[:, None]).to(torch.bfloat16)
     y = torch.empty(rc.R, H, dtype=torch.bfloat16, device=dev); t = torch.empty_like(y); s_ = torch.empty_like(y)
@@ -236,13 +236,14 @@ def main():
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        if ops.RAGGED:                                # utterances packed back to back: only their own frames (+ halos) are rows
-            _, R_dec = ops.RowsCtx.row_starts([v // 2 for v in lh[1]], wl["T_y"] // 2, ops.ROW_ROUND)
+        ragged = tr.cfg.ragged
+        if ragged:                                    # utterances packed back to back: only their own frames (+ halos) are rows
+            _, R_dec = ops.RowsCtx.row_starts([v // 2 for v in lh[1]], wl["T_y"] // 2, tr.cfg.row_round)
         else:
             R_dec = wl["B"] * (wl["T_y"] // 2 + 2 * ops.HALO)
         # in_layer 192 -> 384, k = 5: 368 640 MAC per squeezed frame.  Ragged layout: only the VALID squeezed
         # frames count as algorithmic work (halo / rounding rows the kernel also walks do not)
-        rows_alg = valid_frames // 2 if ops.RAGGED else R_dec
+        rows_alg = valid_frames // 2 if ragged else R_dec
         flops_launch = 2.0 * rows_alg * 384 * 192 * 5
         line = {
             "metric": "mel_frames_per_sec_train_step",
@@ -253,7 +254,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": wl["B"], "T_x": wl["T_x"], "T_y": wl["T_y"],
                        "valid_frames_per_gpu_step": valid_frames, "padded_frames_per_gpu_step": padded_frames,
-                       "rows_layout": (f"ragged (decoder rows {R_dec})" if ops.RAGGED else f"uniform (decoder rows {R_dec})"),
+                       "rows_layout": (f"ragged (decoder rows {R_dec})" if ragged else f"uniform (decoder rows {R_dec})"),
                        "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
                        "launch": (("one HIP graph per step" if world == 1 else "two HIP graphs per step (fwd+bwd | optimizer), RCCL all-reduce between them")
                                   if tr.graph_mode else "eager launches"),
@@ -262,7 +263,7 @@ def main():
                        "final_loss": float(loss)},
             "padded_frames_per_sec": world * padded_frames / (wall / args.steps),
         }
-        avg_ms, rows_launched = gate_conv_leg(dev, model, lh, wl["T_y"], model.decoder.flows[2].wn.p_dropout)
+        avg_ms, rows_launched = gate_conv_leg(dev, model, lh, wl["T_y"], model.decoder.flows[2].wn.p_dropout, ragged, tr.cfg.row_round)
         tf = flops_launch / (avg_ms * 1e-3) / 1e12
         traffic = None                               # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gate_conv_pmc.json")

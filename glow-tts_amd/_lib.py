@@ -24,12 +24,7 @@ PROTOTYPES = {
     "gt_conv_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                   c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p]),
-    "gt_conv_gemm2_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                  c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p]),
-    "gt_conv_gemm2_supported": (c_int, [c_int, c_int, c_int, c_int]),
+                                  c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -41,6 +36,7 @@ PROTOTYPES = {
     "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_flow_scalars": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gt_actnorm_ddi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gt_actnorm_invconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_actnorm_invconv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -92,6 +88,7 @@ class PackDesc(ctypes.Structure):
                 ("row_start", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+GT_TILE_AUTO, GT_TILE_64x64, GT_TILE_64x128, GT_TILE_128x64, GT_TILE_128x128, GT_TILE_256x64 = 0, 1, 2, 3, 4, 5
 GT_DT_F32, GT_DT_I32, GT_DT_F16, GT_DT_BF16, GT_DT_U8 = 0, 1, 2, 3, 4
 GT_ERRORS = {-1: "GT_E_INVAL", -2: "GT_E_UNSUPPORTED", -3: "GT_E_ALIGN", -4: "GT_E_LAUNCH"}
 

@@ -56,45 +56,90 @@ class CouplingBlock(nn.Module):
             self.wn_energy = WNP(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout, 1, n_sqz)
 
     def store_inverse(self):
-        pass
+        """attentions.py:188-194 removes the weight norms of wn / wn_energy / wn_pitch so that synthesis stops
+        recomputing g*v/|v|: here that product only exists inside the packed bf16 images, which FlowSpecDecoder.store_inverse
+        freezes (one pack, reused by every reverse call); the parameters keep their weight_g / weight_v form."""
+        prepare_all(self)
+        self._frozen = True
+
+    def _cond_affine(self, which):
+        """cond_layer1 (one input channel, weight-normed 1x1 conv: modules.py:289-291,320) as the per-frame affine map
+        (w [O], b [O]); differentiable w.r.t. its parameters."""
+        c = getattr(self, which).cond_layer1
+        v = c.weight_v.reshape(c.out_channels)
+        return torch.stack([v * (c.weight_g.reshape(-1) / v.abs()), c.bias])
 
     def forward(self, x, x_mask=None, reverse=False, g=None, emo=None, pitch=None, energy=None, **kwargs):
+        """attentions.py:132-186 as a stand-alone module (inside models.FlowSpecDecoder the whole chain is one node):
+        forward -> (z, logdet); reverse=True -> (x, None), no autograd.  pitch / energy [b,1,2t] (or [b,2t]): contours at
+        the UN-squeezed frame rate for wn_pitch / wn_energy (needs with_prosody_wn=True)."""
+        if (pitch is not None or energy is not None) and not hasattr(self, "wn_pitch"):
+            raise ValueError("pitch / energy conditioning needs CouplingBlock(with_prosody_wn=True)")
+        if x_mask is None:
+            x_mask = torch.ones(x.shape[0], 1, x.shape[2], device=x.device, dtype=x.dtype)
+        pitch = pitch.unsqueeze(1) if (pitch is not None and pitch.dim() == 2) else pitch
+        energy = energy.unsqueeze(1) if (energy is not None and energy.dim() == 2) else energy
+        if not (reverse and getattr(self, "_frozen", False)):
+            prepare_all(self)
+            self._frozen = False
+        runner = _CouplingRunner(self, x_mask, g is not None, self.training and not reverse, energy=energy, pitch=pitch)
+        affs = [self._cond_affine(w) for w, c in (("wn_energy", energy), ("wn_pitch", pitch)) if c is not None]
+        tensors = [x] + ([_wn_cond(self.wn, g)] if g is not None else []) + affs + runner.params
         if reverse:
-            raise NotImplementedError("reverse flow (inference) is out of the training hot-path scope")
-        if pitch is not None or energy is not None:
-            raise NotImplementedError("pitch / energy conditioning runs through models.FlowSpecDecoder (one autograd node)")
-        prepare_all(self)
-        runner = _CouplingRunner(self, x_mask, g is not None, self.training)
-        tensors = [x] + ([_wn_cond(self.wn, g)] if g is not None else []) + runner.params
+            with torch.no_grad():
+                return runner.reverse(*[t.detach() for t in tensors]), None
         z, logdet = _RowsFn.apply(runner, 2, *tensors)
         return z, logdet
 
 
 class _CouplingRunner:
-    def __init__(self, cb, x_mask, has_cond, train, seed=0):
+    def __init__(self, cb, x_mask, has_cond, train, seed=0, energy=None, pitch=None):
         self.cb, self.has_cond, self.train, self.seed = cb, has_cond, train, seed
-        self.x_mask = x_mask
+        self.x_mask, self.energy, self.pitch = x_mask, energy, pitch
         self.params = [p for n, p in cb.named_parameters() if not n.startswith("wn.cond_layer") and "cond_layer1" not in n]
 
-    def forward(self, x, *rest):
-        cond = rest[0] if self.has_cond else None
+    def _inputs(self, x, rest):
+        k = 0
+        cond = eaff = paff = None
+        if self.has_cond:
+            cond = rest[k]; k += 1
+        if self.energy is not None:
+            eaff = rest[k]; k += 1
+        if self.pitch is not None:
+            paff = rest[k]; k += 1
         B, C, T = x.shape
         rc = RowsCtx(_mask_lengths(self.x_mask), T)
         xr = rc.to_rows(x.detach().float() * self.x_mask)
-        x0 = xr[:, :C // 2].to(torch.bfloat16)
-        logdet = torch.zeros(B, dtype=torch.float32, device=x.device)
-        z, saved = flow_impl.coupling_fwd(rc, self.cb, xr, x0, cond, logdet, self.train, self.seed)
-        return (rc.from_rows(z), logdet), (rc, saved)
+        esig, psig = flow_impl.contour_rows(rc, self.energy, B, 2 * T), flow_impl.contour_rows(rc, self.pitch, B, 2 * T)
+        return rc, xr, cond, esig, psig, flow_impl.cond_rows(esig, eaff), flow_impl.cond_rows(psig, paff)
+
+    def forward(self, x, *rest):
+        rc, xr, cond, esig, psig, econd, pcond = self._inputs(x, rest)
+        x0 = xr[:, :x.shape[1] // 2].to(torch.bfloat16)
+        logdet = torch.zeros(x.shape[0], dtype=torch.float32, device=x.device)
+        z, saved = flow_impl.coupling_fwd(rc, self.cb, xr, x0, cond, logdet, self.train, self.seed, econd=econd, pcond=pcond)
+        return (rc.from_rows(z), logdet), (rc, saved, esig, psig)
+
+    def reverse(self, z, *rest):
+        rc, zr, cond, _, _, econd, pcond = self._inputs(z, rest)
+        z0 = zr[:, :z.shape[1] // 2].to(torch.bfloat16)
+        return rc.from_rows(flow_impl.coupling_rev(rc, self.cb, zr, z0, cond, econd=econd, pcond=pcond)).to(z.dtype)
 
     def backward(self, saved_all, dz, dlogdet):
-        rc, saved = saved_all
+        rc, saved, esig, psig = saved_all
         dlogdet = torch.zeros(rc.B, device=dz.device) if dlogdet is None else dlogdet.contiguous().float()
         dzr = rc.to_rows(dz.float())
         with wgrad.WgradQueue(dz.device, site=self.cb):
-            dx, grads, dcond = flow_impl.coupling_bwd(rc, self.cb, saved, dzr, dlogdet, self.has_cond)
+            if esig is None and psig is None:
+                dx, grads, dcond = flow_impl.coupling_bwd(rc, self.cb, saved, dzr, dlogdet, self.has_cond)
+                dpros = [None, None]
+            else:
+                dx, grads, dcond, dpros = flow_impl.coupling_bwd(rc, self.cb, saved, dzr, dlogdet, self.has_cond,
+                                                                 econd=esig is not None, pcond=psig is not None)
         out = [rc.from_rows(dx)]
         if self.has_cond:
             out.append(dcond)
+        out += [flow_impl.cond_affine_grads(dc, sig) for dc, sig in ((dpros[0], esig), (dpros[1], psig)) if sig is not None]
         return out + [grads.get(p) for p in self.params]
 
 

@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
     const int nxt = it + 1;
     const bool has = nxt < NIT;
     const bool newslice = has && (tap == taps - 1);
-    if (has && !(a.exp_ & 2)) { load_W(nxt); if (newslice) load_X(slice + 1); }
+#ifdef GT_DEV_EXPERIMENTS
+    const bool ld_ok = !(a.exp_ & 2);
+#else
+    constexpr bool ld_ok = true;
+#endif
+    if (has && ld_ok) { load_W(nxt); if (newslice) load_X(slice + 1); }
 
     const bf16_t* wsb = &Ws[it & 1][(32 * NB * wn + r) * LDP + 8 * h];
     const bf16_t* xsb = &Xs[slice & 1][(mrow0 + r + tap) * LDP + 8 * h];
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
           acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[bn], bfm[bm], acc[bn][bm], 0, 0, 0);
     }
 
-    if (has && !(a.exp_ & 2)) { store_W(nxt & 1); if (newslice) store_X((slice + 1) & 1); }
+    if (has && ld_ok) { store_W(nxt & 1); if (newslice) store_X((slice + 1) & 1); }
     __syncthreads();
   }
 
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
   // so bias / cond / addend loads and all stores are 16-32 B per lane and whole 128-B lines per row — the MFMA
   // layout itself gives only 8 B per lane with a row stride between lanes.
   float* es = reinterpret_cast<float*>(smem);
+#ifdef GT_DEV_EXPERIMENTS
   if (a.exp_ & 1) {
     float sacc = 0.f;
 #pragma unroll
@@ -164,6 +170,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
     if (sacc == 123.456f) static_cast<bf16_t*>(a.Y)[tid] = 1;
     return;
   }
+#endif
 #pragma unroll
   for (int bm = 0; bm < MB; ++bm)
 #pragma unroll
@@ -335,7 +342,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
                                  void* gate_t, void* gate_s, int ldts,
                                  int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
                                  int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
-                                 const int32_t* row0, int B, void* stream)
+                                 const int32_t* row0, int B, int tile, void* stream)
 {
   if (R < 0 || N <= 0 || Cin <= 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
@@ -345,6 +352,8 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15) return GT_E_ALIGN;
   if (addend && (ldadd & 3)) return GT_E_ALIGN;
   if (cond && (Tp <= 0 || (row0 && B <= 0))) return GT_E_INVAL;
+  if (tile < GT_TILE_AUTO || tile > GT_TILE_256x64) return GT_E_INVAL;
+  if (Np % 64 || Np < N) return GT_E_INVAL;
   ConvArgs a;
   a.X = static_cast<const bf16_t*>(X); a.ldx = ldx; a.W = static_cast<const bf16_t*>(Wp); a.bias = bias;
   a.cond = cond; a.ldc = ldc; a.rowmask = rowmask; a.Y = Y; a.ldy = ldy; a.addend = addend; a.ldadd = ldadd;
@@ -353,7 +362,10 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   a.row0 = row0; a.B = B;
   a.out_f32 = out_f32; a.relu = relu;
   a.y16 = !(ldy & 7);
-  { static int ex = -1; if (ex < 0) { const char* e = getenv("GT_CONV_EXP"); ex = e ? atoi(e) : 0; } a.exp_ = ex; }
+  a.exp_ = 0;
+#ifdef GT_DEV_EXPERIMENTS                    // tools/conv_exp.py builds its own library with this flag; never in the product build
+  { const char* e = getenv("GT_CONV_EXP"); a.exp_ = e ? atoi(e) : 0; }
+#endif
   a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f; a.seed_dev = seed_dev;
   a.gatebwd = (gate == 2); a.gb_thresh = 0;
   if (drop_p > 0.0f) {
@@ -365,43 +377,40 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
     if (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15) return GT_E_ALIGN;
     a.gb_thresh = a.drop_thresh; a.drop_thresh = 0;
   }
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const dim3 block(256);
-  // Short tiles: when 128-row tiles give no more workgroups than the chip has CUs (one wave per SIMD, nothing to hide the
-  // LDS / L2 latency behind), 64-row tiles double the resident waves at the price of streaming the weights twice as often
-  // (cfg2 step 9.00 -> 8.76 ms; with the threshold at 512 workgroups the gain is gone).  GT_CONV_BM64=0 turns it off.
-  static int bm64 = -1;
-  if (bm64 < 0) { const char* e = getenv("GT_CONV_BM64"); bm64 = e ? atoi(e) : 256; }
-  const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
-  static int nit64 = -1;                     // 64 x 64 tiles only for short K loops (dev knob GT_CONV_NIT64; 0 = no limit)
-  if (nit64 < 0) { const char* e = getenv("GT_CONV_NIT64"); nit64 = e ? atoi(e) : 0; }
-  const bool short_k = bnsel == 128 || nit64 == 0 || (Kp / BK) * taps <= nit64;
-  if (bm64 && short_k && ((R + 127) / 128) * (Np / bnsel) <= bm64 && (gate != 1 || (!(N & 127) && Np == N)) && Np % 64 == 0 && Np >= N) {
-    const dim3 grid(8 * (((R + 63) / 64 + 7) / 8) * (Np / bnsel));
-    if (gate == 1) {
-      if (!gate_t || !gate_s || out_f32) return GT_E_INVAL;
-      if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
-      hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, true>), grid, block, 0, st, a);
-    } else if (bnsel == 128) hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, false>), grid, block, 0, st, a);
-    else                     hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 64, false>), grid, block, 0, st, a);
-    return gt_launch_status(__func__);
-  }
-  if (gate == 1) {
+  if (gate == 1) {                            // gate: N = Np = 2 * half, [32 tanh | 32 sigmoid] per 64 packed rows, 128-column tiles
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;
     if ((ldts & 7) || (ldy & 7) || (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15)) return GT_E_ALIGN;
-    static int tall = -1;
-    if (tall < 0) { const char* e = getenv("GT_CONV_BM256"); tall = e ? atoi(e) : 0; }      // measured: no gain on cfg2 (the loop is not fill-bound), kept for experiments
-    const int wgs256 = ((R + 255) / 256) * (Np / 64);
-    if (tall && wgs256 >= 150 && wgs256 <= 300)
-      hipLaunchKernelGGL((gt_conv_gemm_kernel<256, 64, true>), dim3(8 * (((R + 255) / 256 + 7) / 8) * (Np / 64)), block, 0, st, a);
-    else
-      hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, true>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 128)), block, 0, st, a);
-  } else if (Np % 128 == 0) {
-    if (Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, false>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 128)), block, 0, st, a);
-  } else {
-    if (Np % 64 || Np < N) return GT_E_INVAL;
-    hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 64, false>), dim3(8 * (((R + 127) / 128 + 7) / 8) * (Np / 64)), block, 0, st, a);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 block(256);
+  // Tile choice (GT_TILE_AUTO).  Short tiles: when 128-row tiles give no more workgroups than the chip has CUs (one wave
+  // per SIMD, nothing to hide the LDS / L2 latency behind), 64-row tiles double the resident waves at the price of
+  // streaming the weights twice as often (cfg2 step 9.00 -> 8.76 ms; with the threshold at 512 workgroups the gain is
+  // gone).  256-row tiles (gate only) never paid on the measured shapes and are reachable only through `tile`.
+  constexpr int SHORT_TILE_MAX_WGS = 256;
+  const int bnsel = (gate == 1 || Np % 128 == 0) ? 128 : 64;
+  if (tile == GT_TILE_AUTO) {
+    const bool short_rows = ((R + 127) / 128) * (Np / bnsel) <= SHORT_TILE_MAX_WGS;
+    tile = short_rows ? (bnsel == 128 ? GT_TILE_64x128 : GT_TILE_64x64) : (bnsel == 128 ? GT_TILE_128x128 : GT_TILE_128x64);
+  }
+  const int bm = (tile == GT_TILE_64x64 || tile == GT_TILE_64x128) ? 64 : (tile == GT_TILE_256x64 ? 256 : 128);
+  const int bn = (tile == GT_TILE_64x128 || tile == GT_TILE_128x128) ? 128 : 64;
+  if (Np % bn) return GT_E_INVAL;
+  if (gate == 1 && bn != 128 && tile != GT_TILE_256x64) return GT_E_INVAL;       // the gate pairs 32 + 32 columns of one wave
+  if (tile == GT_TILE_256x64 && gate != 1) return GT_E_INVAL;
+  const dim3 grid(8 * (((R + bm - 1) / bm + 7) / 8) * (Np / bn));
+  switch (tile) {
+    case GT_TILE_64x64:   hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 64, false>), grid, block, 0, st, a); break;
+    case GT_TILE_64x128:
+      if (gate == 1) hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, true>), grid, block, 0, st, a);
+      else           hipLaunchKernelGGL((gt_conv_gemm_kernel<64, 128, false>), grid, block, 0, st, a);
+      break;
+    case GT_TILE_128x64:  hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 64, false>), grid, block, 0, st, a); break;
+    case GT_TILE_128x128:
+      if (gate == 1) hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, true>), grid, block, 0, st, a);
+      else           hipLaunchKernelGGL((gt_conv_gemm_kernel<128, 128, false>), grid, block, 0, st, a);
+      break;
+    default:              hipLaunchKernelGGL((gt_conv_gemm_kernel<256, 64, true>), grid, block, 0, st, a); break;
   }
   return gt_launch_status(__func__);
 }

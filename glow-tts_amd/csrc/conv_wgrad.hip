@@ -277,9 +277,8 @@ extern "C" size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int ta
   if (R <= 0 || Cin <= 0 || Cout <= 0 || taps <= 0) { if (slabs_out) *slabs_out = 0; return 0; }
   const int tiles = ((Cout + 127) / 128) * ((Cin + 63) / 64);
   // slabs: enough workgroups to cover the chip, but every slab costs one full dW of partial traffic
-  // (written here, re-read by gt_weightnorm_bwd) — GT_WGRAD_WGS workgroups in total, at most 16 slabs
-  static int target = 0;
-  if (!target) { const char* e = getenv("GT_WGRAD_WGS"); target = e ? atoi(e) : 160; if (target < 1) target = 160; }
+  // (written here, re-read by gt_weightnorm_bwd) — ~160 workgroups in total, at most 16 slabs
+  constexpr int target = 160;
   int S = (target + tiles - 1) / tiles;
   if (S > 16) S = 16;
   const int max_s = (R + KB - 1) / KB;

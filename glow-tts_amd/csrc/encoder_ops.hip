@@ -645,13 +645,15 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
   q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta;
-  static int cfg = -1;                                   // dev knob: waves * 1000 + rows per workgroup
-  if (cfg < 0) { const char* e = getenv("GT_LNB"); cfg = e ? atoi(e) : 16032; }      // measured best on the cfg2 encoder (R = 3584): 16 waves x 32 rows
-  const int waves = cfg / 1000, rpb = cfg % 1000;
-  q.rows_per_block = rpb;
-  if (waves == 16)     hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + rpb - 1) / rpb), dim3(1024), 0, GT_ST(stream), q);
-  else if (waves == 8) hipLaunchKernelGGL(gt_layernorm_bwd_kernel<8>, dim3((R + rpb - 1) / rpb), dim3(512), 0, GT_ST(stream), q);
-  else                 hipLaunchKernelGGL(gt_layernorm_bwd_kernel<4>, dim3((R + rpb - 1) / rpb), dim3(256), 0, GT_ST(stream), q);
+  // geometry: 16 waves x 32 rows per workgroup (the gamma / beta partials are folded in LDS before the atomics) while
+  // that still gives >= 64 workgroups; short inputs fall back to 4 waves x 16 rows so the chip is not left idle
+  if (R >= 64 * 32) {
+    q.rows_per_block = 32;
+    hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + 31) / 32), dim3(1024), 0, GT_ST(stream), q);
+  } else {
+    q.rows_per_block = 16;
+    hipLaunchKernelGGL(gt_layernorm_bwd_kernel<4>, dim3((R + 15) / 16), dim3(256), 0, GT_ST(stream), q);
+  }
   GT_RET();
 }
 
@@ -669,8 +671,7 @@ extern "C" int gt_attn_fwd(const void* q, const void* k, const void* v, int ld, 
   if (D > AT_MAXD || (D & 1) || win < 0 || drop_p >= 1.f) return GT_E_UNSUPPORTED;
   {
     uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
-    static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
-    if (!no_mfma) {
+    {
       const int rc = gt_attn_fwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, out, ldo, P, B, T, Tp, row0, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;                      // handled (or failed loudly) on the MFMA path
     }
@@ -705,8 +706,7 @@ extern "C" int gt_attn_bwd(const void* q, const void* k, const void* v, int ld, 
   float* dS_ws = static_cast<float*>(workspace);
   {
     uint32_t th, sd; float sc; fill_drop(drop_p, drop_seed, th, sd, sc);
-    static const bool no_mfma = getenv("GT_ATTN_NO_MFMA") != nullptr;
-    if (!no_mfma) {
+    {
       const int rc = gt_attn_bwd_mfma_impl(q, k, v, ld, Ek, Ev, lens, dout, lddo, P, workspace, workspace_bytes, dq, dk, dv, lddq,
                                            dEk, dEv, B, T, Tp, row0, H, D, win, th, sd, sc, seed_dev, stream);
       if (rc != 1) return rc;

@@ -375,6 +375,34 @@ __global__ __launch_bounds__(256) void gt_rows_f32_to_bf16_kernel(const float* _
   out[(size_t)m * ldo + c] = f2bf(in[(size_t)m * ldi + c] * (rowmask ? rowmask[m] : 1.0f));
 }
 
+// ActNorm data-dependent initialisation (modules.py:607-619): masked per-channel batch statistics of the rows the layer
+// is about to see.  Pass 1: per-channel sum / sum of squares over all rows (invalid rows are zero in the rows layout), fp64
+// partials folded per workgroup, then atomics.  Pass 2 (one workgroup): logs = -0.5 log(max(var, 1e-6)), bias = -mean * exp(logs).
+__global__ __launch_bounds__(256) void gt_actnorm_ddi_stats_kernel(const float* __restrict__ x, int R, int C, int rows_per_block,
+                                                                  double* __restrict__ sums)
+{
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s = 0.0, q = 0.0;
+    for (int r = r0; r < r1; ++r) { const double v = x[(size_t)r * C + c]; s += v; q += v * v; }
+    atomicAdd(&sums[c], s); atomicAdd(&sums[C + c], q);
+  }
+}
+__global__ __launch_bounds__(256) void gt_actnorm_ddi_finish_kernel(const double* __restrict__ sums, const int32_t* __restrict__ len,
+                                                                   int B, int C, float* __restrict__ logs, float* __restrict__ bias)
+{
+  __shared__ double denom;
+  if (threadIdx.x == 0) { double d = 0.0; for (int b = 0; b < B; ++b) d += (double)len[b]; denom = d; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float m = (float)(sums[c] / denom), msq = (float)(sums[C + c] / denom);
+    const float v = msq - m * m;
+    const float l = 0.5f * logf(fmaxf(v, 1e-6f));
+    bias[c] = -m * expf(-l);
+    logs[c] = -l;
+  }
+}
+
 }  // namespace
 
 #define GT_ST(s) static_cast<hipStream_t>(s)
@@ -416,8 +444,9 @@ extern "C" int gt_actnorm_invconv_bwd(const float* x, const float* dy, float* dx
                                       const float* dlogdet, float* dlogs, float* dbias, float* dW, int B, int R, int C, void* stream)
 {
   if (!x || !dy || !dx || !logs || !bias || !W || !rowmask || !dlogs || !dbias || !dW || R <= 0 || (C & 3) || C > 256) return GT_E_INVAL;
-  static int rows_per_block = 0;                          // dev knob GT_ANB_ROWS
-  if (!rows_per_block) { const char* e = getenv("GT_ANB_ROWS"); rows_per_block = e ? atoi(e) : 128; if (rows_per_block < 4) rows_per_block = 128; }
+  // rows per workgroup: the per-channel partials are folded in LDS before the atomics, so few fat workgroups win;
+  // 128 rows down to 32 for short inputs (>= ~64 workgroups)
+  const int rows_per_block = R >= 64 * 128 ? 128 : (R >= 64 * 64 ? 64 : 32);
   if (dlogdet && (!scal || !len || B <= 0)) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_actnorm_invconv_bwd_kernel, dim3((R + rows_per_block - 1) / rows_per_block), dim3(256), 0, GT_ST(stream),
                      x, dy, dx, logs, bias, W, rowmask, dlogs, dbias, dW, R, C, rows_per_block, scal, len, dlogdet, B);
@@ -485,5 +514,16 @@ extern "C" int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo,
 {
   if (!in || !out || R <= 0 || n <= 0) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_rows_f32_to_bf16_kernel, dim3((R * n + 255) / 256), dim3(256), 0, GT_ST(stream), in, ldi, static_cast<bf16_t*>(out), ldo, rowmask, R, n);
+  GT_RET();
+}
+
+extern "C" int gt_actnorm_ddi(const float* x, const int32_t* len, int B, int R, int C, double* workspace, float* logs, float* bias,
+                              void* stream)
+{
+  if (!x || !len || !workspace || !logs || !bias || B <= 0 || R <= 0 || C <= 0) return GT_E_INVAL;
+  if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, GT_ST(stream)) != hipSuccess) return GT_E_LAUNCH;
+  const int rpb = 64;
+  hipLaunchKernelGGL(gt_actnorm_ddi_stats_kernel, dim3((R + rpb - 1) / rpb), dim3(256), 0, GT_ST(stream), x, R, C, rpb, workspace);
+  hipLaunchKernelGGL(gt_actnorm_ddi_finish_kernel, dim3(1), dim3(256), 0, GT_ST(stream), workspace, len, B, C, logs, bias);
   GT_RET();
 }

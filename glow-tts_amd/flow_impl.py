@@ -72,6 +72,27 @@ def conv_param_grads(conv, x, dy, R, want_bias=True, parts=None):
 
 
 # ----------------------------------------------------------------------------- ActNorm + InvConvNear
+def actnorm_ddi(rc, x, an):
+    """ActNorm.initialize (modules.py:607-619) from the rows this layer is about to see; writes an.logs / an.bias."""
+    L = _lib.lib()
+    R, C = x.shape
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    with torch.no_grad():
+        _lib.check(L.gt_actnorm_ddi(_lib.ptr(x), _lib.ptr(rc.lengths), rc.B, R, C, _lib.ptr(ws), _lib.ptr(an.logs.data),
+                                    _lib.ptr(an.bias.data), _st(x.device)), "gt_actnorm_ddi")
+    an.initialized = True
+
+
+def flow_scalars(logs, W):
+    """scal[18] = {sum logs, logdet W, W^-T} (gt_flow_scalars) for one ActNorm / InvConvNear pair."""
+    L = _lib.lib()
+    lg = logs.detach().reshape(-1).contiguous()
+    Wc = W.detach().contiguous()
+    scal = torch.empty(18, dtype=torch.float32, device=lg.device)
+    _lib.check(L.gt_flow_scalars(_lib.ptr(lg), lg.numel(), _lib.ptr(Wc), _lib.ptr(scal), _st(lg.device)), "gt_flow_scalars")
+    return scal
+
+
 def actnorm_invconv_fwd(rc, x, logs, bias, W, logdet, want_x0=True):
     """x: [R,C] fp32 rows.  Returns y [R,C] fp32, x0 bf16 [R,C/2] (coupling start input), saved."""
     L = _lib.lib()
@@ -187,6 +208,36 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
 
 
 # ----------------------------------------------------------------------------- coupling block
+def contour_rows(rc, c, B, T):
+    """[b,1,t] pitch / energy contour -> [R, 2] fp32 rows (column = frame parity): the time squeeze of modules.py:353-362
+    for one channel, on the squeezed rows context rc (T = un-squeezed frames covered, even)."""
+    if c is None:
+        return None
+    L = _lib.lib()
+    cc = c.detach().float().reshape(B, 1, -1)[:, :, :T].contiguous()
+    assert cc.shape[2] == T, "pitch / energy must cover the mel frames"
+    rows = torch.empty(rc.R, 2, dtype=torch.float32, device=cc.device)
+    _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(cc), _lib.ptr(rows), _lib.ptr(rc.lengths), B, 1, T, rc.Tp, _lib.ptr(rc.row0),
+                                     _st(cc.device)), "gt_squeeze_rows_f32")
+    return rows
+
+
+def cond_rows(sig, aff_b):
+    """per-frame conditioning rows [R, 2*O] = w * contour + b, laid out like the squeezed cond_layer1 output
+    (channel = parity * O + c); layer i of the WNP reads columns [2*H*i, 2*H*(i+1)).  aff_b = (w [O], b [O])."""
+    if sig is None:
+        return None
+    w, b = aff_b[0].detach().float(), aff_b[1].detach().float()
+    return torch.addcmul(b[None, None, :], sig[:, :, None], w[None, None, :]).reshape(sig.shape[0], -1)
+
+
+def cond_affine_grads(dc, sig):
+    """gradient of cond_rows w.r.t. (w, b): d w = sum dcond * contour, d b = sum dcond over (frame, parity) -> [2, O]"""
+    O = dc.shape[1] // 2
+    d3 = dc.view(dc.shape[0], 2, O)
+    return torch.stack([(d3 * sig[:, :, None]).sum((0, 1)), d3.sum((0, 1))])
+
+
 def prosody_chain(cb, econd, pcond):
     """The per-frame conditioned WaveNets that follow cb.wn, in the reference's order (attentions.py:153-154):
     wn_energy then wn_pitch; each is the identity when its conditioning is None (modules.py:323-324)."""
@@ -248,18 +299,18 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
 
 
 # ----------------------------------------------------------------------------- reverse flow (inference)
-def actnorm_invconv_rev(rc, y, logs, bias, W, want_x0=True):
-    """InvConvNear^-1 then ActNorm^-1 on rows (modules.py:647-652, 592-594).  y: [R,C] fp32 -> x, bf16(x[:, :C/2])."""
+def actnorm_invconv_rev(rc, y, logs, bias, W, want_x0=True, scal=None):
+    """InvConvNear^-1 then ActNorm^-1 on rows (modules.py:647-652, 592-594).  y: [R,C] fp32 -> x, bf16(x[:, :C/2]).
+    scal: the pair's cached flow scalars (FlowSpecDecoder.store_inverse); computed here when None."""
     L = _lib.lib()
     dev = y.device
     R, C = y.shape
     x = torch.empty_like(y)
     x0 = torch.empty(R, C // 2, dtype=torch.bfloat16, device=dev) if want_x0 else None
-    scal = torch.empty(18, dtype=torch.float32, device=dev)
     lg = logs.detach().reshape(-1).contiguous()
     bs = bias.detach().reshape(-1).contiguous()
-    Wc = W.detach().contiguous()
-    _lib.check(L.gt_flow_scalars(_lib.ptr(lg), C, _lib.ptr(Wc), _lib.ptr(scal), _st(dev)), "gt_flow_scalars")
+    if scal is None:
+        scal = flow_scalars(logs, W)
     _lib.check(L.gt_actnorm_invconv_rev(_lib.ptr(y), _lib.ptr(x), _lib.ptr(x0), C // 2, _lib.ptr(lg), _lib.ptr(bs), _lib.ptr(scal),
                                         _lib.ptr(rc.rowmask), R, C, _st(dev)), "gt_actnorm_invconv_rev")
     return x, x0

@@ -5,8 +5,6 @@ The forward signature, return values and state_dict keys (`flows.{3k}.logs`, `fl
 `flows.{3k+2}.start.weight_v`, ...) are the reference's; the whole block chain runs as ONE autograd
 node whose forward/backward are explicit HIP kernel launch sequences (flow_impl.py).
 """
-import os
-
 import torch
 from torch import nn
 
@@ -34,10 +32,22 @@ class FlowSpecDecoder(nn.Module):
                                             emoin_channels=emoin_channels, p_dropout=p_dropout,
                                             sigmoid_scale=sigmoid_scale, n_sqz=n_sqz, with_prosody_wn=with_prosody_wn))
         self._step = 0
+        self._inv_cache = None
 
     def store_inverse(self):
+        """models.py:787-789 -> modules.py:667-668 / attentions.py:188-194: freeze the decoder for synthesis.  The
+        reference caches W^-1 and folds the weight norms away; here the packed bf16 weight images and every block's flow
+        scalars (sum logs, logdet W, W^-T) are computed ONCE and reverse calls reuse them (no per-call re-pack) until
+        `clear_inverse()` or a training-mode forward."""
         for f in self.flows:
             f.store_inverse()
+        prepare_all(self)
+        with torch.no_grad():
+            self._inv_cache = [flow_impl.flow_scalars(self.flows[3 * b].logs, self.flows[3 * b + 1].weight)
+                               for b in range(self.n_blocks)]
+
+    def clear_inverse(self):
+        self._inv_cache = None
 
     def forward(self, x, x_mask, g=None, emo=None, pitch=None, energy=None, reverse=False, prepared=False):
         """x: [b, 80, t] (t even after the caller's preprocess, models.py:1248-1253; an odd trailing
@@ -48,8 +58,11 @@ class FlowSpecDecoder(nn.Module):
             raise ValueError("pitch / energy conditioning needs FlowSpecDecoder(with_prosody_wn=True)")
         pitch = pitch.unsqueeze(1) if (pitch is not None and pitch.dim() == 2) else pitch
         energy = energy.unsqueeze(1) if (energy is not None and energy.dim() == 2) else energy
-        if not prepared:
+        cached = reverse and self._inv_cache is not None
+        if not prepared and not cached:
             prepare_all(self)
+        if not reverse:
+            self._inv_cache = None               # parameters may move: the synthesis cache is stale
         wns = [self.flows[3 * b + 2].wn for b in range(self.n_blocks)]
         if reverse:                                  # inference direction (models.py:769-770,781-782): no log-det, no autograd
             with torch.no_grad():
@@ -60,45 +73,8 @@ class FlowSpecDecoder(nn.Module):
         seed = (self._step * 7919) & 0x7fffffff
         conds = list(_wn_cond_all(wns, g)) if g is not None else []
         affs = [a for a in (self._prosody_affine("wn_energy", energy), self._prosody_affine("wn_pitch", pitch)) if a is not None]
-        G = decoder_groups(x)
-        if G == 1:
-            runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed, energy, pitch)
-            z, logdet = _RowsFn.apply(runner, 2, x, *conds, *affs, *runner.params)
-            return z, logdet
-        # Utterances are independent through the decoder and its kernels are latency-bound at <= 1 workgroup per CU: run G
-        # interleaved utterance groups as G autograd nodes on G streams (parallel branches of the step's HIP graph; the
-        # backward of each node replays on its stream).  Their weight gradients go out group after group on the wgrad side
-        # stream, the first one writing and the others adding (WgradQueue(accumulate=...)).
-        dev = x.device
-        main = torch.cuda.current_stream(dev)
-        streams = _group_streams(dev, G)
-        self._wgrad_round = 0
-        self._group_main = main
-        self.__dict__.pop("_parked_wgrads", None)
-        lh = ops._HOST_LENGTHS.get("y")
-        B = x.shape[0]
-        parts = []
-        for gi in range(G):
-            sl = slice(gi, None, G)
-            st = main if gi == 0 else streams[gi]
-            if gi:
-                st.wait_stream(main)
-            if lh is not None:
-                ops._HOST_LENGTHS[f"y{gi}"] = list(lh[sl])
-            with torch.cuda.stream(st):
-                runner = _DecoderRunner(self, x_mask[sl].contiguous(), g is not None, self.training, seed + 1009 * gi,
-                                        None if energy is None else energy[sl].contiguous(),
-                                        None if pitch is None else pitch[sl].contiguous(), ctx_key=f"y{gi}", group=gi, n_groups=G)
-                zg, ldg = _RowsFn.apply(runner, 2, x[sl].contiguous(), *[c[sl].contiguous() for c in conds], *affs, *runner.params)
-            parts.append((zg, ldg))
-        for gi in range(1, G):
-            main.wait_stream(streams[gi])
-            parts[gi][0].record_stream(main); parts[gi][1].record_stream(main)
-        z = torch.empty((B,) + tuple(parts[0][0].shape[1:]), dtype=parts[0][0].dtype, device=dev)
-        logdet = torch.empty(B, dtype=parts[0][1].dtype, device=dev)
-        for gi, (zg, ldg) in enumerate(parts):
-            z[gi::G] = zg
-            logdet[gi::G] = ldg
+        runner = _DecoderRunner(self, x_mask, g is not None, self.training, seed, energy, pitch)
+        z, logdet = _RowsFn.apply(runner, 2, x, *conds, *affs, *runner.params)
         return z, logdet
 
     def _prosody_affine(self, which, contour):
@@ -114,62 +90,16 @@ class FlowSpecDecoder(nn.Module):
         return torch.stack([w, torch.stack([c.bias for c in cls])], dim=1)
 
 
-DECODER_GROUPS = int(os.environ.get("GT_DECODER_GROUPS", "1"))
-_GROUP_STREAMS = {}
-
-
-def decoder_groups(x):
-    """number of concurrent utterance groups the decoder forward / backward is split into for this input"""
-    G = DECODER_GROUPS
-    return G if (G > 1 and x.is_cuda and x.shape[0] >= 2 * G) else 1
-
-
-def _group_streams(dev, G):
-    lst = _GROUP_STREAMS.setdefault(str(dev), [None])
-    while len(lst) < G:
-        lst.append(torch.cuda.Stream(device=dev))
-    return lst
-
-
-class _Site:
-    pass
-
-
-def _group_site(dec, gi):
-    sites = dec.__dict__.setdefault("_group_sites", {})
-    if gi not in sites:
-        sites[gi] = _Site()
-    return sites[gi]
-
-
 class _DecoderRunner:
-    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None, ctx_key="y", group=None, n_groups=1):
+    def __init__(self, dec, x_mask, has_cond, train, seed, energy=None, pitch=None):
         self.dec, self.has_cond, self.train, self.seed = dec, has_cond, train, seed
         self.x_mask = x_mask
-        self.ctx_key, self.group, self.n_groups = ctx_key, group, n_groups   # utterance group of models.DECODER_GROUPS (None: the whole batch)
+        self.cfg = getattr(dec, "rows_cfg", None) or ops.DEFAULT_ROWS        # the owning FlowGenerator's RowsConfig
         self.energy, self.pitch = energy, pitch                                   # [b,1,t] contours (no gradient) or None
         self.params = [p for n, p in dec.named_parameters() if ".wn.cond_layer." not in n and "cond_layer1" not in n]
 
-    def _contour_rows(self, rc, c, B, T):
-        """[b,1,t] contour -> [R, 2] fp32 rows (column = frame parity), the squeeze of modules.py:353-362 for one channel."""
-        if c is None:
-            return None
-        L = _lib.lib()
-        cc = c.detach().float().reshape(B, 1, -1)[:, :, :T].contiguous()
-        assert cc.shape[2] == T, "pitch / energy must cover the mel frames"
-        rows = torch.empty(rc.R, 2, dtype=torch.float32, device=cc.device)
-        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(cc), _lib.ptr(rows), _lib.ptr(rc.lengths), B, 1, T, rc.Tp, _lib.ptr(rc.row0),
-                                         _lib.current_stream(cc.device)), "gt_squeeze_rows_f32")
-        return rows
-
-    @staticmethod
-    def _cond_rows(sig, aff_b):
-        """per-frame conditioning rows [R, 2*O] = w * contour + b, laid out like the squeezed cond_layer1 output
-        (channel = parity * O + c); layer i of the WNP reads columns [2*H*i, 2*H*(i+1))."""
-        if sig is None:
-            return None
-        w, b = aff_b[0].detach().float(), aff_b[1].detach().float()
-        return torch.addcmul(b[None, None, :], sig[:, :, None], w[None, None, :]).reshape(sig.shape[0], -1)
+    _contour_rows = staticmethod(lambda rc, c, B, T: flow_impl.contour_rows(rc, c, B, T))
+    _cond_rows = staticmethod(flow_impl.cond_rows)
 
     def _split_inputs(self, rest):
         nb = self.dec.n_blocks
@@ -191,7 +121,7 @@ class _DecoderRunner:
         dev = x.device
         T2 = T // 2
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)          # mask[:, :, 1::2] (commons.py:348)
-        rc = ops.make_ctx(len_sq, T2, self.ctx_key, div=2)
+        rc = ops.make_ctx(len_sq, T2, "y", div=2, cfg=self.cfg)
         xin = x.detach().float().contiguous()
         rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
@@ -202,6 +132,9 @@ class _DecoderRunner:
         cur = rows
         for b in range(nb):
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+            if not an.initialized:                                    # data-dependent init, once (modules.py:588-590)
+                assert not torch.cuda.is_current_stream_capturing(), "run the DDI batch before capturing the step"
+                flow_impl.actnorm_ddi(rc, cur, an)
             y1, x0, s1 = flow_impl.actnorm_invconv_fwd(rc, cur, an.logs, an.bias, ic.weight, logdet)
             cur, s2 = flow_impl.coupling_fwd(rc, cb, y1, x0, conds[b], logdet, self.train, self.seed + 16 * b,
                                              econd=self._cond_rows(esig, None if eaff is None else eaff[b]),
@@ -219,7 +152,7 @@ class _DecoderRunner:
         dev = z.device
         T2 = T // 2
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)
-        rc = ops.make_ctx(len_sq, T2, self.ctx_key, div=2)
+        rc = ops.make_ctx(len_sq, T2, "y", div=2, cfg=self.cfg)
         zin = z.float().contiguous()
         cur = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
@@ -231,7 +164,8 @@ class _DecoderRunner:
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
             cur = flow_impl.coupling_rev(rc, cb, cur, x0, conds[b], econd=self._cond_rows(esig, None if eaff is None else eaff[b]),
                                          pcond=self._cond_rows(psig, None if paff is None else paff[b]))
-            cur, x0 = flow_impl.actnorm_invconv_rev(rc, cur, an.logs, an.bias, ic.weight, want_x0=b > 0)
+            cur, x0 = flow_impl.actnorm_invconv_rev(rc, cur, an.logs, an.bias, ic.weight, want_x0=b > 0,
+                                                    scal=None if dec._inv_cache is None else dec._inv_cache[b])
         x = torch.empty(B, C, T2 * 2, dtype=torch.float32, device=dev)
         _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(x), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
         return x.to(z.dtype)
@@ -257,44 +191,25 @@ class _DecoderRunner:
         deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None
         dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None
         cur = drows
-        # data-gradient chain now; the weight gradients of every `chunk` blocks go out as one batch (wgrad.ASYNC: on a
-        # side stream, beside the rest of the chain)
-        chunk = int(os.environ.get("GT_WGRAD_CHUNK", "12"))
-        site, acc, side, hand_over = dec, False, False, True
-        if self.group is not None:
-            flat = hasattr(self.params[0], "_gt_flat_grad")
-            dec._wgrad_round += 1
-            last = dec._wgrad_round == self.n_groups
-            # every group's kernels write the SAME flat slices: autograd must see each parameter's gradient once (from the
-            # group whose backward runs last), not G aliases of one buffer that it would add to each other
-            hand_over = (not flat) or dec._wgrad_round == self.n_groups
-            site = _group_site(dec, self.group)
-            chunk = nb
-        for b1 in range(nb, 0, -chunk):
-            b0 = max(0, b1 - chunk)
-            q = wgrad.WgradQueue(dev, site=dec.flows[3 * b0 + 2] if chunk < nb else site)
-            if self.group is not None and flat and not last:
-                # the groups write the SAME flat gradient slices: park this group's batch; the last group of the step's
-                # backward flushes its own (writing) and then the parked ones (adding), all on its stream — no extra stream
-                q.defer_to = dec.__dict__.setdefault("_parked_wgrads", [])
-            with q:
-                for b in reversed(range(b0, b1)):
-                    an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
-                    s1, s2 = saved[b]
-                    if esig is None and psig is None:
-                        cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
-                    else:
-                        cur, g2, dconds[b], dpros = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond,
-                                                                           econd=esig is not None, pcond=psig is not None)
-                        # cond = w * contour + b per (frame, parity, channel): d w = sum dcond * contour, d b = sum dcond
-                        for dc, sig, dst in ((dpros[0], esig, deaff), (dpros[1], psig, dpaff)):
-                            if dc is not None:
-                                d3 = dc.view(rc.R, 2, O)
-                                dst[b, 0] = (d3 * sig[:, :, None]).sum((0, 1))
-                                dst[b, 1] = d3.sum((0, 1))
-                    grads.update(g2)
-                    cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
-                    grads.update(g1)
+        # data-gradient chain now; ALL weight gradients of the decoder go out as one batch when the block ends
+        with wgrad.WgradQueue(dev, site=dec):
+            for b in reversed(range(nb)):
+                an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+                s1, s2 = saved[b]
+                if esig is None and psig is None:
+                    cur, g2, dconds[b] = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond)
+                else:
+                    cur, g2, dconds[b], dpros = flow_impl.coupling_bwd(rc, cb, s2, cur, dlogdet, self.has_cond,
+                                                                       econd=esig is not None, pcond=psig is not None)
+                    # cond = w * contour + b per (frame, parity, channel): d w = sum dcond * contour, d b = sum dcond
+                    for dc, sig, dst in ((dpros[0], esig, deaff), (dpros[1], psig, dpaff)):
+                        if dc is not None:
+                            d3 = dc.view(rc.R, 2, O)
+                            dst[b, 0] = (d3 * sig[:, :, None]).sum((0, 1))
+                            dst[b, 1] = d3.sum((0, 1))
+                grads.update(g2)
+                cur, g1 = flow_impl.actnorm_invconv_bwd(rc, s1, cur, dlogdet, an.logs, an.bias, ic.weight)
+                grads.update(g1)
         dx = torch.zeros(B, C, T, dtype=torch.float32, device=dev) if T != T2 * 2 else torch.empty(B, C, T, dtype=torch.float32, device=dev)
         if T == T2 * 2:
             _lib.check(L.gt_unsqueeze_rows_f32(_lib.ptr(cur), _lib.ptr(dx), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_unsqueeze_rows_f32")
@@ -306,24 +221,7 @@ class _DecoderRunner:
         if self.has_cond:
             out += dconds
         out += [d for d in (deaff, dpaff) if d is not None]
-        if self.group is not None and dec._wgrad_round == self.n_groups:
-            # last group of the step's backward (the others are already enqueued on their streams): tie them to this
-            # stream, which autograd joins with its caller through the parameter gradients handed over below
-            cur = torch.cuda.current_stream(dev)
-            for st in [dec._group_main] + _group_streams(dev, self.n_groups)[1:]:
-                if st is not None and st != cur:
-                    cur.wait_stream(st)
-            for pq in dec.__dict__.pop("_parked_wgrads", []):          # the other groups' weight gradients, added to ours
-                for _, _, parts, dv, dg, db in pq.items:
-                    for x_, dy_, _, _ in parts:
-                        x_.record_stream(cur); dy_.record_stream(cur)
-                pq.defer_to, pq.accumulate = None, True
-                pq.flush()
-        if hand_over:
-            return out + [grads.get(p) for p in self.params]
-        flat_store = self.params[0]._gt_flat_grad[0].untyped_storage().data_ptr()
-        keep = lambda t: t if (t is not None and t.untyped_storage().data_ptr() != flat_store) else None   # noqa: E731
-        return out + [keep(grads.get(p)) for p in self.params]
+        return out + [grads.get(p) for p in self.params]
 
 
 from .text_models import DurationPredictor, FlowGenerator, TextEncoder, mle_loss  # noqa: E402,F401

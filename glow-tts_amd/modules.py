@@ -239,6 +239,8 @@ class ActNorm(nn.Module):
         pass
 
     def set_ddi(self, ddi):
+        """modules.py:604-605: the next forward (of the owning FlowSpecDecoder) sets logs / bias from the masked batch
+        statistics of this layer's input (ActNorm.initialize, modules.py:607-619 -> gt_actnorm_ddi), once."""
         self.initialized = not ddi
 
 
@@ -255,6 +257,7 @@ class InvConvNear(nn.Module):
         self.weight = nn.Parameter(w_init)
 
     def store_inverse(self):
+        """modules.py:667-668 (the kernels take W^-T from the cached flow scalars of FlowSpecDecoder.store_inverse)."""
         self.weight_inv = torch.inverse(self.weight.float()).to(dtype=self.weight.dtype)
 
 

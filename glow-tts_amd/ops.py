@@ -110,10 +110,19 @@ def zeros_small(shape, dtype, device):
     return a["buf"][off:off + nbytes].view(dtype)[:n].view(shape)
 
 
-_PREBUILT = {}          # "x" / "y" -> ragged RowsCtx the next forward must use (train.Trainer, around capture / replay)
-_HOST_LENGTHS = {}      # "x" / "y" -> list of ints for the batch in flight (set by FlowGenerator.forward)
-RAGGED = False          # train.Trainer turns it on: utterances are packed back to back (see RowsCtx)
-ROW_ROUND = 128         # ragged R is rounded up to this (row tiles of the GEMMs)
+class RowsConfig:
+    """Rows-layout state of ONE model (a FlowGenerator shares one object with its encoder and decoder; a stand-alone
+    module uses DEFAULT_ROWS = uniform layout).  Nothing here is process-global: two trainers, or an evaluation model
+    beside a trainer, do not see each other's settings."""
+
+    def __init__(self, ragged=False, row_round=128):
+        self.ragged = ragged        # utterances packed back to back (see RowsCtx); train.Trainer turns it on for its model
+        self.row_round = row_round  # ragged R is rounded up to this (row tiles of the GEMMs; 512 under HIP graphs)
+        self.host_lengths = {}      # "x" / "y" -> list of ints for the batch in flight (set by FlowGenerator.forward)
+        self.prebuilt = {}          # "x" / "y" -> ragged RowsCtx the next forward must use (train.Trainer, around capture / replay)
+
+
+DEFAULT_ROWS = RowsConfig()
 
 
 def rows_add_cond(rc, x, xb, cond, want_f32=True, want_bf16=True):
@@ -147,9 +156,6 @@ def cond_grad(rc, *row_grads):
     return tot
 
 
-ACCUM_LIVE = False      # True between GradBuckets.zero_accum() and the last gather() of a step
-
-
 def grad_accumulator(param, shape=None):
     """Zero-initialised fp32 buffer that a backward kernel accumulates a (non-conv) parameter's gradient into with
     atomics.  Under train.Trainer it is the parameter's own slice of the flat gradient buffer (train.GradBuckets lays
@@ -157,7 +163,8 @@ def grad_accumulator(param, shape=None):
     a zeros_small buffer."""
     shape = tuple(shape) if shape is not None else tuple(param.shape)
     fg = getattr(param, "_gt_flat_grad", None)
-    if ACCUM_LIVE and fg is not None and getattr(param, "_gt_prezeroed", False):
+    gb = getattr(param, "_gt_bucket", None)      # train.GradBuckets: live between its zero_accum() and the step's last gather()
+    if fg is not None and gb is not None and gb.accum_live and getattr(param, "_gt_prezeroed", False):
         buf, off = fg
         return buf[off:off + param.numel()].view(shape)
     return zeros_small(shape, torch.float32, param.device)
@@ -189,7 +196,7 @@ class RowsCtx:
             self.rowmask = self.rowmask2d.reshape(-1).contiguous()
             return
         assert len(lengths_host) == self.B
-        rnd = self.rnd = int(round_to or ROW_ROUND)
+        rnd = self.rnd = int(round_to or DEFAULT_ROWS.row_round)
         starts, self.R = self.row_starts(lengths_host, self.T, rnd)  # the last utterance owns the rounding rows
         # Tp only sizes grids: the upper bound keeps a captured graph valid for any batch with the same R
         self.Tp = self.T + 2 * HALO + rnd - 1
@@ -271,23 +278,19 @@ class RowsCtx:
         return out.transpose(1, 2).to(dtype or xr.dtype).contiguous()
 
 
-def make_ctx(lengths, T, which, div=1):
-    """RowsCtx for the text side (which = "x") or the mel side ("y", div = n_sqz): ragged when ops.RAGGED is on and
-    the host knows the lengths of the batch in flight (FlowGenerator.forward / train.Trainer put them in), else uniform."""
-    pre = _PREBUILT.get(which)
+def make_ctx(lengths, T, which, div=1, cfg=None):
+    """RowsCtx for the text side (which = "x") or the mel side ("y", div = n_sqz) under the model's RowsConfig: ragged
+    when cfg.ragged is on and the host knows the lengths of the batch in flight (FlowGenerator.forward / train.Trainer
+    put them in), else uniform."""
+    cfg = cfg or DEFAULT_ROWS
+    pre = cfg.prebuilt.get(which)
     if pre is not None:                                     # the captured-graph path: context built (and refreshed) outside
         assert pre.T == int(T) and pre.B == int(lengths.shape[0]), "prebuilt rows context does not fit this batch"
         return pre
-    lh = _HOST_LENGTHS.get(which) if RAGGED else None
+    lh = cfg.host_lengths.get(which) if cfg.ragged else None
     if lh is None:
         return RowsCtx(lengths, T)
-    return RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh])
-
-
-def _use_gemm2():
-    """The LDS-DMA ring kernel (conv_gemm2.hip) is opt-in: on the cfg2 shapes it ties with the register-staged kernel
-    (both are bound by the L2 -> LDS fill of the weight tiles), so the simpler one is the default."""
-    return os.environ.get("GT_CONV2", "0") == "1"
+    return RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh], round_to=cfg.row_round)
 
 
 class PackSlice:
@@ -298,16 +301,12 @@ class PackSlice:
         assert parent.taps == 1 and not parent.gate
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, 1, False
         self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
-        self.frag_f, self.frag_d = parent.frag_f, parent.frag_d
-        # forward image Pf[co][k0 + ci] / data-gradient image Pd[k0 + ci][co]; fragment order: whole (k/16) resp. (n/32) steps
+        # forward image Pf[co][k0 + ci] / data-gradient image Pd[k0 + ci][co]
         assert k0 % 32 == 0
-        self.fwd = parent.fwd[(k0 // 16) * 512:] if parent.frag_f else parent.fwd[k0:]
-        self.dgrad = parent.dgrad[(k0 // 32) * (parent.Kp_d // 16) * 512:] if parent.frag_d else parent.dgrad[k0 * parent.Kp_d:]
+        self.fwd = parent.fwd[k0:]
+        self.dgrad = parent.dgrad[k0 * parent.Kp_d:]
         self.inv_norm = None
-
-    @property
-    def flags(self):
-        return 2 * int(self.frag_f) + 4 * int(self.frag_d)
+        self.flags = 0
 
 
 class PackSliceN:
@@ -318,20 +317,15 @@ class PackSliceN:
         assert parent.taps == 1 and not parent.gate and n0 % 32 == 0
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, 1, False
         self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
-        self.frag_f, self.frag_d = parent.frag_f, parent.frag_d
         # forward image Pf[n0 + co][ci] / data-gradient image Pd[ci][n0 + co]
-        self.fwd = parent.fwd[(n0 // 32) * (parent.Kp_f // 16) * 512:] if parent.frag_f else parent.fwd[n0 * parent.Kp_f:]
-        self.dgrad = parent.dgrad[(n0 // 16) * 512:] if parent.frag_d else parent.dgrad[n0:]
+        self.fwd = parent.fwd[n0 * parent.Kp_f:]
+        self.dgrad = parent.dgrad[n0:]
         self.inv_norm = None
-
-    @property
-    def flags(self):
-        return 2 * int(self.frag_f) + 4 * int(self.frag_d)
+        self.flags = 0
 
 
 class PackedConv:
-    """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing.  Shapes the second
-    generation kernel takes (gt_conv_gemm2_supported) are packed in MFMA-fragment order, the rest row-major."""
+    """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing (row-major [taps][Np][Kp])."""
 
     def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False):
         """norm_only: only the per-row 1/||v|| is wanted (the weight itself is packed elsewhere, e.g. into the
@@ -340,23 +334,18 @@ class PackedConv:
         self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
         self.fwd = self.dgrad = None
         self.Kp_f = self.Np_f = self.Kp_d = self.Np_d = 0
-        self.frag_f = self.frag_d = False
         if norm_only:
             return
-        L = _lib.lib()
-        if _use_gemm2():
-            self.frag_f = bool(L.gt_conv_gemm2_supported(Cout, Cin, taps, int(gate)))
-            self.frag_d = bool(L.gt_conv_gemm2_supported(Cin, Cout, taps, 0))
         self.Kp_f = _round_up(Cin, 64)
-        self.Np_f = Cout if (gate or self.frag_f) else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
+        self.Np_f = Cout if gate else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
         self.Kp_d = _round_up(Cout, 64)
-        self.Np_d = Cin if self.frag_d else (_round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64))
+        self.Np_d = _round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64)
         self.fwd = torch.zeros(taps * self.Np_f * self.Kp_f, dtype=torch.int16, device=device)
         self.dgrad = torch.zeros(taps * self.Np_d * self.Kp_d, dtype=torch.int16, device=device)
 
     @property
     def flags(self):
-        return int(bool(self.gate)) + 2 * int(self.frag_f) + 4 * int(self.frag_d)
+        return int(bool(self.gate))
 
     def pack(self, v, g=None):
         """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""
@@ -373,9 +362,10 @@ class PackedConv:
 
 def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=None, out_f32=False,
               addend=None, relu=False, gate=False, gate_t=None, gate_s=None, drop_p=0.0, seed=0, R=None, tag=None,
-              cond_per_row=False):
+              cond_per_row=False, tile=0):
     """Y = epilogue(conv(x)) in the rows layout via gt_conv_gemm_bf16.  x: [R, >=Cin] bf16.
-    `out`/`addend` may be column-slices of wider row buffers (row stride taken from .stride(0))."""
+    `out`/`addend` may be column-slices of wider row buffers (row stride taken from .stride(0)).
+    tile: _lib.GT_TILE_* (0 = the library's choice; tests force every variant)."""
     L = _lib.lib()
     assert x.dtype == torch.bfloat16 and x.stride(1) == 1
     R = x.shape[0] if R is None else R
@@ -391,9 +381,8 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
         if gate_t is None:
             gate_t = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
             gate_s = torch.empty(R, n_out, device=x.device, dtype=torch.bfloat16)
-    fn = L.gt_conv_gemm2_bf16 if (pc.frag_d if dgrad else pc.frag_f) else L.gt_conv_gemm_bf16
     _ev = KERNEL_TIMER.start(tag)
-    rc = fn(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
+    rc = L.gt_conv_gemm_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(W), _lib.ptr(bias),
                              _lib.ptr(cond), 0 if cond is None else cond.stride(0),
                              _lib.ptr(ctx.rowmask) if mask else None,
                              _lib.ptr(out), out.stride(0), int(out_f32),
@@ -402,7 +391,7 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
                              _lib.ptr(seed_word(x.device)) if drop_p > 0 else None,
                              _lib.ptr(ctx.row0) if (cond is not None and not cond_per_row) else None,
-                             0 if cond_per_row else ctx.B, _lib.current_stream(x.device))
+                             0 if cond_per_row else ctx.B, int(tile), _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)
-    _lib.check(rc, "gt_conv_gemm2_bf16" if fn is L.gt_conv_gemm2_bf16 else "gt_conv_gemm_bf16")
+    _lib.check(rc, "gt_conv_gemm_bf16")
     return (out, gate_t, gate_s) if gate == 1 else out

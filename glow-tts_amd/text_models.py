@@ -144,7 +144,7 @@ class _TextEncoderRunner:
         dev = self.ids.device
         C = te.hidden_channels
         Ce = C - te.lin_channels                         # token-embedding channels; the language vector fills [Ce, C)
-        rc = ops.make_ctx(self.lengths.to(torch.int32), T, "x")
+        rc = ops.make_ctx(self.lengths.to(torch.int32), T, "x", cfg=getattr(te, "rows_cfg", None))
         x = torch.empty(rc.R, C, dtype=torch.float32, device=dev)
         xb = torch.empty(rc.R, C, dtype=torch.bfloat16, device=dev)
         emb = te.emb.weight.detach()
@@ -371,6 +371,9 @@ class FlowGenerator(nn.Module):
         # takes the raw pitch / energy contours.  Their LOSSES (l_pitch / l_energy) come from the stochastic predictors of
         # SURVEY §8 f1, which are not built: those two entries of the return tuple stay None.
         self._step = 0
+        # rows-layout state of THIS model (ragged packing, row rounding, the batch's host-side lengths): shared with the
+        # encoder / decoder runners; train.Trainer configures it — nothing process-global
+        self.rows_cfg = self.encoder.rows_cfg = self.decoder.rows_cfg = ops.RowsConfig()
 
     @torch.no_grad()
     def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0, g=None, l=None):
@@ -379,7 +382,7 @@ class FlowGenerator(nn.Module):
         Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)).  The output length is data
         dependent, so this reads the predicted lengths back from the device once."""
         self.prepare()
-        ops._HOST_LENGTHS.clear()
+        self.rows_cfg.host_lengths.clear()
         if l is not None:
             l = self.emb_l(l).unsqueeze(-1)
         xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
@@ -461,7 +464,7 @@ class FlowGenerator(nn.Module):
 
     def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None,
                 lengths_host=None, defer_encoder_backward=False):
-        """lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (ops.RAGGED) size its buffers
+        """lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (self.rows_cfg.ragged) size its buffers
         without a device sync (the data loader has them); without it they are read back from the device.
         defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
         decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
@@ -472,11 +475,11 @@ class FlowGenerator(nn.Module):
         assert (g is None) == (self.gin_channels == 0), "g [b, gin_channels, 1] is required exactly when gin_channels != 0"
         self.prepare()
         self._step += 1
-        if ops.RAGGED:
+        if self.rows_cfg.ragged:
             lh = lengths_host if lengths_host is not None else (x_lengths.tolist(), y_lengths.tolist())
-            ops._HOST_LENGTHS["x"], ops._HOST_LENGTHS["y"] = list(lh[0]), list(lh[1])
+            self.rows_cfg.host_lengths["x"], self.rows_cfg.host_lengths["y"] = list(lh[0]), list(lh[1])
         else:
-            ops._HOST_LENGTHS.clear()
+            self.rows_cfg.host_lengths.clear()
         # The text encoder (needs the text only) and the decoder (needs the mel only) are independent until the likelihood
         # lattice, and so are their backward passes: the encoder runs on its own stream (a parallel branch of the step's HIP
         # graph) — autograd replays each node's backward on the stream of its forward, so the encoder's backward overlaps

@@ -93,8 +93,10 @@ class GradBuckets:
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         cap = max(self.ALIGN, int(bucket_mb * (1 << 20) / 4) // self.ALIGN * self.ALIGN)
         self.buckets = [(s, min(s + cap, self.total)) for s in range(0, self.total, cap)]
+        self.accum_live = False       # True between zero_accum() and the last gather() of a step (ops.grad_accumulator)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             p._gt_flat_grad = (self.flat, o)
+            p._gt_bucket = self
             p._gt_prezeroed = i < self.n_accum
         self.accum_end = self.offsets[self.n_accum] if self.n_accum < len(self.params) else self.total
         self.on_gpu = dev.type == "cuda"
@@ -104,10 +106,9 @@ class GradBuckets:
     def zero_accum(self):
         """Start of a step: clear the accumulated-gradient region and let ops.grad_accumulator hand out its slices
         (until the step's last gather(); a model run outside a Trainer step never sees the flat buffer)."""
-        from . import ops
         if self.n_accum:
             self.flat[:self.accum_end].zero_()
-            ops.ACCUM_LIVE = True
+            self.accum_live = True
 
     def view(self, i):
         p, o = self.params[i], self.offsets[i]
@@ -121,8 +122,7 @@ class GradBuckets:
         dsts, srcs = [], []
         hi = len(self.params) if hi is None else hi
         if lo == 0:
-            from . import ops
-            ops.ACCUM_LIVE = False
+            self.accum_live = False
         for i in range(lo, hi):
             p = self.params[i]
             g = p.grad
@@ -231,25 +231,35 @@ CAPTURE_MODE = "thread_local"
 class Trainer:
     """zero_grad -> forward -> loss -> backward -> all-reduce -> grad-norm -> AdamW step.
 
-    graph=True captures the step (forward, MAS, backward, optimizer: ~1 k kernel launches) into HIP graphs after
-    three eager warm-up steps and replays them; the batch then lives in static buffers (`step` copies into them)
-    and dropout masks still change every replay because every dropout kernel mixes the device-resident seed word
-    (ops.seed_word) that the graph itself bumps.  One process alone: ONE graph.  Data-parallel (world > 1): the
-    backward is phased (everything but the text encoder, then the text encoder) and the step is three graphs —
-    forward + first backward | encoder backward | optimizer — with the RCCL all-reduces of the flat gradient buffer
-    launched between them: the decoder's slice (~90 % of the bytes) is on the wire while the encoder's backward runs
-    (collectives stay outside the captured regions).
+    graph=True captures the step (forward, MAS, backward, optimizer: several hundred kernel launches) into HIP graphs
+    and replays them; the batch then lives in static buffers (`step` copies into them) and dropout masks still change
+    every replay because every dropout kernel mixes the device-resident seed word (ops.seed_word) that the graph itself
+    bumps.  One process alone: ONE graph.  Data-parallel (world > 1): the backward is phased (everything but the text
+    encoder, then the text encoder) and the step is three graphs — forward + first backward | encoder backward |
+    optimizer — with the RCCL all-reduces of the flat gradient buffer launched between them: the decoder's slice (~90 %
+    of the bytes) is on the wire while the encoder's backward runs (collectives stay outside the captured regions).
 
-    Rows layout: ragged (ops.RAGGED, GT_RAGGED=0 turns it off) — every utterance owns exactly its own frames, so the
-    ~30 % of padded frames of an LJSpeech-shaped batch cost nothing.  The row count is rounded (128 eager, 512 under
-    graphs) and one graph is captured per distinct (text rows, mel rows) pair; a replay only refreshes the per-utterance
-    row offsets on the device.  `step(..., lengths_host=(x_lengths, y_lengths))` takes the lengths as Python ints (the
-    data loader has them); without it they are read back from the device (one sync per step)."""
+    A first-seen graph key is side-effect free: the eager warm-up steps that precede a capture run without
+    collectives, and parameters, Adam moments, the step word and the dropout seed word are restored afterwards — every
+    `step()` applies exactly ONE optimizer update and issues exactly one step's collectives, whether it captured or
+    replayed, so ranks that meet new keys on different steps stay in lock-step.  Batches are padded (zeros, masked by the
+    lengths) to multiples of (pad_tx, pad_ty) so that the number of distinct keys stays small, and at most `max_graphs`
+    captured keys are kept (least recently used goes first; ~2 GiB of graph memory each at cfg 2).
+
+    Rows layout: ragged (model.rows_cfg.ragged; GT_RAGGED=0 or ragged=False turns it off) — every utterance owns exactly
+    its own frames, so the ~30 % of padded frames of an LJSpeech-shaped batch cost nothing.  The row count is rounded
+    (128 eager, 512 under graphs) and one graph is captured per distinct (text rows, mel rows, padded shapes) key; a
+    replay only refreshes the per-utterance row offsets on the device.  `step(..., lengths_host=(x_lengths, y_lengths))`
+    takes the lengths as Python ints (the data loader has them); without it they are read back from the device (one
+    sync per step)."""
+
+    WARMUPS = 2
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
-                 split_graph=None):
+                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph forces the phased, several-graph form (default: world > 1)."""
+        from collections import OrderedDict
         self.model = model
         self.world = world
         self.graph_mode = bool(graph)
@@ -270,29 +280,45 @@ class Trainer:
         assert all(n.startswith("decoder.") for n in names[self.dec0:]), "decoder parameters must be the tail of the model"
         self.dec0_off = self.buckets.offsets[self.dec0] if self.dec0 < len(names) else self.buckets.total
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
-        from . import wgrad
-        # Weight-gradient batches on their own side stream (GT_WGRAD_ASYNC=1) paid while the step was one chain (12.7 ->
-        # 12.2 ms); now that the text encoder is a parallel branch of the graph, a third concurrent stream costs more in
-        # cross-queue dependencies than it hides (8.54 vs 7.24 ms/step): off by default.
-        wgrad.ASYNC = os.environ.get("GT_WGRAD_ASYNC", "0") != "0"
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
-        self._captured = {}                       # (text rows, mel rows) -> (graphs, static inputs, outputs, row contexts)
-        from . import ops
-        ops.RAGGED = os.environ.get("GT_RAGGED", "1") != "0"
-        self.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
+        self._captured = OrderedDict()            # key -> (graphs, static inputs, outputs, row contexts); LRU, <= max_graphs
+        self.max_graphs = int(max_graphs)
+        self.pad_tx, self.pad_ty = int(pad_tx), int(pad_ty)
+        assert self.pad_ty % 2 == 0
+        self.n_captures = 0
+        self.cfg = model.rows_cfg                 # this model's rows-layout state (ops.RowsConfig): nothing process-global
+        self.cfg.ragged = (os.environ.get("GT_RAGGED", "1") != "0") if ragged is None else bool(ragged)
+        self.cfg.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
 
-    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
-        from . import ops
+    @property
+    def adam_steps(self):
+        """Adam's step word on the device (equals n_steps: one update per step(); reads back, test / logging use)."""
+        return int(self.opt.hyper[5].item())
+
+    def _loss(self, outs):
+        """The reference's training loss (train_ms_emo_lang_pitch.py:295-306): mle + sum(l_length) [+ 0.5 l_pitch + 0.5 l_energy]."""
         m = self.model
-        ops.bump_seed(ids.device)
-        ops.arena_begin(ids.device)              # one fill for all the small zeroed accumulators of this step
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, l_pitch, l_energy), _, _ = outs
+        l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
+        loss = l_mle + torch.sum(l_length)
+        if l_pitch is not None:
+            loss = loss + 0.5 * l_pitch
+        if l_energy is not None:
+            loss = loss + 0.5 * l_energy
+        return loss, l_mle
+
+    def _begin(self, device):
+        from . import ops
+        ops.bump_seed(device)
+        ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
         self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
-        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {}))
-        l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
-        loss = l_mle + torch.sum(l_length)
+
+    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
+        self._begin(ids.device)
+        loss, l_mle = self._loss(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {})))
         loss.backward()
         self.buckets.gather()
         return loss.detach(), l_mle.detach()
@@ -306,17 +332,9 @@ class Trainer:
 
     def _phase1(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
         """forward + the backward of everything but the text encoder; the decoder's gradients are then in the flat buffer."""
-        from . import ops
-        m = self.model
-        ops.bump_seed(ids.device)
-        ops.arena_begin(ids.device)
-        self.buckets.zero_accum()
-        for p in self.buckets.params:
-            p.grad = None
-        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, _, _), _, _ = m(ids, t_x, y, t_y, lengths_host=lengths_host,
-                                                                           defer_encoder_backward=True, **(cond or {}))
-        l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
-        loss = l_mle + torch.sum(l_length)
+        self._begin(ids.device)
+        loss, l_mle = self._loss(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, defer_encoder_backward=True,
+                                            **(cond or {})))
         loss.backward()
         self.buckets.gather(self.dec0, None)
         return loss.detach(), l_mle.detach()
@@ -325,35 +343,47 @@ class Trainer:
         self.model.backward_encoder()
         self.buckets.gather(0, self.dec0)
 
-    def _step_impl(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
+    def _step_impl(self, ids, t_x, y, t_y, lengths_host=None, cond=None, collectives=True):
         if not self.split:
             out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host, cond)
-            self.buckets.allreduce()
+            if collectives:
+                self.buckets.allreduce()
         else:
             out = self._phase1(ids, t_x, y, t_y, lengths_host, cond)
-            self.buckets.allreduce(self.dec0_off, None, wait=False)      # on the wire while the encoder's backward runs
+            if collectives:
+                self.buckets.allreduce(self.dec0_off, None, wait=False)      # on the wire while the encoder's backward runs
             self._phase2()
-            self.buckets.allreduce(0, self.dec0_off, wait=True)
+            if collectives:
+                self.buckets.allreduce(0, self.dec0_off, wait=True)
         self._optim(ids.device)
         return out
+
+    # ---- capture ---------------------------------------------------------------------------------------------------
+    def _snapshot(self, device):
+        from . import ops
+        o = self.opt
+        return [(t, t.clone()) for t in (o.flat_p, o.m, o.v, o.hyper, ops.seed_word(device))]
+
+    @staticmethod
+    def _restore(snap):
+        for t, c in snap:
+            t.copy_(c)
 
     def _capture(self, ids, t_x, y, t_y, lh, cond=None):
         from . import ops
         static = [t.clone() for t in (ids, t_x, y, t_y)] + [{k: v.clone() for k, v in (cond or {}).items()}]
         ctxs = {}
-        if ops.RAGGED:                               # row contexts live outside the graph; replays refresh them in place
-            ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0])
-            for key, sl in self._y_groups(y):        # one context per concurrent utterance group of the decoder
-                ctxs[key] = ops.RowsCtx((static[3][sl] // 2).to(torch.int32), y.shape[2] // 2,
-                                        lengths_host=[int(v) // 2 for v in lh[1][sl]])
-        ops._PREBUILT.update(ctxs)
+        if self.cfg.ragged:                          # row contexts live outside the graph; replays refresh them in place
+            ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0], round_to=self.cfg.row_round)
+            ctxs["y"] = ops.RowsCtx((static[3] // 2).to(torch.int32), y.shape[2] // 2, lengths_host=[int(v) // 2 for v in lh[1]],
+                                    round_to=self.cfg.row_round)
+        self.cfg.prebuilt.update(ctxs)
         try:
             return self._capture_with(static, lh, ctxs)
         finally:
-            ops._PREBUILT.clear()
+            self.cfg.prebuilt.clear()
 
     def _capture_with(self, static, lh, ctxs):
-        from . import ops
         ids = static[0]
         cond = static[4]
         static = static[:4]
@@ -363,17 +393,30 @@ class Trainer:
         side = self._cap_stream
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            for _ in range(3):                       # warm-up: one-time attribute calls, scratch growth, optimizer state
-                self._step_impl(*static, lengths_host=lh, cond=cond)
+            # warm-up (one-time attribute calls, scratch growth, pinned staging pools) WITHOUT side effects: no
+            # collectives, and everything the optimizer / dropout state machine touched is put back afterwards
+            snap = self._snapshot(ids.device)
+            try:
+                for _ in range(self.WARMUPS):
+                    self._step_impl(*static, lengths_host=lh, cond=cond, collectives=False)
+            finally:
+                self._restore(snap)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and work they launched on another stream would stay outside the captured graph
         g1 = torch.cuda.CUDAGraph()
-        if not self.split:
+        if not self.split and self.world == 1:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
-                out = self._step_impl(*static, lengths_host=lh, cond=cond)
+                out = self._step_impl(*static, lengths_host=lh, cond=cond, collectives=False)
             graphs = (g1,)
+        elif not self.split:                         # one backward, then the whole buffer on the wire, then the optimizer
+            with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
+                out = self._fwd_bwd(*static, lengths_host=lh, cond=cond)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
+                self._optim(ids.device)
+            graphs = (g1, g2)
         else:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
                 out = self._phase1(*static, lengths_host=lh, cond=cond)
@@ -384,63 +427,90 @@ class Trainer:
             with torch.cuda.graph(g3, stream=side, pool=g1.pool(), capture_error_mode=CAPTURE_MODE):
                 self._optim(ids.device)
             graphs = (g1, g2, g3)
+        self.n_captures += 1
         return graphs, static + [cond], out, ctxs
 
-    @staticmethod
-    def _y_groups(y):
-        """[(context key, batch slice)] of the decoder's utterance groups (models.DECODER_GROUPS; one group: the batch)"""
-        G = models.decoder_groups(y)
-        return [("y", slice(None))] if G == 1 else [(f"y{gi}", slice(gi, None, G)) for gi in range(G)]
-
-    def _rows_key(self, ids, y, lh):
+    def _rows_key(self, Tx, Ty, lh):
         from . import ops
-        if not ops.RAGGED:
+        if not self.cfg.ragged:
             return (0, 0)
-        _, rx = ops.RowsCtx.row_starts(lh[0], ids.shape[1], ops.ROW_ROUND)
-        rys = tuple(ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1][sl]], y.shape[2] // 2, ops.ROW_ROUND)[1]
-                    for _, sl in self._y_groups(y))
-        return (rx,) + rys
+        _, rx = ops.RowsCtx.row_starts(lh[0], Tx, self.cfg.row_round)
+        _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], Ty // 2, self.cfg.row_round)
+        return (rx, ry)
 
-    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None, l=None):
-        """One optimizer step.  g [b, gin_channels, 1]: speaker vectors of the multi-speaker configs (cfg 4);
-        pitch / energy [b, 1, t_y]: raw contours of cfg 5 (FlowGenerator.forward normalises them, models.py:1054-1071);
-        l [b]: language ids (cfg 5)."""
-        cond = {k: v for k, v in (("g", g), ("pitch", pitch), ("energy", energy), ("l", l)) if v is not None}
-        from . import ops
-        ops.ROW_ROUND = self.row_round
-        if self.total_steps:
-            self.opt.set_schedule(*one_cycle(self.n_steps, self.total_steps, self.max_lr))
-        self.n_steps += 1
-        lh = lengths_host
-        if ops.RAGGED and lh is None:
-            lh = (t_x.tolist(), t_y.tolist())        # device sync: pass lengths_host to avoid it
+    @staticmethod
+    def _pad_time(t, T):
+        """zero-pad the last dim of t to T (the lengths mask the padding everywhere downstream)"""
+        if t.shape[-1] == T:
+            return t
+        out = t.new_zeros(t.shape[:-1] + (T,))
+        out[..., :t.shape[-1]] = t
+        return out
+
+    def precapture(self, batches):
+        """Capture the graphs of these batches up front ([(ids, t_x, y, t_y, lengths_host, cond kwargs)]) without taking
+        a training step: parameters / optimizer state are exactly what they were afterwards."""
         if not self.graph_mode:
-            return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
-        key = self._rows_key(ids, y, lh) + (tuple(ids.shape), tuple(y.shape))
+            return
+        for ids, t_x, y, t_y, lh, cond in batches:
+            self._graph_for(ids, t_x, y, t_y, lh, dict(cond or {}))
+
+    def _graph_for(self, ids, t_x, y, t_y, lh, cond):
+        """-> (captured entry or None if capture is impossible, padded inputs)"""
+        Tx = -(-ids.shape[1] // self.pad_tx) * self.pad_tx
+        Ty = -(-y.shape[2] // self.pad_ty) * self.pad_ty
+        ids, y = self._pad_time(ids, Tx), self._pad_time(y, Ty)
+        cond = {k: (self._pad_time(v, Ty) if k in ("pitch", "energy") else v) for k, v in cond.items()}
+        key = self._rows_key(Tx, Ty, lh) + (tuple(ids.shape), tuple(y.shape), tuple(sorted(cond)))
         cap = self._captured.get(key)
         if cap is None:
             try:
-                cap = self._captured[key] = self._capture(ids, t_x, y, t_y, lh, cond)
-            except Exception as e:                   # e.g. a collective that refuses capture: keep training, eagerly
+                cap = self._capture(ids, t_x, y, t_y, lh, cond)
+            except Exception as e:                   # e.g. an allocation the capture refuses: keep training, eagerly
                 import warnings
                 warnings.warn(f"HIP graph capture of the training step failed ({e!r}); continuing with eager launches")
                 self.graph_mode = False
                 # auxiliary streams that had joined the aborted capture may be left in capture state: start over with fresh ones
                 from . import text_models, wgrad
-                text_models._ENC_STREAMS.clear(); models._GROUP_STREAMS.clear(); wgrad._SIDE.clear(); wgrad._PENDING.clear()
-                ops._PREBUILT.clear()
-                return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
+                text_models._ENC_STREAMS.clear(); wgrad._SIDE.clear(); wgrad._PENDING.clear()
+                self.cfg.prebuilt.clear()
+                return None, (ids, y, cond)
+            self._captured[key] = cap
+            while len(self._captured) > self.max_graphs:      # least recently used key goes (its graphs free their pool)
+                self._captured.popitem(last=False)
+        else:
+            self._captured.move_to_end(key)
+        return cap, (ids, y, cond)
+
+    def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None, l=None, emo=None, emo_cartesian=None):
+        """One optimizer step.  g: speaker input ([b, gin_channels, 1] at the encoder boundary, or the raw [b, 512]
+        embedding when the model owns emb_g); pitch / energy [b, 1, t_y]: raw contours of cfg 5 (FlowGenerator.forward
+        normalises them, models.py:1054-1071); l [b]: language ids; emo [b] / emo_cartesian [b, 3]: cfg 5's emotion inputs."""
+        cond = {k: v for k, v in (("g", g), ("pitch", pitch), ("energy", energy), ("l", l), ("emo", emo),
+                                  ("emo_cartesian", emo_cartesian)) if v is not None}
+        if self.total_steps:
+            self.opt.set_schedule(*one_cycle(self.n_steps, self.total_steps, self.max_lr))
+        self.n_steps += 1
+        lh = lengths_host
+        if self.cfg.ragged and lh is None:
+            lh = (t_x.tolist(), t_y.tolist())        # device sync: pass lengths_host to avoid it
+        if not self.graph_mode:
+            return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
+        cap, (ids_p, y_p, cond_p) = self._graph_for(ids, t_x, y, t_y, lh, cond)
+        if cap is None:
+            return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
         graphs, static, out, ctxs = cap
-        for dst, src in list(zip(static[:4], (ids, t_x, y, t_y))) + [(static[4][k], v) for k, v in cond.items()]:
+        for dst, src in list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
         if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)
-            ok = ctxs["x"].refresh(static[1], lh[0])
-            for key, sl in self._y_groups(y):
-                ok = ok and ctxs[key].refresh(static[3][sl] // 2, [int(v) // 2 for v in lh[1][sl]])
+            ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
             assert ok, "row count of the batch does not match the captured graph"
-        graphs[0].replay()
-        if len(graphs) > 1:                          # collectives sit BETWEEN the graphs, never inside one
+        graphs[0].replay()                           # collectives sit BETWEEN the graphs, never inside one
+        if len(graphs) == 2:
+            self.buckets.allreduce()
+            graphs[1].replay()
+        elif len(graphs) == 3:
             self.buckets.allreduce(self.dec0_off, None, wait=False)      # decoder slice: overlaps the encoder's backward
             graphs[1].replay()
             self.buckets.allreduce(0, self.dec0_off, wait=True)

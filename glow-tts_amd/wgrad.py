@@ -27,11 +27,11 @@ assert JOB.itemsize == 64 and TILE.itemsize == 16 and WNB.itemsize == 96
 ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
 MAX_SLABS = 8
 
-# ASYNC (set by train.Trainer): flush() launches on a side stream, so the batched weight-gradient kernels of the
+# ASYNC (process-level dev knob GT_WGRAD_ASYNC=1, read once at import; off by default): flush() launches on a side stream, so the batched weight-gradient kernels of the
 # decoder overlap with whatever the backward does next (the rest of the data-gradient chain, the text encoder's
 # backward: mostly small kernels that leave CUs idle); join() makes the current stream wait for them and must run
 # before anything reads the gradients (train.GradBuckets.gather does).
-ASYNC = False
+ASYNC = os.environ.get("GT_WGRAD_ASYNC", "0") != "0"   # measured: a third concurrent stream costs more than it hides
 _SIDE = {}
 _PENDING = set()
 _ACTIVE = []            # stack of open queues
@@ -98,9 +98,8 @@ class WgradQueue:
         self.dev = device
         self.site = site            # object that owns the cached tables (the runner's module)
         self.items = []             # (conv, R, parts[(x, dy, co_begin, co_count)], dv, dg, db)
-        # accumulate: the gradients are ADDED to what their destinations hold (a second utterance group of the same step:
-        # models.DECODER_GROUPS); side_stream: flush on the wgrad side stream even without ASYNC, so that the flushes of
-        # concurrent groups are ordered among themselves
+        # accumulate: the gradients are ADDED to what their destinations hold; side_stream: flush on the wgrad side stream
+        # even without ASYNC
         self.accumulate, self.force_side = accumulate, side_stream
         self.defer_to = None        # a list: leaving the block parks the queue there instead of flushing (the owner flushes later)
 

@@ -119,27 +119,22 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
  * Dropout masks are a counter-based hash of (seed, row, col), replayed by the backward kernels.
  * seed_dev (here and in every entry point that takes it; may be NULL) is a device uint32 XOR-ed into the
  * host seed at kernel start: a captured HIP graph then draws fresh masks on every replay by bumping that word.
+ * tile: 0 = the library's choice from (R, Np, gate); tests force a variant with GT_TILE_64x64 … GT_TILE_256x64
+ * (rows x packed channels per workgroup; a variant the shape does not allow returns GT_E_INVAL).
  * Alignment: all pointers 16 B; N%4, Cin%8, ldx%8, ldy%4, Kp%64 == 0. */
+#define GT_TILE_AUTO 0
+#define GT_TILE_64x64 1
+#define GT_TILE_64x128 2
+#define GT_TILE_128x64 3
+#define GT_TILE_128x128 4
+#define GT_TILE_256x64 5
 int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
                       const float* cond, int ldc, const float* rowmask,
                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,
                       void* gate_t, void* gate_s, int ldts,
                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
-                      const int32_t* row0, int B, void* stream);
-
-/* Second-generation implicit GEMM (LDS-DMA rings for both operands, 128x192 / 128x96 / 64x192 / 64x96 tiles): same
- * arguments and semantics as gt_conv_gemm_bf16, for shapes gt_conv_gemm2_supported() accepts (Cin % 64 == 0,
- * N % 96 == 0, gate == 1 needs N % 192 == 0; Np == N, Kp == Cin).  Wp must be packed in MFMA-fragment order
- * (gt_pack_conv_weights flag 2 for the forward image, 4 for the data-gradient image). */
-int gt_conv_gemm2_supported(int N, int Cin, int taps, int gate);
-int gt_conv_gemm2_bf16(const void* X, int ldx, const void* Wp, const float* bias,
-                       const float* cond, int ldc, const float* rowmask,
-                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,
-                       void* gate_t, void* gate_s, int ldts,
-                       int R, int N, int Cin, int taps, int Tp, int Np, int Kp,
-                       int relu, int gate, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
-                      const int32_t* row0, int B, void* stream);
+                      const int32_t* row0, int B, int tile, void* stream);
 
 /* Weight preparation for gt_conv_gemm_bf16: w = g*v/||v|| when g != NULL (torch weight_norm,
  * dim 0: modules.py:127,132,141, attentions.py:103) else w = v; v is [Cout, Cin, taps] fp32.
@@ -147,7 +142,7 @@ int gt_conv_gemm2_bf16(const void* X, int ldx, const void* Wp, const float* bias
  * (roles swapped, taps flipped) and inv_norm[Cout] = 1/||v|| (optional; pack pointers may both be NULL when only
  * the norms are wanted).  Padding entries are not touched: zero the buffers once.
  * `gate` is a bit set: 1 = WaveNet-gate row interleave of the forward image ([32 tanh | 32 sigmoid] per 64 rows),
- * 2 = forward image in MFMA-fragment order [tap][n/32][k/16][lane = n%32 + 32*((k%16)/8)][k%8] for gt_conv_gemm2_bf16,
+ * 2 = forward image in MFMA-fragment order [tap][n/32][k/16][lane = n%32 + 32*((k%16)/8)][k%8] (one 1-KB MFMA A-fragment per (n/32, k/16): the fused WaveNet-layer kernels),
  * 4 = the same for the data-gradient image (Np, Kp multiples of 32 / 16 then). */
 int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
                          float* inv_norm, int Cout, int Cin, int taps,
@@ -210,6 +205,13 @@ int gt_squeeze_rows_f32(const float* y, float* rows, const int32_t* len_sq, int 
                         const int32_t* row0, void* stream);
 int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t* len_sq, int B, int C, int Ty, int Tp,
                           const int32_t* row0, void* stream);
+
+/* ActNorm data-dependent initialisation (ActNorm.initialize, modules.py:607-619) on the rows layout: from the rows x
+ * [R, C] fp32 the layer is about to see (rows outside an utterance are zero) and the valid frame counts len[B]:
+ *   m = sum x / sum len, v = sum x^2 / sum len - m^2, logs = -0.5 log(max(v, 1e-6)), bias = -m * exp(logs).
+ * workspace: 2*C doubles (cleared here).  One-off (first batch of a run with ddi=true, configs/base.json:13). */
+int gt_actnorm_ddi(const float* x, const int32_t* len, int B, int R, int C, double* workspace, float* logs, float* bias,
+                   void* stream);
 
 /* ActNorm (modules.py:584-599) + InvConvNear (modules.py:635-665) fused, rows layout fp32 [R,C]:
  *   y = (W_4x4 applied per group {2g,2g+1,C/2+2g,C/2+2g+1} to (bias + exp(logs)*x)) * mask

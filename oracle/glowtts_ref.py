@@ -80,6 +80,35 @@ def actnorm_fwd(P, pre, x, x_mask):
     return z, logs.sum() * x_len
 
 
+def actnorm_initialize(x, x_mask):
+    """modules.ActNorm.initialize (modules.py:607-619): data-dependent init from the masked batch statistics of the
+    layer's input -> (logs [1,C,1], bias [1,C,1])."""
+    denom = torch.sum(x_mask, [0, 2])
+    m = torch.sum(x * x_mask, [0, 2]) / denom
+    m_sq = torch.sum(x * x * x_mask, [0, 2]) / denom
+    v = m_sq - (m ** 2)
+    logs = 0.5 * torch.log(torch.clamp_min(v, 1e-6))
+    return (-logs).view(1, -1, 1), (-m * torch.exp(-logs)).view(1, -1, 1)
+
+
+def decoder_ddi(P, pre, x, x_mask, g=None, n_blocks=12, **kw):
+    """models.FlowSpecDecoder.forward on a decoder whose ActNorms were set_ddi(True) (the reference's init.py flow): every
+    ActNorm initialises from the input it sees (modules.py:588-590), block after block.  Returns a copy of P with the
+    initialised logs / bias, and the forward's (z, logdet) under them."""
+    P = dict(P)
+    n_sqz = kw.get("n_sqz", 2)
+    with torch.no_grad():
+        h, m = squeeze(x, x_mask, n_sqz)
+        for b in range(n_blocks):
+            P[pre + f"flows.{3 * b}.logs"], P[pre + f"flows.{3 * b}.bias"] = actnorm_initialize(h, m)
+            h, _ = actnorm_fwd(P, pre + f"flows.{3 * b}.", h, m)
+            h, _ = invconv_fwd(P, pre + f"flows.{3 * b + 1}.", h, m, kw.get("n_split", 4))
+            h, _ = coupling_fwd(P, pre + f"flows.{3 * b + 2}.", h, m, g, kw.get("n_layers", 4), kw.get("hidden", 192),
+                                kw.get("kernel_size", 5), kw.get("sigmoid_scale", False))
+    z, ld = decoder_fwd(P, pre, x, x_mask, g, n_blocks=n_blocks, **kw)
+    return P, z, ld
+
+
 def invconv_fwd(P, pre, x, x_mask, n_split=4):
     """modules.InvConvNear.forward (modules.py:635-665), restated as the grouped 4x4 mix it is
     (SURVEY App. A (ii)): for g < c/4, idx = {2g, 2g+1, c/2+2g, c/2+2g+1}: z[idx] = W @ x[idx]."""

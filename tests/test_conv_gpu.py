@@ -159,49 +159,70 @@ def test_gate_backward_epilogue_replays_forward_dropout(built):
     assert (nz_s & ~keep_s).float().mean().item() < 0.01 and (~nz_s & keep_s & keep_t).float().mean().item() < 0.02
 
 
-@pytest.mark.parametrize("Cin,Cout,k,tile", [(192, 384, 5, 0), (384, 192, 5, 0), (192, 192, 1, 0), (768, 192, 1, 0), (192, 768, 3, 0),
-                                             (192, 384, 5, 2), (192, 384, 1, 3), (192, 192, 3, 4)])
-def test_conv_gemm2_ring_kernel_matches_torch(built, monkeypatch, Cin, Cout, k, tile):
-    """The opt-in LDS-DMA ring kernel (gt_conv_gemm2_bf16, fragment-ordered weights) against torch conv1d, forward and
-    data gradient, on every tile shape (GT_CONV2_TILE 1..4; 0 = the kernel's own choice), ragged lengths."""
+TILES = {"64x64": 1, "64x128": 2, "128x64": 3, "128x128": 4, "256x64": 5}
+
+
+@pytest.mark.parametrize("Cin,Cout,k,tile,big", [
+    (192, 192, 1, "64x64", False), (192, 192, 1, "128x64", False), (192, 768, 3, "64x128", False), (192, 768, 3, "128x128", False),
+    (384, 192, 5, "128x64", False), (192, 160, 1, "128x64", False), (80, 192, 1, "64x64", False),
+    # R >= 11k rows: what the library's own choice runs at cfg 2's skip GEMM and at every larger batch
+    (192, 192, 1, "auto", True), (768, 192, 1, "auto", True), (192, 768, 3, "auto", True), (192, 192, 5, "128x64", True)])
+def test_conv_every_tile_variant_matches_torch(built, Cin, Cout, k, tile, big):
+    """Forward + data gradient of the implicit-GEMM conv with the tile FORCED through the C-ABI's `tile` argument (and the
+    library's own choice at R >= 11k rows, where it picks the 128-row tiles), ragged lengths, vs torch conv1d."""
     from glow_tts_amd import ops
-    monkeypatch.setenv("GT_CONV2", "1")
-    if tile:
-        monkeypatch.setenv("GT_CONV2_TILE", str(tile))
-    B, T = 3, 150
-    ctx, x, w, b = make(B, T, Cin, Cout, k, seed=Cin + Cout + k, lens=[150, 97, 1])
+    B, T = (30, 400) if big else (3, 150)
+    lens = ([400, 397, 1] + [380 - 3 * i for i in range(27)]) if big else [150, 97, 1]
+    ctx, x, w, b = make(B, T, Cin, Cout, k, seed=Cin + Cout + k, lens=lens)
+    assert not big or ctx.R >= 11000
     xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
     pc = ops.PackedConv(Cout, Cin, k).pack(wb.float())
-    assert pc.frag_f and pc.frag_d
+    t = TILES.get(tile, 0)
+    if t in (2, 4) and pc.Np_f % 128:
+        pytest.skip("128-column tiles need Np % 128 == 0")
     xr = ctx.to_rows(xb)
-    y = ops.conv_rows(xr, pc, ctx, bias=b, out_f32=True)
+    y = ops.conv_rows(xr, pc, ctx, bias=b, out_f32=True, tile=t)
     want = ref_conv(xb, wb, b, k // 2)
     scale = want.abs().max().item()
     got = ctx.from_rows(y)
     assert torch.allclose(got, want, atol=2e-3 * scale, rtol=0), (got - want).abs().max().item() / scale
-    # data gradient: conv of dY with the dgrad image == autograd's input gradient
     g = torch.Generator().manual_seed(1)
-    dy = (torch.randn(B, Cout, T, generator=g).to(dev()) * ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)).to(torch.bfloat16)
+    msk = ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)
+    dy = (torch.randn(B, Cout, T, generator=g).to(dev()) * msk).to(torch.bfloat16)
     xx = xb.float().requires_grad_(True)
     F.conv1d(xx, wb.float(), None, padding=k // 2).backward(dy.float())
-    dx = ctx.from_rows(ops.conv_rows(ctx.to_rows(dy), pc, ctx, dgrad=True, out_f32=True))
-    valid = ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1).bool().expand_as(dx)
+    td = t if (t not in (2, 4) or pc.Np_d % 128 == 0) else 0
+    dx = ctx.from_rows(ops.conv_rows(ctx.to_rows(dy), pc, ctx, dgrad=True, out_f32=True, tile=td))
+    valid = msk.bool().expand_as(dx)
     s2 = xx.grad.abs().max().item()
     assert torch.allclose(dx[valid], xx.grad[valid], atol=2e-3 * s2, rtol=0), (dx - xx.grad)[valid].abs().max().item() / s2
 
 
-def test_conv_gemm2_gate_matches_first_generation(built, monkeypatch):
-    """Gate epilogue of the ring kernel == the first-generation kernel on the same operands (same dropout seed)."""
+@pytest.mark.parametrize("tile,big", [("64x128", False), ("128x128", False), ("256x64", False), ("auto", True)])
+def test_gate_conv_every_tile_variant(built, tile, big):
+    """WaveNet gate epilogue (tanh * sigmoid, T / S saved) on every gate tile variant vs torch, incl. R >= 11k rows."""
     from glow_tts_amd import ops
-    B, T, H, k = 2, 96, 192, 5
-    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=3)
-    xr = ctx.to_rows(x.to(torch.bfloat16))
-    pc1 = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
-    a1, t1, s1 = ops.conv_rows(xr, pc1, ctx, bias=b, gate=True, drop_p=0.1, seed=77)
-    monkeypatch.setenv("GT_CONV2", "1")
-    pc2 = ops.PackedConv(2 * H, H, k, gate=True).pack(w)
-    assert pc2.frag_f and not pc1.frag_f
-    a2, t2, s2 = ops.conv_rows(xr, pc2, ctx, bias=b, gate=True, drop_p=0.1, seed=77)
+    H, k = 192, 5
+    B, T = (30, 400) if big else (2, 96)
+    lens = ([400, 397, 1] + [380 - 3 * i for i in range(27)]) if big else [96, 51]
+    ctx, x, w, b = make(B, T, H, 2 * H, k, seed=3, lens=lens)
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    pc = ops.PackedConv(2 * H, H, k, gate=True).pack(wb.float())
+    a, t_, s_ = ops.conv_rows(ctx.to_rows(xb), pc, ctx, bias=b, gate=True, tile=TILES.get(tile, 0))
+    pre = ref_conv(xb, wb, b, k // 2)
+    want = torch.tanh(pre[:, :H]) * torch.sigmoid(pre[:, H:])
     valid = ctx.rowmask.bool()
-    for u, v in ((a1, a2), (t1, t2), (s1, s2)):
-        assert torch.allclose(u.float()[valid], v.float()[valid], atol=1e-2, rtol=0)
+    for got, ref in ((a, want), (t_, torch.tanh(pre[:, :H])), (s_, torch.sigmoid(pre[:, H:]))):
+        assert torch.allclose(got.float()[valid], ctx.to_rows(ref)[valid], atol=1.2e-2, rtol=0)
+
+
+def test_conv_tile_argument_is_validated(built):
+    """A tile the shape does not allow is refused (GT_E_INVAL), not silently replaced."""
+    from glow_tts_amd import ops
+    ctx, x, w, b = make(2, 32, 192, 192, 1, seed=5)
+    pc = ops.PackedConv(192, 192, 1).pack(w)
+    xr = ctx.to_rows(x.to(torch.bfloat16))
+    with pytest.raises(RuntimeError, match="GT_E_INVAL"):
+        ops.conv_rows(xr, pc, ctx, tile=TILES["64x128"])        # Np = 192 is not a multiple of 128
+    with pytest.raises(RuntimeError, match="GT_E_INVAL"):
+        ops.conv_rows(xr, pc, ctx, tile=TILES["256x64"])        # gate-only variant

@@ -253,7 +253,9 @@ def test_decoder_pitch_energy_speaker_conditioning(built, ragged, pitch_only):
 
     dec = dec.to(dev())
     yd, gd = y.to(dev()).requires_grad_(True), spk.to(dev()).requires_grad_(True)
-    ops.RAGGED = ragged
+    dec.rows_cfg = ops.RowsConfig(ragged=ragged)      # a stand-alone decoder: its own rows-layout state
+    if ragged:
+        dec.rows_cfg.host_lengths["y"] = list(lens)
     try:
         zd, ldd = dec(yd, m.to(dev()), g=gd, pitch=pit.to(dev()), energy=None if ene is None else ene.to(dev()))
         assert relerr(zd.detach().cpu(), z.detach()) < 3e-2, relerr(zd.detach().cpu(), z.detach())
@@ -264,7 +266,7 @@ def test_decoder_pitch_energy_speaker_conditioning(built, ragged, pitch_only):
         xr, _ = dec(zrev.to(dev()), m.to(dev()), g=spk.to(dev()), pitch=pit.to(dev()),
                     energy=None if ene is None else ene.to(dev()), reverse=True)
     finally:
-        ops.RAGGED = False
+        dec.rows_cfg = ops.RowsConfig()
     assert relerr(yd.grad.cpu(), yy.grad) < 3e-2, relerr(yd.grad.cpu(), yy.grad)
     assert relerr(gd.grad.cpu(), gg.grad) < 6e-2, relerr(gd.grad.cpu(), gg.grad)
     for name, p in dec.named_parameters():
@@ -284,36 +286,138 @@ def test_decoder_pitch_energy_speaker_conditioning(built, ragged, pitch_only):
     assert relerr(xr.cpu(), want.detach()) < 3e-2
 
 
-@pytest.mark.parametrize("ragged", [False, True])
-def test_decoder_utterance_groups_match_the_single_chain(built, ragged):
-    """models.DECODER_GROUPS: the decoder run as 2 interleaved utterance groups on 2 streams (uneven: 3 + 2 utterances)
-    gives the same outputs and gradients as one chain over the batch (evaluation mode: dropout masks are indexed by row)."""
-    from glow_tts_amd import models, ops
-    B, T, lens = 5, 50, [50, 27, 12, 44, 31]
-    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05, gin_channels=256), "decoder.").eval().to(dev())
-    g = torch.Generator().manual_seed(31)
-    m = lens_mask(lens, T).to(dev())
-    y = (torch.randn(B, 80, T, generator=g)).to(dev()) * m
-    spk = torch.randn(B, 256, 1, generator=g).to(dev())
-    rz = torch.randn(B, 80, T, generator=g).to(dev()) * m; rl = (torch.randn(B, generator=g) * 0.1).to(dev())
-    res = []
-    ops.RAGGED = ragged
+def test_coupling_block_standalone_reverse_and_prosody(built):
+    """attentions.CouplingBlock as a stand-alone module (attentions.py:132-186): forward with g + pitch + energy incl. the
+    gradients of cond_layer1, reverse=True (attentions.py:178-180) and reverse(forward(x)) == x, vs the oracle."""
+    from glow_tts_amd import attentions
+    cb = fill_module(attentions.CouplingBlock(160, 192, 5, 1, 4, gin_channels=256, p_dropout=0.05, with_prosody_wn=True), "cb.").eval()
+    P = {k: v.clone().requires_grad_(True) for k, v in cpu_state(cb, "cb.").items()}
+    B, T = 2, 30
+    g = torch.Generator().manual_seed(18)
+    m = lens_mask([30, 11], T)
+    x = torch.randn(B, 160, T, generator=g) * m
+    spk = torch.randn(B, 256, 1, generator=g)
+    m2 = lens_mask([60, 22], 2 * T)
+    pit, ene = torch.randn(B, 1, 2 * T, generator=g) * m2, torch.randn(B, 1, 2 * T, generator=g).abs() * m2
+    xx = x.clone().requires_grad_(True)
+    z, ld = R.coupling_fwd(P, "cb.", xx, m, spk, pitch=pit, energy=ene)
+    rz = torch.randn(z.shape, generator=g) * m
+    ((z * rz).sum() + ld.sum() * 0.1).backward()
+    cb = cb.to(dev())
+    xd = x.to(dev()).requires_grad_(True)
+    zd, ldd = cb(xd, m.to(dev()), g=spk.to(dev()), pitch=pit.to(dev()), energy=ene.to(dev()))
+    assert relerr(zd.detach().cpu(), z.detach()) < 3e-2 and (ldd.detach().cpu() - ld.detach()).abs().max() < 0.5
+    ((zd * rz.to(dev())).sum() + ldd.sum() * 0.1).backward()
+    assert relerr(xd.grad.cpu(), xx.grad) < 3e-2
+    for name in ("wn_pitch.cond_layer1.weight_g", "wn_pitch.cond_layer1.bias", "wn_energy.cond_layer1.weight_g",
+                 "wn_energy.cond_layer1.bias", "wn_energy.in_layers.1.weight_v", "wn.cond_layer.bias"):
+        got, want = dict(cb.named_parameters())[name].grad, P["cb." + name].grad
+        assert got is not None and relerr(got.cpu(), want) < 6e-2, (name, relerr(got.cpu(), want))
+    with torch.no_grad():
+        xr, none = cb(zd.detach(), m.to(dev()), reverse=True, g=spk.to(dev()), pitch=pit.to(dev()), energy=ene.to(dev()))
+        want = R.coupling_rev({k: v.detach() for k, v in P.items()}, "cb.", z.detach(), m, spk, pitch=pit, energy=ene)
+    assert none is None
+    assert relerr(xr.cpu(), want) < 3e-2
+    assert relerr(xr.cpu(), x) < 3e-2                                   # reverse(forward(x)) == x
+    cb.store_inverse()                                                  # frozen images: same answer, no re-pack
+    with torch.no_grad():
+        xr2, _ = cb(zd.detach(), m.to(dev()), reverse=True, g=spk.to(dev()), pitch=pit.to(dev()), energy=ene.to(dev()))
+    assert torch.equal(xr, xr2)
+
+
+def test_actnorm_ddi_initialises_block_after_block(built):
+    """ActNorm data-dependent init (modules.py:588-590, 607-619; configs/base.json "ddi": true): set_ddi(True) on every
+    ActNorm, one forward — each layer takes logs / bias from the masked statistics of the input IT sees; later forwards
+    leave them alone.  vs the oracle's restatement (pinned by ddi_* in float_golden.npz)."""
+    from glow_tts_amd import models, modules
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 3, 4, p_dropout=0.05), "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    B, T, lens = 3, 44, [44, 30, 6]
+    m = lens_mask(lens, T)
+    y = torch.randn(B, 80, T, generator=torch.Generator().manual_seed(4)) * 1.7 + 0.3
+    y = y * m
+    P2, z, ld = R.decoder_ddi(P, "decoder.", y, m, n_blocks=3)
+    dec = dec.to(dev())
+    for f in dec.flows:
+        if isinstance(f, modules.ActNorm):
+            f.set_ddi(True)
+    with torch.no_grad():
+        zd, ldd = dec(y.to(dev()), m.to(dev()))
+    for b in range(3):
+        an = dec.flows[3 * b]
+        assert an.initialized
+        assert relerr(an.logs.detach().cpu(), P2[f"decoder.flows.{3 * b}.logs"]) < 2e-2, b      # bf16 GEMMs upstream of blocks > 0
+        assert relerr(an.bias.detach().cpu(), P2[f"decoder.flows.{3 * b}.bias"]) < 2e-2, b
+    assert relerr(dec.flows[0].logs.detach().cpu(), P2["decoder.flows.0.logs"]) < 1e-5           # block 0: fp32 only
+    assert relerr(zd.cpu(), z) < 3e-2
+    logs0 = dec.flows[3].logs.detach().clone()
+    with torch.no_grad():
+        dec(y.to(dev()) * 0.5, m.to(dev()))
+    assert torch.equal(dec.flows[3].logs.detach(), logs0)
+
+
+def test_store_inverse_caches_the_synthesis_state(built):
+    """FlowSpecDecoder.store_inverse (models.py:787-789): reverse calls after it reuse the packed weights and flow scalars
+    and give the same mel; a training-mode forward drops the cache."""
+    from glow_tts_amd import models, modules as gm
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 2, 4, p_dropout=0.05), "decoder.").eval().to(dev())
+    m = lens_mask([40, 22], 40).to(dev())
+    z = torch.randn(2, 80, 40, device=dev()) * m
+    x1, _ = dec(z, m, reverse=True)
+    dec.store_inverse()
+    assert dec._inv_cache is not None and len(dec._inv_cache) == 2
+    calls = []
+    orig = gm._PackPlan.run
+    gm._PackPlan.run = lambda self: (calls.append(1), orig(self))[1]
     try:
-        for G in (1, 2):
-            models.DECODER_GROUPS = G
-            for p in dec.parameters():
-                p.grad = None
-            yy, gg = y.clone().requires_grad_(True), spk.clone().requires_grad_(True)
-            z, ld = dec(yy, m, g=gg)
-            ((z * rz).sum() + (ld * rl).sum()).backward()
-            torch.cuda.synchronize()
-            res.append((z.detach().clone(), ld.detach().clone(), yy.grad.clone(), gg.grad.clone(),
-                        {n: p.grad.clone() for n, p in dec.named_parameters()}))
+        x2, _ = dec(z, m, reverse=True)
     finally:
-        models.DECODER_GROUPS = 1
-        ops.RAGGED = False
-    (z1, l1, gy1, gg1, p1), (z2, l2, gy2, gg2, p2) = res
-    assert torch.equal(z1, z2) and torch.allclose(l1, l2, rtol=1e-5, atol=1e-4)
-    assert relerr(gy2, gy1) < 1e-5 and relerr(gg2, gg1) < 1e-3
-    for n in p1:
-        assert relerr(p2[n], p1[n]) < 2e-3, (n, relerr(p2[n], p1[n]))         # slab / atomic summation order differs
+        gm._PackPlan.run = orig
+    assert not calls and torch.equal(x1, x2)
+    dec(z, m)
+    assert dec._inv_cache is None
+
+
+def _full_size_case(B, T_y, seed, n_check=3):
+    """The 12-block decoder forward + backward on a full BASELINE batch (ragged rows, R ~ 9-10 k), compared for a few
+    utterances against the oracle run on just those utterances (utterances are independent through the decoder)."""
+    from glow_tts_amd import models, ops
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 12, 4, p_dropout=0.05), "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    g = torch.Generator().manual_seed(seed)
+    lens = (torch.randint(T_y * 3 // 16, T_y // 2 + 1, (B,), generator=g) * 2).tolist()
+    lens[0] = T_y
+    m = lens_mask(lens, T_y)
+    y = torch.randn(B, 80, T_y, generator=g) * m
+    rz = torch.randn(B, 80, T_y, generator=g) * m
+    rl = torch.randn(B, generator=g) * 0.1
+    dec = dec.to(dev())
+    dec.rows_cfg = ops.RowsConfig(ragged=True, row_round=512)
+    dec.rows_cfg.host_lengths["y"] = list(lens)
+    yd = y.to(dev()).requires_grad_(True)
+    zd, ldd = dec(yd, m.to(dev()))
+    ((zd * rz.to(dev())).sum() + (ldd * rl.to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    R_rows = sum(v // 2 + 4 for v in lens)
+    for u in [0, B // 2, B - 1][:n_check]:
+        T = lens[u]
+        yy = y[u:u + 1, :, :T].clone().requires_grad_(True)
+        z, ld = R.decoder_fwd(P, "decoder.", yy, m[u:u + 1, :, :T], n_blocks=12)
+        ((z * rz[u:u + 1, :, :T]).sum() + (ld * rl[u:u + 1]).sum()).backward()
+        assert relerr(zd[u:u + 1, :, :T].detach().cpu(), z.detach()) < 3e-2, u
+        assert abs(ldd[u].item() - ld.item()) < 2e-3 * (T // 2) * 160 + 1e-2, (u, ldd[u].item(), ld.item())
+        assert relerr(yd.grad[u:u + 1, :, :T].cpu(), yy.grad) < 4e-2, (u, relerr(yd.grad[u:u + 1, :, :T].cpu(), yy.grad))
+        assert zd[u, :, T:].abs().max().item() == 0 if T < T_y else True
+    return R_rows
+
+
+def test_decoder_full_size_cfg2_batch(built):
+    """cfg 2 (configs/base.json): B = 32, T_y <= 800, 12 blocks, ragged R ~ 9 k rows — the shape the bench runs."""
+    rows = _full_size_case(32, 800, seed=1234)
+    assert rows > 8000
+
+
+def test_decoder_full_size_cfg3_batch(built):
+    """cfg 3 (configs/base_blank.json shapes): B = 32, T_y <= 872."""
+    rows = _full_size_case(32, 872, seed=77, n_check=2)
+    assert rows > 8000

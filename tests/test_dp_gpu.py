@@ -37,29 +37,58 @@ def _worker(rank, world, port, q):
             m.encoder.pre.p_dropout = 0.0
             return m
 
-        batch = train.synth_batch(4, 40, 120, rank, dev)          # a different batch per rank
-        lh = (batch[1].tolist(), batch[3].tolist())
-        out = {}
+        # a STREAM of batches, different lengths on every rank, so that the ranks meet new graph keys on different steps
+        # (rank 0: keys a b a a c, rank 1: keys d d e d e) — ADVICE r1: that used to de-synchronise the collectives
+        seeds = [[0, 3, 0, 0, 5], [11, 11, 13, 11, 13]][rank]
+        shapes = {0: (40, 120), 3: (40, 120), 5: (37, 100), 11: (44, 140), 13: (40, 120)}
+        stream = [train.synth_batch(4, *shapes[sd], sd, dev) for sd in seeds]
+        out, ncap = {}, None
         for name, graph, w in (("eager", False, world), ("graph", True, world), ("solo", False, 1)):
             m = make()
             tr = train.Trainer(m, world=w, graph=graph)
-            n = 1 if graph else 4                                  # a graph trainer's first call = 3 warm-ups + 1 replay
-            for _ in range(n):
-                loss, _ = tr.step(*batch, lengths_host=lh)
+            tr.cfg.row_round = 32
+            for b in stream:
+                loss, _ = tr.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))
             torch.cuda.synchronize()
+            assert tr.adam_steps == tr.n_steps == len(stream)       # one update per step(), captured or replayed
             if graph:
                 assert tr.graph_mode and len(next(iter(tr._captured.values()))[0]) == 3
+                ncap = tr.n_captures
             out[name] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
         gathered = [torch.zeros_like(out["eager"]) for _ in range(world)]
         dist.all_gather(gathered, out["eager"])
         same_across_ranks = all(torch.equal(gathered[0], g) for g in gathered)
+        gathered_g = [torch.zeros_like(out["graph"]) for _ in range(world)]
+        dist.all_gather(gathered_g, out["graph"])
+        same_across_ranks = same_across_ranks and all(torch.equal(gathered_g[0], g) for g in gathered_g)
         graph_vs_eager = (out["graph"] - out["eager"]).abs().max().item()
         vs_solo = (out["solo"] - out["eager"]).abs().max().item()
-        q.put((rank, same_across_ranks, graph_vs_eager, vs_solo, None))
+
+        # SURVEY §4 "distributed": world-2 gradients == single-rank gradients of the CONCATENATED batch.  The mean of the
+        # per-rank gradients is the concatenated batch's gradient when the ranks' loss normalisers (valid frames / tokens)
+        # agree, so both ranks take the same lengths here and different content.
+        ids, t_x, y, t_y = train.synth_batch(4, 40, 120, 0, dev)
+        gen = torch.Generator().manual_seed(100 + rank)
+        y_r = (y + 0.3 * torch.randn(y.shape, generator=gen).to(dev)) * (y != 0)
+        ids_r = ((ids + rank * 7) % 147 + 1) * (ids != 0)
+        lh = (t_x.tolist(), t_y.tolist())
+        m = make(); tr = train.Trainer(m, world=world, graph=False)
+        tr._fwd_bwd(ids_r, t_x, y_r, t_y, lh); tr.buckets.allreduce()
+        torch.cuda.synchronize()
+        g_dp = tr.buckets.flat.detach().clone()
+        parts_y = [torch.zeros_like(y_r) for _ in range(world)]; dist.all_gather(parts_y, y_r)
+        parts_i = [torch.zeros_like(ids_r) for _ in range(world)]; dist.all_gather(parts_i, ids_r)
+        m1 = make(); t1 = train.Trainer(m1, world=1, graph=False)
+        cat = lambda ps: torch.cat(ps, 0)                          # noqa: E731
+        t1._fwd_bwd(cat(parts_i), cat([t_x] * world), cat(parts_y), cat([t_y] * world), (lh[0] * world, lh[1] * world))
+        torch.cuda.synchronize()
+        g_cat = t1.buckets.flat.detach()
+        concat_err = ((g_dp - g_cat).double().norm() / g_cat.double().norm().clamp_min(1e-12)).item()
+        q.put((rank, same_across_ranks, graph_vs_eager, vs_solo, ncap, concat_err, None))
         dist.destroy_process_group()
     except Exception as e:                                         # surface the failure instead of a queue timeout
         import traceback
-        q.put((rank, False, -1.0, -1.0, traceback.format_exc()))
+        q.put((rank, False, -1.0, -1.0, 0, -1.0, traceback.format_exc()))
 
 
 def test_data_parallel_trainer_world2_on_one_gpu(built):
@@ -68,10 +97,12 @@ def test_data_parallel_trainer_world2_on_one_gpu(built):
     port = 29700 + (os.getpid() % 2000)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=600) for _ in range(2))
     [p.join(timeout=60) for p in procs]
-    for rank, same, gve, solo, err in res:
+    for rank, same, gve, solo, ncap, cerr, err in res:
         assert err is None, err
         assert same, "ranks ended with different parameters"
         assert gve < 5e-3, gve                       # three graphs + collectives between them == eager phased step
         assert solo > 1e-4, "the gradient exchange changed nothing"
+        assert ncap >= 2, ncap                       # several keys were captured mid-stream on every rank
+        assert 0 <= cerr < 2e-2, cerr                # world-2 mean gradient == gradient of the concatenated batch (bf16 GEMMs)

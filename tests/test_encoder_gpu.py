@@ -149,12 +149,12 @@ def test_train_forward_backward_with_language_and_speaker(built, ragged):
     spk = torch.randn(B, 256, 1, generator=g)
     lid = torch.tensor([2, 0, 1])
     gen = gen.to(dev())
-    ops.RAGGED = ragged
+    gen.rows_cfg.ragged = ragged
     try:
         (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
             gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=spk.to(dev()), l=lid.to(dev()))
     finally:
-        ops.RAGGED = False
+        gen.rows_cfg.ragged = False
     l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
     (l_mle + l_length.sum()).backward()
     lvec = torch.nn.functional.embedding(lid, P["emb_l.weight"]).unsqueeze(-1)
@@ -259,13 +259,13 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     ids = ids * (torch.arange(Tx)[None, :] < xl[:, None])
 
     gen = gen.to(dev())
-    ops.RAGGED = ragged
+    gen.rows_cfg.ragged = ragged
     try:
         (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, _, _), _, _ = \
             gen(ids.to(dev()), xl.to(dev()), y.to(dev()), yl.to(dev()), g=None if spk is None else spk.to(dev()),
                 pitch=None if pitch is None else pitch.to(dev()), energy=None if energy is None else energy.to(dev()))
     finally:
-        ops.RAGGED = False
+        gen.rows_cfg.ragged = False
     l_mle = models.mle_loss(z, z_m, z_logs, logdet, z_mask)
     loss = l_mle + l_length.sum()
     loss.backward()
