@@ -364,6 +364,205 @@ def duration_predictor_fwd(P, pre, x, x_mask, kernel_size=3, g=None, l=None):
     return x * x_mask
 
 
+# ----------------------------------------------------------------------------- stochastic predictors
+def layer_norm2(x, gamma, beta, eps=1e-5):
+    """modules.LayerNorm2 (modules.py:46-68): F.layer_norm over the channel dim, eps 1e-5."""
+    return F.layer_norm(x.transpose(1, -1), (x.shape[1],), gamma, beta, eps).transpose(1, -1)
+
+
+def dds_conv(P, pre, x, x_mask, g=None, kernel_size=3, num_layers=3):
+    """modules.DilatedDepthSeparableConv.forward (modules.py:718-735), eval mode (dropout off)."""
+    if g is not None:
+        x = x + g
+    for i in range(num_layers):
+        d = kernel_size ** i
+        pad = (kernel_size * d - d) // 2
+        y = F.conv1d(x * x_mask, P[pre + f"convs_sep.{i}.weight"], P[pre + f"convs_sep.{i}.bias"], padding=pad, dilation=d,
+                     groups=x.shape[1])
+        y = F.gelu(layer_norm2(y, P[pre + f"norms_1.{i}.gamma"], P[pre + f"norms_1.{i}.beta"]))
+        y = F.conv1d(y, P[pre + f"convs_1x1.{i}.weight"], P[pre + f"convs_1x1.{i}.bias"])
+        y = F.gelu(layer_norm2(y, P[pre + f"norms_2.{i}.gamma"], P[pre + f"norms_2.{i}.beta"]))
+        x = x + y
+    return x * x_mask
+
+
+def rq_spline_fwd(inputs, uw, uh, ud, tail_bound=5.0, min_bin=1e-3, min_der=1e-3):
+    """transforms.piecewise_rational_quadratic_transform(inverse=False, tails="linear") (transforms.py:12-202): inputs [...],
+    uw / uh [..., K], ud [..., K-1] -> (outputs, logabsdet).  Restated without boolean-mask scatter: the spline is
+    evaluated everywhere on clamped inputs and the linear tails are selected afterwards (same values inside and outside)."""
+    K = uw.shape[-1]
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    const = math.log(math.exp(1 - min_der) - 1)
+    ud = F.pad(ud, (1, 1), value=const)
+    left = bottom = -tail_bound
+    right = top = tail_bound
+    x = inputs.clamp(left, right)
+    widths = min_bin + (1 - min_bin * K) * F.softmax(uw, dim=-1)
+    cumw = F.pad(torch.cumsum(widths, -1), (1, 0)) * (right - left) + left
+    cumw = torch.cat([torch.full_like(cumw[..., :1], left), cumw[..., 1:-1], torch.full_like(cumw[..., :1], right)], -1)
+    widths = cumw[..., 1:] - cumw[..., :-1]
+    der = min_der + F.softplus(ud)
+    heights = min_bin + (1 - min_bin * K) * F.softmax(uh, dim=-1)
+    cumh = F.pad(torch.cumsum(heights, -1), (1, 0)) * (top - bottom) + bottom
+    cumh = torch.cat([torch.full_like(cumh[..., :1], bottom), cumh[..., 1:-1], torch.full_like(cumh[..., :1], top)], -1)
+    heights = cumh[..., 1:] - cumh[..., :-1]
+    loc = cumw.detach().clone(); loc[..., -1] += 1e-6                          # transforms.searchsorted (:46-48)
+    idx = (torch.sum(x[..., None] >= loc, -1) - 1).clamp(0, K - 1)[..., None]
+    in_cw, in_w = cumw.gather(-1, idx)[..., 0], widths.gather(-1, idx)[..., 0]
+    in_ch, in_h = cumh.gather(-1, idx)[..., 0], heights.gather(-1, idx)[..., 0]
+    delta = (heights / widths).gather(-1, idx)[..., 0]
+    d0, d1 = der.gather(-1, idx)[..., 0], der[..., 1:].gather(-1, idx)[..., 0]
+    theta = (x - in_cw) / in_w
+    t1 = theta * (1 - theta)
+    num = in_h * (delta * theta.pow(2) + d0 * t1)
+    den = delta + (d0 + d1 - 2 * delta) * t1
+    out = in_ch + num / den
+    dnum = delta.pow(2) * (d1 * theta.pow(2) + 2 * delta * t1 + d0 * (1 - theta).pow(2))
+    lad = torch.log(dnum) - 2 * torch.log(den)
+    return torch.where(inside, out, inputs), torch.where(inside, lad, torch.zeros_like(lad))
+
+
+def rq_spline_inv(inputs, uw, uh, ud, tail_bound=5.0, min_bin=1e-3, min_der=1e-3):
+    """the inverse=True branch of the same transform (transforms.py:152-180) -> outputs only (synthesis)."""
+    K = uw.shape[-1]
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    const = math.log(math.exp(1 - min_der) - 1)
+    ud = F.pad(ud, (1, 1), value=const)
+    lo, hi = -tail_bound, tail_bound
+    y = inputs.clamp(lo, hi)
+    widths = min_bin + (1 - min_bin * K) * F.softmax(uw, dim=-1)
+    cumw = F.pad(torch.cumsum(widths, -1), (1, 0)) * (hi - lo) + lo
+    cumw[..., 0] = lo; cumw[..., -1] = hi
+    widths = cumw[..., 1:] - cumw[..., :-1]
+    der = min_der + F.softplus(ud)
+    heights = min_bin + (1 - min_bin * K) * F.softmax(uh, dim=-1)
+    cumh = F.pad(torch.cumsum(heights, -1), (1, 0)) * (hi - lo) + lo
+    cumh[..., 0] = lo; cumh[..., -1] = hi
+    heights = cumh[..., 1:] - cumh[..., :-1]
+    loc = cumh.clone(); loc[..., -1] += 1e-6
+    idx = (torch.sum(y[..., None] >= loc, -1) - 1).clamp(0, K - 1)[..., None]
+    in_cw, in_w = cumw.gather(-1, idx)[..., 0], widths.gather(-1, idx)[..., 0]
+    in_ch, in_h = cumh.gather(-1, idx)[..., 0], heights.gather(-1, idx)[..., 0]
+    delta = (heights / widths).gather(-1, idx)[..., 0]
+    d0, d1 = der.gather(-1, idx)[..., 0], der[..., 1:].gather(-1, idx)[..., 0]
+    a = (y - in_ch) * (d0 + d1 - 2 * delta) + in_h * (delta - d0)
+    b = in_h * d0 - (y - in_ch) * (d0 + d1 - 2 * delta)
+    c = -delta * (y - in_ch)
+    root = (2 * c) / (-b - torch.sqrt(b.pow(2) - 4 * a * c))
+    return torch.where(inside, root * in_w + in_cw, inputs)
+
+
+def conv_flow(P, pre, x, x_mask, g, reverse=False, hidden=192, num_bins=10, tail_bound=5.0):
+    """modules.ConvFlow.forward (modules.py:792-819), in_channels = 2."""
+    x0, x1 = x[:, :1], x[:, 1:]
+    h = F.conv1d(x0, P[pre + "pre.weight"], P[pre + "pre.bias"])
+    h = dds_conv(P, pre + "convs.", h, x_mask, g=g)
+    h = F.conv1d(h, P[pre + "proj.weight"], P[pre + "proj.bias"]) * x_mask
+    b, c, t = x0.shape
+    h = h.reshape(b, c, -1, t).permute(0, 1, 3, 2)
+    uw = h[..., :num_bins] / math.sqrt(hidden)
+    uh = h[..., num_bins:2 * num_bins] / math.sqrt(hidden)
+    ud = h[..., 2 * num_bins:]
+    if reverse:
+        x1 = rq_spline_inv(x1, uw, uh, ud, tail_bound)
+        return torch.cat([x0, x1], 1) * x_mask
+    x1, lad = rq_spline_fwd(x1, uw, uh, ud, tail_bound)
+    return torch.cat([x0, x1], 1) * x_mask, torch.sum(lad * x_mask, [1, 2])
+
+
+def elementwise_affine(P, pre, x, x_mask, reverse=False):
+    """modules.ElementwiseAffine.forward (modules.py:750-756)."""
+    if reverse:
+        return (x - P[pre + "translation"]) * torch.exp(-P[pre + "log_scale"]) * x_mask
+    y = (x * torch.exp(P[pre + "log_scale"]) + P[pre + "translation"]) * x_mask
+    return y, torch.sum(P[pre + "log_scale"] * x_mask, [1, 2])
+
+
+def _flow_stack(P, pre, z, x_mask, g, n_flows=4):
+    """flows[0] = ElementwiseAffine, flows[1:] = ConvFlow, each ConvFlow followed by a channel flip (models.py:314-318)"""
+    logdet_tot = 0
+    for idx in range(n_flows + 1):
+        if idx == 0:
+            z, ld = elementwise_affine(P, pre + "0.", z, x_mask)
+        else:
+            z, ld = conv_flow(P, pre + f"{idx}.", z, x_mask, g)
+            z = torch.flip(z, [1])
+        logdet_tot = logdet_tot + ld
+    return z, logdet_tot
+
+
+def _predictor_cond(P, pre, x, x_mask, g=None, l=None):
+    """pre -> (+ cond(g)) (+ cond_lang(l)) -> convs -> proj * mask (models.py:262-278, 365-377): the text-side condition"""
+    x = F.conv1d(x.detach(), P[pre + "pre.weight"], P[pre + "pre.bias"])
+    if g is not None:
+        x = x + F.conv1d(g.detach(), P[pre + "cond.weight"], P[pre + "cond.bias"])
+    if l is not None:
+        x = x + F.conv1d(l.detach(), P[pre + "cond_lang.weight"], P[pre + "cond_lang.bias"])
+    x = dds_conv(P, pre + "convs.", x, x_mask)
+    return F.conv1d(x, P[pre + "proj.weight"], P[pre + "proj.bias"]) * x_mask
+
+
+def sdp_fwd(P, pre, x, x_mask, w, noise, g=None, l=None, n_flows=4):
+    """models.StochasticDurationPredictor.forward, reverse=False (models.py:261-322), eval mode; `noise` [b,2,t] replaces
+    the torch.randn draw of :288 (the reference multiplies it by x_mask itself).  Returns the per-utterance nll [b]."""
+    x = _predictor_cond(P, pre, x, x_mask, g, l)
+    h = F.conv1d(w, P[pre + "post_pre.weight"], P[pre + "post_pre.bias"])
+    h = dds_conv(P, pre + "post_convs.", h, x_mask)
+    h = F.conv1d(h, P[pre + "post_proj.weight"], P[pre + "post_proj.bias"]) * x_mask
+    e_q = noise * x_mask
+    z_q, logdet_tot_q = _flow_stack(P, pre + "post_flows.", e_q, x_mask, x + h, n_flows)
+    z_u, z_v = z_q[:, :1], z_q[:, 1:]
+    u = torch.sigmoid(z_u) * x_mask
+    z0 = (w - u) * x_mask
+    logdet_tot_q = logdet_tot_q + torch.sum((F.logsigmoid(z_u) + F.logsigmoid(-z_u)) * x_mask, [1, 2])
+    nll_post = torch.sum(-0.5 * (math.log(2 * math.pi) + (e_q ** 2)) * x_mask, [1, 2]) - logdet_tot_q
+    z0 = torch.log(torch.clamp_min(z0, 1e-5)) * x_mask
+    logdet_tot = torch.sum(-z0, [1, 2])
+    z = torch.cat([z0, z_v], 1)
+    z, ld = _flow_stack(P, pre + "flows.", z, x_mask, x, n_flows)
+    logdet_tot = logdet_tot + ld
+    nll = torch.sum(0.5 * (math.log(2 * math.pi) + (z ** 2)) * x_mask, [1, 2]) - logdet_tot
+    return nll + nll_post
+
+
+def spp_fwd(P, pre, x, x_mask, dr, noise, g=None, n_flows=4):
+    """models.StochasticPitchPredictor / StochasticEnergyPredictor.forward, reverse=False (models.py:364-396, 438-470):
+    z = cat(dr, noise * mask) through the flow stack conditioned on the text-side features; nll [b]."""
+    x = _predictor_cond(P, pre, x, x_mask, g)
+    z = torch.cat([dr, noise * x_mask], 1)
+    z, logdet_tot = _flow_stack(P, pre + "flows.", z, x_mask, x, n_flows)
+    return torch.sum(0.5 * (math.log(2 * math.pi) + (z ** 2)) * x_mask, [1, 2]) - logdet_tot
+
+
+def predictor_reverse(P, pre, x, x_mask, noise, g=None, l=None, n_flows=4):
+    """reverse=True branch shared by the three predictors (models.py:324-333, 398-407): flows reversed with the useless
+    vflow dropped, z = noise (already scaled), flip before every flow; returns channel 0 = logw / log-f0 / log-energy."""
+    x = _predictor_cond(P, pre, x, x_mask, g, l)
+    order = list(reversed(range(n_flows + 1)))
+    order = order[:-2] + [order[-1]]
+    z = noise
+    for idx in order:
+        z = torch.flip(z, [1])
+        z = elementwise_affine(P, pre + "flows.0.", z, x_mask, reverse=True) if idx == 0 else \
+            conv_flow(P, pre + f"flows.{idx}.", z, x_mask, x, reverse=True)
+    return z[:, :1]
+
+
+# ----------------------------------------------------------------------------- cfg 5 front end
+def emotion_speaker_vector(P, g, emo, emo_cartesian):
+    """models.FlowGenerator.forward front end (models.py:1008-1042): g [b,512] raw speaker embedding, emo [b] int64,
+    emo_cartesian [b,3] -> the conditioning vector [b, gin, 1] that encoder / predictors / decoder see."""
+    g = F.linear(F.normalize(g), P["emb_g.weight"], P["emb_g.bias"])
+    emos_proj = F.linear(F.embedding(emo, P["emo_id_proj.weight"]), P["emo_proj.weight"], P["emo_proj.bias"])
+    intens = F.linear(emo_cartesian[:, :1], P["emo_VAD_inten_proj.weight"], P["emo_VAD_inten_proj.bias"])
+    ele = F.embedding(torch.bucketize(emo_cartesian[:, 1].contiguous(), P["elevation_bins"]), P["elevation_emb.weight"])
+    azi = F.embedding(torch.bucketize(emo_cartesian[:, 2].contiguous(), P["azimuth_bins"]), P["azimuth_emb.weight"])
+    style = F.linear(torch.cat((ele, azi), -1), P["sty_proj.weight"], P["sty_proj.bias"])
+    emosty = F.layer_norm(F.softplus(torch.cat((emos_proj, style), -1)), (style.shape[-1] * 2,),
+                          P["emosty_layer_norm.weight"], P["emosty_layer_norm.bias"])
+    return torch.cat((g, intens + emosty), -1).unsqueeze(-1)
+
+
 # ----------------------------------------------------------------------------- training glue
 def logp_lattice(x_m, x_logs, z):
     """models.py:1076-1082"""
@@ -428,3 +627,39 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pit
     l_mle = mle_loss(z, z_m, z_logs, logdet, z_mask)
     return dict(z=z, z_m=z_m, z_logs=z_logs, logdet=logdet, z_mask=z_mask, x_m=x_m, x_mask=x_mask,
                 attn=attn, logp=logp, l_length=l_length, l_mle=l_mle, loss=l_mle + torch.sum(l_length))
+
+
+def train_forward_full(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g, emo, emo_cartesian, pitch, energy, lids, noises):
+    """models.FlowGenerator.forward as the fork runs it for configs/base_blank_emo_lang_pitch.json (models.py:1007-1133):
+    speaker / emotion front end, language embedding, TextEncoder, FlowSpecDecoder with the pitch / energy WaveNets, logp,
+    MAS, StochasticDurationPredictor loss, x_feature = x @ attn, stochastic pitch / energy predictor losses, prior expansion.
+    noises = (e_w [b,2,t_x], e_p [b,1,t_y], e_e [b,1,t_y]) replace the three torch.randn draws (models.py:288,383,457).
+    Returns the reference's 5-tuple entries by name plus the training loss of train_ms_emo_lang_pitch.py:295-306."""
+    n_sqz = hp.get("n_sqz", 2)
+    gv = emotion_speaker_vector(P, g, emo, emo_cartesian)                     # [b, gin, 1]
+    lv = F.embedding(lids, P["emb_l.weight"]).unsqueeze(-1)                   # [b, lin, 1]
+    x, x_m, x_logs, x_mask = text_encoder_fwd(P, "encoder.", ids, x_lengths, gv, hp["hidden_channels"], hp["n_layers_enc"],
+                                              hp["n_heads"], hp["window_size"], hp["kernel_size"], hp["prenet"],
+                                              hp["mean_only"], l=lv)
+    y_max = (y.size(2) // n_sqz) * n_sqz
+    y = y[:, :, :y_max]
+    y_lengths = (y_lengths // n_sqz) * n_sqz
+    z_mask = sequence_mask(y_lengths, y_max).unsqueeze(1).to(x_mask.dtype)
+    attn_mask = x_mask.unsqueeze(-1) * z_mask.unsqueeze(2)
+    pitch_norm, energy_norm = contour_norm(pitch, y_max), contour_norm(energy, y_max)
+    z, logdet = decoder_fwd(P, "decoder.", y, z_mask, gv, hp["n_blocks_dec"], hp["n_block_layers"], hp["hidden_channels"],
+                            hp["kernel_size_dec"], 4, n_sqz, pitch=pitch_norm, energy=energy_norm)
+    with torch.no_grad():
+        logp = logp_lattice(x_m, x_logs, z)
+        attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1).detach()
+    w = attn.squeeze(1).sum(2).unsqueeze(1)
+    l_length = sdp_fwd(P, "encoder.proj_w.", x, x_mask, w, noises[0], g=gv, l=lv) / torch.sum(x_mask)
+    x_feature = torch.matmul(x, attn.squeeze(1))
+    l_pitch = torch.sum(spp_fwd(P, "proj_pitch.", x_feature, z_mask, pitch_norm, noises[1], g=gv) / torch.sum(z_mask))
+    l_energy = torch.sum(spp_fwd(P, "proj_energy.", x_feature, z_mask, energy_norm, noises[2], g=gv) / torch.sum(z_mask))
+    z_m = torch.matmul(attn.squeeze(1).transpose(1, 2), x_m.transpose(1, 2)).transpose(1, 2)
+    z_logs = torch.matmul(attn.squeeze(1).transpose(1, 2), x_logs.transpose(1, 2)).transpose(1, 2)
+    l_mle = mle_loss(z, z_m, z_logs, logdet, z_mask)
+    loss = l_mle + torch.sum(l_length) + 0.5 * l_pitch + 0.5 * l_energy
+    return dict(z=z, z_m=z_m, z_logs=z_logs, logdet=logdet, z_mask=z_mask, x_m=x_m, x_mask=x_mask, attn=attn, logp=logp,
+                l_length=l_length, l_pitch=l_pitch, l_energy=l_energy, l_mle=l_mle, loss=loss, g=gv, x=x, x_feature=x_feature)

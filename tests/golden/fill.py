@@ -45,6 +45,8 @@ def fill_module(module, prefix=""):
     """In-place closed-form fill of every parameter of an nn.Module (by its state-dict name)."""
     with torch.no_grad():
         for name, p in module.named_parameters():
+            if not p.requires_grad:                  # frozen tables (the fork's elevation / azimuth bin edges) keep their values
+                continue
             p.copy_(closed_form(prefix + name, p.shape, p.dtype))
     return module
 

@@ -225,6 +225,138 @@ def main():
     dpl = fill_module(models.DurationPredictor(192, 256, 3, 0.1, gin_channels=256, lin_channels=4), "dpl.").eval()
     out.update(lang_l=lng, tel_x=lx, tel_m=lm, tel_gl=gl, dpl_out=dpl(xe, xm, g=spk, l=lng))
 
+    # ---- ActNorm data-dependent initialisation (modules.py:588-590, 607-619): set_ddi(True) on every ActNorm of a 3-block
+    # decoder, one forward — appended after everything above (every section from here on draws from its own generator)
+    gd = torch.Generator().manual_seed(4)
+    md = lens_mask([44, 30, 6], 44)
+    yd = (torch.randn(3, 80, 44, generator=gd) * 1.7 + 0.3) * md
+    decd = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 3, 4, p_dropout=0.05, n_split=4, n_sqz=2), "decoder.").eval()
+    for f in decd.flows:
+        if hasattr(f, "set_ddi"):
+            f.set_ddi(True)
+    with torch.no_grad():
+        zdd, ldd = decd(yd, md)
+    out.update(ddi_y=yd, ddi_mask=md, ddi_z=zdd, ddi_logdet=ldd,
+               **{f"ddi_logs{b}": decd.flows[3 * b].logs.detach().clone() for b in range(3)},
+               **{f"ddi_bias{b}": decd.flows[3 * b].bias.detach().clone() for b in range(3)})
+
+    # ---- DilatedDepthSeparableConv, ElementwiseAffine, ConvFlow (spline), the three stochastic predictors
+    import transforms
+    gs = torch.Generator().manual_seed(99)
+    T = 23; xm = lens_mask([23, 11], T)
+    xs_ = (torch.randn(2, 192, T, generator=gs) * xm).requires_grad_(True)
+    gcond = torch.randn(2, 192, T, generator=gs) * 0.5
+    dds = fill_module(modules.DilatedDepthSeparableConv(192, 3, 3, 0.5), "dds.").eval()
+    od = dds(xs_, xm, g=gcond)
+    (gxd,) = grads_of([(od, 21)], [xs_])
+    out.update(f1_mask=xm, dds_x=xs_, dds_g=gcond, dds_out=od, dds_gx=gxd)
+    # the spline itself on inputs that reach both tails and every bin
+    sp_in = (torch.randn(2, 1, T, generator=gs) * 3.5).requires_grad_(True)
+    uw, uh = torch.randn(2, 1, T, 10, generator=gs).requires_grad_(True), torch.randn(2, 1, T, 10, generator=gs).requires_grad_(True)
+    ud = torch.randn(2, 1, T, 9, generator=gs).requires_grad_(True)
+    so, sl = transforms.piecewise_rational_quadratic_transform(sp_in, uw, uh, ud, inverse=False, tails="linear", tail_bound=5.0)
+    gsp = grads_of([(so, 22), (sl, 23)], [sp_in, uw, uh, ud])
+    with torch.no_grad():
+        sinv, _ = transforms.piecewise_rational_quadratic_transform(so.detach(), uw, uh, ud, inverse=True, tails="linear", tail_bound=5.0)
+    out.update(sp_in=sp_in, sp_uw=uw, sp_uh=uh, sp_ud=ud, sp_out=so, sp_lad=sl, sp_gin=gsp[0], sp_guw=gsp[1], sp_guh=gsp[2],
+               sp_gud=gsp[3], sp_inv=sinv)
+    ea = fill_module(modules.ElementwiseAffine(2), "ea.")
+    z2 = (torch.randn(2, 2, T, generator=gs) * xm)
+    eo, el = ea(z2, xm)
+    out.update(ea_x=z2, ea_out=eo, ea_logdet=el)
+    cf = fill_module(modules.ConvFlow(2, 192, 3, num_layers=3), "cf.").eval()
+    z2g = z2.clone().requires_grad_(True); gc2 = gcond.clone().requires_grad_(True)
+    co, cl = cf(z2g, xm, g=gc2)
+    gz2, gg2 = grads_of([(co, 24), (cl, 25)], [z2g, gc2])
+    with torch.no_grad():
+        cinv = cf(co.detach(), xm, g=gcond, reverse=True)
+    out.update(cf_out=co, cf_logdet=cl, cf_gz=gz2, cf_gg=gg2, cf_inv=cinv)
+
+    class _Noise:                                   # replaces the predictors' torch.randn draws by tensors we keep
+        def __init__(self, queue):
+            self.q, self.orig = list(queue), torch.randn
+        def __enter__(self):
+            torch.randn = lambda *a, **k: self.q.pop(0)
+        def __exit__(self, *a):
+            torch.randn = self.orig
+            assert not self.q
+
+    spk5 = torch.randn(2, 512, 1, generator=gs) * 0.5
+    lng5 = torch.randn(2, 4, 1, generator=gs)
+    xe5 = torch.randn(2, 192, T, generator=gs) * xm
+    wdur = (torch.randint(1, 6, (2, 1, T), generator=gs).float()) * xm
+    e_w = torch.randn(2, 2, T, generator=gs)
+    sdp = fill_module(models.StochasticDurationPredictor(192, 192, 3, 0.5, 4, gin_channels=512, lin_channels=4), "sdp.").eval()
+    with _Noise([e_w.clone()]):
+        nll_w = sdp(xe5, xm, wdur, g=spk5, l=lng5)
+    prm = dict(sdp.named_parameters())
+    sdp_names = ["flows.0.log_scale", "flows.2.proj.weight", "flows.4.convs.convs_sep.2.weight", "post_flows.1.pre.weight",
+                 "post_flows.3.convs.norms_2.1.gamma", "post_convs.convs_1x1.0.weight", "post_pre.bias", "convs.norms_1.0.beta",
+                 "pre.weight", "proj.bias", "cond.weight", "cond_lang.bias", "post_flows.0.translation", "post_proj.weight"]
+    gs_ = grads_of([(nll_w, 26)], [prm[n] for n in sdp_names])
+    with _Noise([e_w.clone()]):
+        logw_rev = sdp(xe5, xm, g=spk5, l=lng5, reverse=True, noise_scale=0.8)
+    out.update(p5_g=spk5, p5_l=lng5, p5_x=xe5, p5_w=wdur, p5_ew=e_w, sdp_nll=nll_w, sdp_rev=logw_rev,
+               **{"sdp_g_" + n: v for n, v in zip(sdp_names, gs_)})
+    Tf = 31; fm = lens_mask([31, 18], Tf)
+    xf5 = torch.randn(2, 192, Tf, generator=gs) * fm
+    pn5 = torch.randn(2, 1, Tf, generator=gs) * 1.5 * fm
+    e_p = torch.randn(2, 1, Tf, generator=gs)
+    spp = fill_module(models.StochasticPitchPredictor(192, 256, 3, 0.1, 4, gin_channels=512), "spp.").eval()
+    with _Noise([e_p.clone()]):
+        nll_p = spp(xf5, fm, pn5, g=spk5)
+    prp = dict(spp.named_parameters())
+    spp_names = ["flows.0.translation", "flows.1.proj.bias", "flows.3.convs.convs_1x1.2.weight", "convs.convs_sep.1.bias", "pre.bias",
+                 "cond.bias", "proj.weight"]
+    gp_ = grads_of([(nll_p, 27)], [prp[n] for n in spp_names])
+    with _Noise([torch.cat([e_p, e_p.flip(2)], 1).clone()]):
+        pit_rev = spp(xf5, fm, g=spk5, reverse=True, noise_scale=0.7)
+    sep = fill_module(models.StochasticEnergyPredictor(192, 256, 3, 0.1, 4, gin_channels=512), "sep.").eval()
+    with _Noise([e_p.clone()]):
+        nll_e = sep(xf5, fm, pn5.abs(), g=spk5)
+    out.update(p5_fmask=fm, p5_xf=xf5, p5_pitch=pn5, p5_ep=e_p, spp_nll=nll_p, spp_rev=pit_rev, sep_nll=nll_e,
+               **{"spp_g_" + n: v for n, v in zip(spp_names, gp_)})
+
+    # ---- cfg 5 as the reference runs it: the FULL models.FlowGenerator(**hps.model) of configs/base_blank_emo_lang_pitch.json
+    # (the only config it constructs for), forward(x, x_lengths, y, y_lengths, g, emo, emo_cartesian, pitch,
+    # energy, l) + the training loss of train_ms_emo_lang_pitch.py:295-306 + parameter gradients
+    import json
+    with open(os.path.join(REF, "configs", "base_blank_emo_lang_pitch.json")) as f:
+        hm = json.load(f)["model"]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        gen = models.FlowGenerator(n_vocab=187, out_channels=80, n_lang=10, **hm)
+    fill_module(gen, "").eval()
+    g5 = torch.Generator().manual_seed(555)
+    B5, Tx5, Ty5 = 2, 19, 42
+    xl5, yl5 = torch.tensor([19, 12]), torch.tensor([42, 29])
+    ids5 = torch.randint(1, 187, (B5, Tx5), generator=g5) * (torch.arange(Tx5)[None, :] < xl5[:, None])
+    ym5 = lens_mask(yl5.tolist(), Ty5)
+    y5 = torch.randn(B5, 80, Ty5, generator=g5) * ym5
+    graw = torch.randn(B5, 512, generator=g5)
+    emo5 = torch.tensor([3, 0]); cart5 = torch.tensor([[0.7, 2.1, -0.3], [1.2, 1.7, 2.5]])
+    pit5 = ((80 + 200 * torch.rand(B5, 1, Ty5, generator=g5)) * (torch.rand(B5, 1, Ty5, generator=g5) > 0.3)) * ym5
+    ene5 = (1 + 10 * torch.rand(B5, 1, Ty5, generator=g5)) * ym5
+    lid5 = torch.tensor([2, 0])
+    n_w, n_p, n_e = torch.randn(B5, 2, Tx5, generator=g5), torch.randn(B5, 1, Ty5, generator=g5), torch.randn(B5, 1, Ty5, generator=g5)
+    with _Noise([n_w.clone(), n_p.clone(), n_e.clone()]):
+        (z5, zm5, zlogs5, ld5, zmask5), (xm5, _, xmask5), (attn5, ll5, lp5, le5), _, _ = \
+            gen(ids5, xl5, y5, yl5, g=graw, emo=emo5, emo_cartesian=cart5, pitch=pit5, energy=ene5, l=lid5)
+    lmle5 = commons.mle_loss(z5, zm5, zlogs5, ld5, zmask5)
+    loss5 = lmle5 + torch.sum(ll5.float()) + lp5 * 0.5 + le5 * 0.5
+    pg = dict(gen.named_parameters())
+    full_names = ["emb_g.weight", "emo_id_proj.weight", "emo_proj.bias", "emo_VAD_inten_proj.weight", "elevation_emb.weight",
+                  "azimuth_emb.weight", "sty_proj.weight", "emosty_layer_norm.weight", "emb_l.weight", "encoder.emb.weight",
+                  "encoder.encoder.cond_g.weight", "encoder.proj_w.flows.1.proj.weight", "encoder.proj_w.post_flows.2.pre.bias",
+                  "proj_pitch.flows.3.proj.weight", "proj_pitch.cond.weight", "proj_energy.flows.0.log_scale",
+                  "proj_energy.convs.convs_sep.0.weight", "decoder.flows.2.wn.cond_layer.weight_g",
+                  "decoder.flows.35.wn_pitch.cond_layer1.bias", "decoder.flows.17.end.weight", "encoder.proj_m.weight"]
+    gfull = torch.autograd.grad(loss5, [pg[n] for n in full_names], allow_unused=True)
+    out.update(full_ids=ids5, full_xl=xl5, full_yl=yl5, full_y=y5, full_g=graw, full_emo=emo5, full_cart=cart5, full_pitch=pit5,
+               full_energy=ene5, full_lid=lid5, full_nw=n_w, full_np=n_p, full_ne=n_e, full_z=z5, full_zm=zm5, full_logdet=ld5,
+               full_attn=attn5, full_l_length=ll5, full_l_pitch=lp5, full_l_energy=le5, full_l_mle=lmle5, full_loss=loss5,
+               **{"full_g_" + n: (v if v is not None else torch.zeros_like(pg[n])) for n, v in zip(full_names, gfull)})
+
     path = os.path.join(HERE, "float_golden.npz")
     np.savez_compressed(path, **{k: v.detach().cpu().numpy() for k, v in out.items()})
     print("wrote", path, len(out), "arrays", os.path.getsize(path), "bytes")
