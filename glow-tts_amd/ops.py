@@ -3,8 +3,6 @@
 PyTorch is used here only for device memory, streams and trivial index plumbing (building the
 row mask); all arithmetic of the hot path happens in libglowtts_hip.so.
 """
-import os
-
 import torch
 
 from . import _lib
@@ -194,6 +192,7 @@ class RowsCtx:
             t = torch.arange(self.Tp, device=self.device) - HALO
             self.rowmask2d = ((t[None, :] >= 0) & (t[None, :] < self.lengths[:, None])).to(torch.float32)
             self.rowmask = self.rowmask2d.reshape(-1).contiguous()
+            self.rowutt = (torch.arange(self.R, device=self.device) // self.Tp).to(torch.int32)
             return
         assert len(lengths_host) == self.B
         rnd = self.rnd = int(round_to or DEFAULT_ROWS.row_round)
@@ -208,6 +207,7 @@ class RowsCtx:
         self.rowbatch = torch.empty(self.R, dtype=torch.int64, device=self.device)
         self.rowframe = torch.empty(self.R, dtype=torch.int32, device=self.device)
         self.rowmask = torch.empty(self.R, dtype=torch.float32, device=self.device)
+        self.rowutt = torch.empty(self.R, dtype=torch.int32, device=self.device)
         self._fill(starts)
 
     def _fill(self, starts):
@@ -216,6 +216,11 @@ class RowsCtx:
         _lib.check(_lib.lib().gt_rows_ctx_fill(_lib.ptr(self.row0), _lib.ptr(self.lengths), _lib.ptr(self.rowbatch),
                                                _lib.ptr(self.rowframe), _lib.ptr(self.rowmask), self.B, self.R,
                                                _lib.current_stream(self.device)), "gt_rows_ctx_fill")
+        self.rowutt.copy_(self.rowbatch)                                # int32 twin of rowbatch (predictor kernels)
+
+    def row_utt(self):
+        """int32 [R]: utterance of every row (rows past the last utterance's frames belong to the last one)."""
+        return self.rowutt
 
     def utt_sum(self, rows, out, accumulate=False, masked=True):
         """out[b, :] (+)= sum of the (valid) rows of utterance b; rows bf16 or fp32 [R, C] (a column slice is fine),

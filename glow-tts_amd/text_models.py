@@ -88,8 +88,7 @@ class TextEncoder(nn.Module):
                  kernel_size, p_dropout, window_size=None, block_length=None, mean_only=False, prenet=False, use_sdp=False,
                  gin_channels=0, lin_channels=0, emoin_channels=0):
         super().__init__()
-        assert not use_sdp, "StochasticDurationPredictor is SURVEY §8 (f1): next round"
-        self.gin_channels, self.lin_channels = gin_channels, lin_channels
+        self.use_sdp, self.gin_channels, self.lin_channels = use_sdp, gin_channels, lin_channels
         self.n_vocab, self.out_channels, self.hidden_channels = n_vocab, out_channels, hidden_channels
         self.filter_channels, self.filter_channels_dp, self.n_heads, self.n_layers = filter_channels, filter_channels_dp, n_heads, n_layers
         self.kernel_size, self.p_dropout, self.window_size, self.mean_only, self.prenet = kernel_size, p_dropout, window_size, mean_only, prenet
@@ -97,8 +96,12 @@ class TextEncoder(nn.Module):
         # of every position (models.py:654-664, 698-699)
         self.emb = nn.Embedding(n_vocab, hidden_channels - lin_channels)
         nn.init.normal_(self.emb.weight, 0.0, (hidden_channels - lin_channels) ** -0.5)
-        self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout, gin_channels=gin_channels,
-                                        lin_channels=lin_channels)
+        if use_sdp:                                                  # models.py:668-670
+            from .predictors import StochasticDurationPredictor
+            self.proj_w = StochasticDurationPredictor(hidden_channels, 192, 3, 0.5, 4, gin_channels=gin_channels, lin_channels=lin_channels)
+        else:
+            self.proj_w = DurationPredictor(hidden_channels, filter_channels_dp, kernel_size, p_dropout, gin_channels=gin_channels,
+                                            lin_channels=lin_channels)
         if prenet:
             self.pre = ConvReluNorm(hidden_channels, hidden_channels, hidden_channels, kernel_size=5, n_layers=3, p_dropout=0.5)
         self.encoder = Encoder(hidden_channels, filter_channels, n_heads, n_layers, kernel_size, p_dropout,
@@ -340,56 +343,129 @@ def _encoder_stream(dev):
 
 
 class FlowGenerator(nn.Module):
-    """Training forward of Glow-TTS for the base configs (configs/base.json, base_blank.json):
-    TextEncoder -> FlowSpecDecoder -> logp -> MAS -> durations / prior expansion, with the return
-    structure of reference models.py:1133 (entries this sub-graph does not produce are None)."""
+    """reference models.FlowGenerator (models.py:792-1256): constructor arguments, forward / infer signatures, return
+    structure and state_dict keys of the fork.
+
+    * configs/base_blank_emo_lang_pitch.json (cfg 5, the one config the reference class constructs for — SURVEY F1):
+      `FlowGenerator(n_vocab, out_channels=80, n_lang=10, **hps.model)` builds the speaker / emotion front end
+      (use_spk_embeds, use_emo_embeds: emb_g, emo_*, elevation / azimuth tables, models.py:904-937), the language
+      embedding, the StochasticDurationPredictor inside the encoder (use_sdp) and the stochastic pitch / energy predictors
+      (use_spp / use_sep); forward(x, x_lengths, y, y_lengths, g, emo, emo_cartesian, pitch, energy, l) is called exactly as
+      train_ms_emo_lang_pitch.py:284-289 calls it and returns the 5-tuple of models.py:1133 with l_pitch / l_energy filled.
+    * the base configs (cfg 1-4), for which the fork's class raises NameError (F1): the upstream-equivalent live
+      sub-graph — use_sdp=False gives the deterministic DurationPredictor, g (if gin_channels) enters as [b, gin, 1] at
+      the encoder / duration-predictor / decoder boundary, entries this sub-graph does not produce are None.
+
+    with_prosody_wn (ours; implied by use_spp / use_sep): create the fork's wn_pitch / wn_energy in every coupling block.
+    The reference always creates them (two thirds of the decoder's parameters are dead weight in the base
+    configs); here they exist only when something can feed them."""
 
     def __init__(self, n_vocab, hidden_channels, filter_channels, filter_channels_dp, out_channels, kernel_size=3, n_heads=2,
-                 n_layers_enc=6, p_dropout=0., n_blocks_dec=12, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
-                 p_dropout_dec=0., n_speakers=0, gin_channels=0, n_split=4, n_sqz=1, sigmoid_scale=False, window_size=None,
-                 block_length=None, mean_only=False, hidden_channels_enc=None, hidden_channels_dec=None, prenet=False,
-                 with_prosody_wn=False, n_lang=0, lin_channels=0, **kwargs):
+                 n_layers_enc=10, p_dropout=0., n_blocks_dec=12, kernel_size_dec=5, dilation_rate=5, n_block_layers=4,
+                 p_dropout_dec=0., n_speakers=0, n_lang=0, gin_channels=0, lin_channels=0, emoin_channels=0, n_split=4, n_sqz=1,
+                 sigmoid_scale=False, window_size=None, block_length=None, mean_only=False, hidden_channels_enc=None,
+                 hidden_channels_dec=None, prenet=False, use_spk_embeds=False, use_lang_embeds=False, use_emo_embeds=False,
+                 use_sdp=True, use_spp=False, use_sep=False, with_prosody_wn=None, **kwargs):
         super().__init__()
         from .models import FlowSpecDecoder
-        # Multi-speaker configs (cfg 4, configs/base_blank_ms.json: gin_channels=256): the speaker vector enters
-        # forward()/infer() as g [b, gin_channels, 1], i.e. AT the encoder / duration-predictor / decoder boundary
-        # (models.py:1046,1075,1090).  The fork's front end that produces it (emb_g over an external 512-d speaker
-        # embedding concatenated with its emotion/style embeddings, models.py:1007-1044) sits before that boundary.
-        self.n_sqz, self.mean_only, self.out_channels, self.gin_channels = n_sqz, mean_only, out_channels, gin_channels
-        self.encoder = TextEncoder(n_vocab, out_channels, hidden_channels_enc or hidden_channels, filter_channels,
-                                   filter_channels_dp, n_heads, n_layers_enc, kernel_size, p_dropout, window_size=window_size,
-                                   block_length=block_length, mean_only=mean_only, prenet=prenet, use_sdp=False,
-                                   gin_channels=gin_channels, lin_channels=lin_channels)
-        self.n_lang, self.lin_channels = n_lang, lin_channels
-        if n_lang > 1:                                               # models.py:914-916
-            self.emb_l = nn.Embedding(n_lang, lin_channels)
-            nn.init.xavier_uniform_(self.emb_l.weight)
+        self.n_vocab, self.hidden_channels, self.out_channels = n_vocab, hidden_channels, out_channels
+        self.n_sqz, self.mean_only, self.gin_channels, self.lin_channels, self.n_lang = n_sqz, mean_only, gin_channels, lin_channels, n_lang
+        self.use_spk_embeds, self.use_emo_embeds = use_spk_embeds, use_emo_embeds
+        self.use_lang_embeds = use_lang_embeds or (n_lang > 1 and lin_channels > 0)
+        self.use_sdp, self.use_spp, self.use_sep = use_sdp, use_spp, use_sep
+        henc = hidden_channels_enc or hidden_channels
+        self.encoder = TextEncoder(n_vocab, out_channels, henc, filter_channels, filter_channels_dp, n_heads, n_layers_enc,
+                                   kernel_size, p_dropout, window_size=window_size, block_length=block_length, mean_only=mean_only,
+                                   prenet=prenet, use_sdp=use_sdp, gin_channels=gin_channels, lin_channels=lin_channels)
+        if with_prosody_wn is None:
+            with_prosody_wn = bool(use_spp or use_sep)
         self.decoder = FlowSpecDecoder(out_channels, hidden_channels_dec or hidden_channels, kernel_size_dec, dilation_rate,
                                        n_blocks_dec, n_block_layers, p_dropout=p_dropout_dec, n_split=n_split, n_sqz=n_sqz,
                                        sigmoid_scale=sigmoid_scale, gin_channels=gin_channels, with_prosody_wn=with_prosody_wn)
-        # with_prosody_wn: the fork's wn_pitch / wn_energy in every coupling block (attentions.py:113-114); forward() then
-        # takes the raw pitch / energy contours.  Their LOSSES (l_pitch / l_energy) come from the stochastic predictors of
-        # SURVEY §8 f1, which are not built: those two entries of the return tuple stay None.
+        if use_spk_embeds:                                           # models.py:904-906
+            self.emb_g = nn.Linear(512, gin_channels // 2)
+        if self.use_lang_embeds:                                     # models.py:913-916
+            self.emb_l = nn.Embedding(n_lang, lin_channels)
+            nn.init.xavier_uniform_(self.emb_l.weight)
+        if use_emo_embeds:                                           # models.py:918-937 ("Cartesian Emo")
+            q, e = gin_channels // 4, gin_channels // 8
+            self.emo_id_proj = nn.Embedding(5, q)
+            nn.init.normal_(self.emo_id_proj.weight, mean=0, std=gin_channels // 4 ** -0.5)     # (sic: // binds first)
+            self.emo_proj = nn.Linear(q, q, bias=True)
+            self.emo_VAD_inten_proj = nn.Linear(1, gin_channels // 2)
+            self.elevation_bins = nn.Parameter(torch.linspace(math.pi / 2, math.pi, 2), requires_grad=False)
+            self.elevation_emb = nn.Embedding(2, e)
+            nn.init.normal_(self.elevation_emb.weight, mean=0, std=gin_channels // 8 ** -0.5)
+            self.azimuth_bins = nn.Parameter(torch.linspace(-math.pi / 2, math.pi, 4), requires_grad=False)
+            self.azimuth_emb = nn.Embedding(4, e)
+            nn.init.normal_(self.azimuth_emb.weight, mean=0, std=gin_channels // 8 ** -0.5)
+            self.sty_proj = nn.Linear(q, q, bias=True)
+            self.emosty_layer_norm = nn.LayerNorm(gin_channels // 2)
+        if use_spp:                                                  # models.py:954-965
+            from .predictors import StochasticPitchPredictor
+            self.proj_pitch = StochasticPitchPredictor(henc, 256, 3, 0.1, 4, gin_channels=gin_channels)
+        if use_sep:                                                  # models.py:970-981
+            from .predictors import StochasticEnergyPredictor
+            self.proj_energy = StochasticEnergyPredictor(henc, 256, 3, 0.1, 4, gin_channels=gin_channels)
         self._step = 0
         # rows-layout state of THIS model (ragged packing, row rounding, the batch's host-side lengths): shared with the
         # encoder / decoder runners; train.Trainer configures it — nothing process-global
         self.rows_cfg = self.encoder.rows_cfg = self.decoder.rows_cfg = ops.RowsConfig()
 
-    @torch.no_grad()
-    def infer(self, x, x_lengths, noise_scale=1.0, length_scale=1.0, g=None, l=None):
-        """Synthesis (reference FlowGenerator.infer, models.py:1122-1232, on the live sub-graph: no speaker / emotion /
-        pitch / energy inputs): text -> durations -> expanded prior -> z = z_m + noise -> decoder(reverse=True) -> mel.
-        Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)).  The output length is data
-        dependent, so this reads the predicted lengths back from the device once."""
+    # ---- conditioning front end (models.py:1008-1042) -----------------------------------------------------------------
+    def condition(self, g, emo, emo_cartesian):
+        """-> the conditioning vector [b, gin, 1] that encoder / predictors / decoder see.  These are ~15 small ops on
+        [B, <= 512] tensors per step (B rows): host-side PyTorch plumbing, differentiable w.r.t. all their parameters."""
+        F = torch.nn.functional
+        if self.use_spk_embeds:
+            if g is None:
+                raise ValueError("this model owns emb_g: forward needs the raw speaker embedding g [b, 512]")
+            g = self.emb_g(F.normalize(g.squeeze(-1) if g.dim() == 3 else g))
+        if not self.use_emo_embeds:
+            if emo is not None or emo_cartesian is not None:
+                raise ValueError("emo / emo_cartesian given to a model built without use_emo_embeds")
+            if g is None:
+                return None
+            return g.unsqueeze(-1) if g.dim() == 2 else g
+        if emo is None or emo_cartesian is None or g is None:
+            raise ValueError("use_emo_embeds: forward needs g, emo [b] and emo_cartesian [b, 3] (models.py:1018-1042)")
+        emos_proj = self.emo_proj(self.emo_id_proj(emo))
+        intens = self.emo_VAD_inten_proj(emo_cartesian[:, :1])
+        ele = self.elevation_emb(torch.bucketize(emo_cartesian[:, 1].contiguous(), self.elevation_bins))
+        azi = self.azimuth_emb(torch.bucketize(emo_cartesian[:, 2].contiguous(), self.azimuth_bins))
+        style = self.sty_proj(torch.cat((ele, azi), dim=-1))
+        emosty = self.emosty_layer_norm(F.softplus(torch.cat((emos_proj, style), dim=-1)))
+        return torch.cat((g, intens + emosty), dim=-1).unsqueeze(-1)
+
+    def store_inverse(self):
+        """models.py:1255-1256: freeze the model for synthesis (weights packed once, flow scalars cached)."""
         self.prepare()
+        self.decoder.store_inverse()
+
+    @torch.no_grad()
+    def infer(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, l=None, gst_token=None,
+              noise_scale=1., noise_scale_w=1., f0_noise_scale=1., energy_noise_scale=1., length_scale=1., pitch_scale=1.0,
+              energy_scale=1.0):
+        """Synthesis (reference FlowGenerator.infer, models.py:1135-1231): text -> durations (deterministic predictor, or the
+        stochastic one run in reverse) -> expanded prior -> [predicted pitch / energy] -> z = z_m + noise ->
+        decoder(reverse=True) -> mel.  Returns ((y, z_m, z_logs, None, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_),
+        (pitch, energy)).  The output length is data dependent, so this reads the predicted lengths back from the device once."""
+        if self.decoder._inv_cache is None:
+            self.prepare()
         self.rows_cfg.host_lengths.clear()
+        g = self.condition(g, emo, emo_cartesian)
         if l is not None:
             l = self.emb_l(l).unsqueeze(-1)
         xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
         rc, xb = self.encoder._last_rows
-        dvec = self.encoder.proj_w.cond_vec(g, l)
-        runner = _DurationRunner(self.encoder.proj_w, rc, xb, False, 0, has_cond=dvec is not None)
-        (logw,), _ = runner.forward(*([dvec] if dvec is not None else []))
+        pw = self.encoder.proj_w
+        dvec = pw.cond_vec(g, l)
+        if self.use_sdp:
+            nz = torch.randn(rc.R, 2, dtype=torch.float32, device=x.device) * noise_scale_w
+            logw = rc.from_rows(pw._reverse_rows(rc, xb, dvec, nz)[:, None].contiguous())
+        else:
+            runner = _DurationRunner(pw, rc, xb, False, 0, has_cond=dvec is not None)
+            (logw,), _ = runner.forward(*([dvec] if dvec is not None else []))
         w = torch.exp(logw) * x_mask * length_scale
         w_ceil = torch.ceil(w)
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
@@ -402,7 +478,7 @@ class FlowGenerator(nn.Module):
         attn = ((j[None, None, :] < cum[:, :, None]) & (j[None, None, :] >= (cum - dur)[:, :, None])).to(x_mask.dtype)
         attn = (attn * x_mask.transpose(1, 2) * z_mask).unsqueeze(1)
         frame2token = torch.searchsorted(cum.contiguous(), j[None, :].expand(cum.shape[0], Ty).contiguous(), right=True)
-        frame2token = frame2token.clamp_(max=dur.shape[1] - 1).to(torch.int32)
+        frame2token = frame2token.clamp_(max=dur.shape[1] - 1).to(torch.int32).contiguous()
         L = _lib.lib()
         B, C, Tx = x_m.shape
         xm = x_m.float().contiguous()
@@ -420,8 +496,29 @@ class FlowGenerator(nn.Module):
             z_logs = z_logs * z_mask
         logw_ = torch.log(1e-8 + torch.sum(attn.squeeze(1), -1)).unsqueeze(1) * x_mask
         z = (z_m + torch.exp(z_logs) * torch.randn_like(z_m) * noise_scale) * z_mask
-        y, logdet = self.decoder(z, z_mask, g=g, reverse=True, prepared=True)
-        return (y, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_)
+        pitch = energy = None
+        if self.use_spp or self.use_sep:                              # models.py:1203-1228
+            rcf = ops.RowsCtx(y_lengths.to(torch.int32), Ty)
+            xf = self._gather_features(rc, xb, rcf, frame2token)
+            if self.use_spp:
+                nz = torch.randn(rcf.R, 2, dtype=torch.float32, device=x.device) * f0_noise_scale
+                pitch = rcf.from_rows(self.proj_pitch._reverse_rows(rcf, xf, self.proj_pitch.cond_vec(g), nz)[:, None].contiguous()).squeeze(1) * pitch_scale
+            if self.use_sep:
+                nz = torch.randn(rcf.R, 2, dtype=torch.float32, device=x.device) * energy_noise_scale
+                energy = rcf.from_rows(self.proj_energy._reverse_rows(rcf, xf, self.proj_energy.cond_vec(g), nz)[:, None].contiguous()).squeeze(1) * energy_scale
+        yo, logdet = self.decoder(z, z_mask, g=g, pitch=pitch, energy=energy, reverse=True, prepared=True)
+        return (yo, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_), (pitch, energy)
+
+    @staticmethod
+    def _gather_features(rcx, xb, rcf, frame2token):
+        """x_feature = x @ attn (models.py:1094) for a hard path: frame rows <- token rows (gt_rows_gather_tokens), bf16"""
+        C = xb.shape[1]
+        out = torch.empty(rcf.R, C, dtype=torch.bfloat16, device=xb.device)
+        _lib.check(_lib.lib().gt_rows_gather_tokens(_lib.ptr(xb), xb.stride(0), _lib.ptr(frame2token), frame2token.shape[1],
+                                                    _lib.ptr(rcx.row0), rcx.Tp, _lib.ptr(rcf.row_utt()), _lib.ptr(rcf.row0), rcf.Tp,
+                                                    _lib.ptr(rcf.rowmask), _lib.ptr(out), rcf.R, C, _lib.current_stream(xb.device)),
+                   "gt_rows_gather_tokens")
+        return out
 
     def _predict_logw(self, g, l=None):
         """logw = proj_w(x.detach(), x_mask, g=g, l=l) (models.py:1090) on the rows the text encoder just produced."""
@@ -442,7 +539,8 @@ class FlowGenerator(nn.Module):
     def prepare(self):
         """Re-pack every conv weight for the MFMA kernels (once per optimizer step)."""
         prepare_all(self)
-        self.encoder.proj_w.prepare_extra()
+        if not self.use_sdp:
+            self.encoder.proj_w.prepare_extra()
 
     @staticmethod
     def _contour(c, y_max_length):
@@ -463,21 +561,28 @@ class FlowGenerator(nn.Module):
         return y, y_lengths, y_max_length
 
     def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None,
-                lengths_host=None, defer_encoder_backward=False):
-        """lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (self.rows_cfg.ragged) size its buffers
-        without a device sync (the data loader has them); without it they are read back from the device.
+                lengths_host=None, defer_encoder_backward=False, noise=None):
+        """models.py:1007-1133.  Beyond the reference's arguments:
+        lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (self.rows_cfg.ragged) size its
+        buffers without a device sync (the data loader has them); without it they are read back from the device.
         defer_encoder_backward: cut the autograd graph at the text encoder's outputs, so that `loss.backward()` yields the
-        decoder's (and the duration predictor's) gradients only and `backward_encoder()` runs the rest later — the
-        data-parallel trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs."""
-        assert emo is None and emo_cartesian is None, "emotion inputs (cfg 5's front end) are not on the round-1 path"
+        decoder's (and the predictors') gradients only and `backward_encoder()` runs the rest later — the data-parallel
+        trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs.
+        noise = (e_w [b,2,t_x], e_p [b,1,t_y], e_e [b,1,t_y]): the predictors' torch.randn draws (models.py:288,383,457),
+        injected by the parity tests."""
+        g = self.condition(g, emo, emo_cartesian)
         if l is not None:
-            l = self.emb_l(l).unsqueeze(-1)                          # language ids [b] -> [b, lin_channels, 1] (models.py:1011-1012)
-        assert (g is None) == (self.gin_channels == 0), "g [b, gin_channels, 1] is required exactly when gin_channels != 0"
+            l = self.emb_l(l).unsqueeze(-1)                          # language ids [b] -> [b, lin_channels, 1] (models.py:1012-1013)
+        assert (g is None) == (self.gin_channels == 0), "a speaker / conditioning vector is required exactly when gin_channels != 0"
+        if (self.use_spp and pitch is None) or (self.use_sep and energy is None):
+            raise ValueError("use_spp / use_sep: forward needs the pitch / energy contours (models.py:1057-1115)")
         self.prepare()
         self._step += 1
         if self.rows_cfg.ragged:
             lh = lengths_host if lengths_host is not None else (x_lengths.tolist(), y_lengths.tolist())
-            self.rows_cfg.host_lengths["x"], self.rows_cfg.host_lengths["y"] = list(lh[0]), list(lh[1])
+            hl = self.rows_cfg.host_lengths
+            hl["x"], hl["y"] = list(lh[0]), list(lh[1])
+            hl["f"] = [int(v) // self.n_sqz * self.n_sqz for v in lh[1]]
         else:
             self.rows_cfg.host_lengths.clear()
         # The text encoder (needs the text only) and the decoder (needs the mel only) are independent until the likelihood
@@ -485,16 +590,17 @@ class FlowGenerator(nn.Module):
         # graph) — autograd replays each node's backward on the stream of its forward, so the encoder's backward overlaps
         # the decoder's too.  Both are chains of latency-bound kernels on a fraction of the CUs.
         fork = ENCODER_STREAM and x.is_cuda
+        logw = None
         if fork:
             main = torch.cuda.current_stream(x.device)
             enc_stream = _encoder_stream(x.device)
             enc_stream.wait_stream(main)
             with torch.cuda.stream(enc_stream):
                 xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
-                logw = self._predict_logw(g, l)   # needs the encoder's output only (x is detached, models.py:586): same branch
+                if not self.use_sdp:
+                    logw = self._predict_logw(g, l)   # needs the encoder's output only (x is detached, models.py:586): same branch
         else:
             xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
-            logw = None
         self._deferred = []
         if defer_encoder_backward:
             leaf = x_m.detach().requires_grad_(True)
@@ -504,21 +610,41 @@ class FlowGenerator(nn.Module):
                 self._deferred.append((x_logs, leaf)); x_logs = leaf
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
-        z, logdet = self.decoder(y, z_mask, g=g, pitch=self._contour(pitch, y_max_length), energy=self._contour(energy, y_max_length),
-                                 prepared=True)
+        pitch_norm, energy_norm = self._contour(pitch, y_max_length), self._contour(energy, y_max_length)
+        z, logdet = self.decoder(y, z_mask, g=g, pitch=pitch_norm, energy=energy_norm, prepared=True)
         if fork:
             main.wait_stream(enc_stream)
-            for t_ in (xo, x_m, x_logs, x_mask, logw):
+            for t_ in (xo, x_m, x_logs, x_mask, self.encoder._last_rows[1]) + ((logw,) if logw is not None else ()):
                 t_.record_stream(main)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             attn = mas.path.unsqueeze(1)
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
-        logw_ = torch.log(w + 1e-8) * x_mask
-        if logw is None:
-            logw = self._predict_logw(g, l)
-        l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)  # models.py:1089-1092
+        rcx, xb = self.encoder._last_rows
+        if self.use_sdp:                                                       # models.py:1086-1088
+            pw = self.encoder.proj_w
+            w_rows = rcx.to_rows(w.float())[:, 0].contiguous()
+            nw = None if noise is None else rcx.to_rows(noise[0].float())
+            l_length = pw.nll_rows(rcx, xb, w_rows, pw.cond_vec(g, l), nw) / torch.sum(x_mask)
+        else:                                                                  # models.py:1089-1092
+            logw_ = torch.log(w + 1e-8) * x_mask
+            if logw is None:
+                logw = self._predict_logw(g, l)
+            l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
+        l_pitch = l_energy = None
+        if self.use_spp or self.use_sep:                                       # models.py:1094-1115
+            rcf = ops.make_ctx(y_lengths.to(torch.int32), y_max_length, "f", cfg=self.rows_cfg)
+            xf = self._gather_features(rcx, xb, rcf, mas.frame2token)
+            zsum = torch.sum(z_mask)
+            if self.use_spp:
+                pp = self.proj_pitch
+                npz = None if noise is None else rcf.to_rows(noise[1].float())[:, 0].contiguous()
+                l_pitch = torch.sum(pp.nll_rows(rcf, xf, rcf.to_rows(pitch_norm.float())[:, 0].contiguous(), pp.cond_vec(g), npz) / zsum)
+            if self.use_sep:
+                pe = self.proj_energy
+                nez = None if noise is None else rcf.to_rows(noise[2].float())[:, 0].contiguous()
+                l_energy = torch.sum(pe.nll_rows(rcf, xf, rcf.to_rows(energy_norm.float())[:, 0].contiguous(), pe.cond_vec(g), nez) / zsum)
         z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
         z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)
         self.last_logp = logp
-        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, None, None), (None, None, None, None), None
+        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, l_pitch, l_energy), (None, None, None, None), None

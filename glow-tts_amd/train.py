@@ -19,7 +19,9 @@ from . import models
 BASE_MODEL = dict(hidden_channels=192, filter_channels=768, filter_channels_dp=256, kernel_size=3, p_dropout=0.1,
                   n_blocks_dec=12, n_layers_enc=6, n_heads=2, p_dropout_dec=0.05, dilation_rate=1, kernel_size_dec=5,
                   n_block_layers=4, n_sqz=2, prenet=True, mean_only=True, hidden_channels_enc=192,
-                  hidden_channels_dec=192, window_size=4)      # == reference configs/base.json "model"
+                  hidden_channels_dec=192, window_size=4,      # == reference configs/base.json "model"
+                  use_sdp=False)   # the upstream-equivalent live sub-graph (deterministic DurationPredictor; SURVEY F1: the fork's
+                                   # class, whose default is use_sdp=True, does not construct for the base configs)
 
 
 def load_model_config(path=None):
@@ -271,7 +273,11 @@ class Trainer:
                 accum += list(mod.parameters(recurse=False))
             elif kind == "MultiHeadAttention":
                 accum += [mod.emb_rel_k, mod.emb_rel_v]
-        self.buckets = GradBuckets(list(model.parameters()), world, accum=accum)
+        # flat-buffer order: everything but the decoder first, the decoder's parameters last (whatever the registration order
+        # of the model's sub-modules; checkpoint.py maps the flat layout back to model.parameters() order by identity)
+        named = list(model.named_parameters())
+        plist = [p for n, p in named if not n.startswith("decoder.")] + [p for n, p in named if n.startswith("decoder.")]
+        self.buckets = GradBuckets(plist, world, accum=accum)
         # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
         # first backward call and travel over xGMI while the text encoder's backward runs
         name_of = {id(p): n for n, p in model.named_parameters()}
@@ -377,6 +383,9 @@ class Trainer:
             ctxs["x"] = ops.RowsCtx(static[1].to(torch.int32), ids.shape[1], lengths_host=lh[0], round_to=self.cfg.row_round)
             ctxs["y"] = ops.RowsCtx((static[3] // 2).to(torch.int32), y.shape[2] // 2, lengths_host=[int(v) // 2 for v in lh[1]],
                                     round_to=self.cfg.row_round)
+            if getattr(self.model, "use_spp", False) or getattr(self.model, "use_sep", False):     # frame-rate rows of the pitch / energy predictors
+                ctxs["f"] = ops.RowsCtx((static[3] // 2 * 2).to(torch.int32), y.shape[2] // 2 * 2,
+                                        lengths_host=[int(v) // 2 * 2 for v in lh[1]], round_to=self.cfg.row_round)
         self.cfg.prebuilt.update(ctxs)
         try:
             return self._capture_with(static, lh, ctxs)
@@ -436,7 +445,8 @@ class Trainer:
             return (0, 0)
         _, rx = ops.RowsCtx.row_starts(lh[0], Tx, self.cfg.row_round)
         _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], Ty // 2, self.cfg.row_round)
-        return (rx, ry)
+        _, rf = ops.RowsCtx.row_starts([int(v) // 2 * 2 for v in lh[1]], Ty // 2 * 2, self.cfg.row_round)
+        return (rx, ry, rf)
 
     @staticmethod
     def _pad_time(t, T):
@@ -505,6 +515,8 @@ class Trainer:
                 dst.copy_(src)
         if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)
             ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
+            if "f" in ctxs:
+                ok = ok and ctxs["f"].refresh(static[3] // 2 * 2, [int(v) // 2 * 2 for v in lh[1]])
             assert ok, "row count of the batch does not match the captured graph"
         graphs[0].replay()                           # collectives sit BETWEEN the graphs, never inside one
         if len(graphs) == 2:

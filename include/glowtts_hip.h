@@ -338,6 +338,74 @@ int gt_coupling_rev(const float* out, const float* z, float* x, const float* row
 int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                   float* gnorm_sq, void* stream);
 
+/* ---- Stochastic duration / pitch / energy predictors (models.py:217-481, modules.py:683-819,
+ * transforms.py:12-202) on the rows layout.  C = 192 (filter_channels = in_channels, models.py:223).  `utt` is the
+ * int32 utterance index of every row ([R]); rows with rowmask == 0 are zero on input and on output.  Gradient outputs
+ * named d<param> ACCUMULATE (atomics); `acc` / `gacc` are per-utterance [B] accumulators of the negative log-likelihood
+ * and their incoming gradient.
+ *
+ * DilatedDepthSeparableConv layer i (modules.py:726-734), dilation = kernel_size^i, kernel_size = 3:
+ *   gt_dds_sep_fwd:  a1 = gelu(LayerNorm2(dwconv_d(x) + b))                -> bf16 rows, operand of the 1x1 conv (gt_conv_gemm_bf16)
+ *   gt_dds_out_fwd:  out = (x + dropout(gelu(LayerNorm2(h2)))) * mask       h2 = 1x1 conv output incl. bias (fp32 rows)
+ *   gt_dds_out_bwd:  dy -> d h2 (bf16), d gamma2 / d beta2
+ *   gt_dds_sep_bwd:  d a1 (fp32, from the 1x1 data-gradient GEMM) -> d h1, d gamma1 / d beta1   (h1 recomputed from x)
+ *   gt_dds_dw_bwd:   dx = (dy + dwconv_d^T(d h1)) * mask, d w [C,3], d b [C] */
+int gt_dds_sep_fwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
+                   const int32_t* utt, const float* rowmask, void* a1_bf16, int lda, int R, int C, int dilation, float eps, void* stream);
+int gt_dds_out_fwd(const float* h2, const float* x, int ldx, const float* gamma, const float* beta, const float* rowmask,
+                   float* out, void* out_bf16, int R, int C, float eps, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+int gt_dds_out_bwd(const float* h2, const float* dy, const float* gamma, const float* beta, const float* rowmask,
+                   void* dh2_bf16, float* dgamma, float* dbeta, int R, int C, float eps, float drop_p, uint32_t seed,
+                   const uint32_t* seed_dev, void* stream);
+int gt_dds_sep_bwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
+                   const int32_t* utt, const float* rowmask, const float* da1, float* dh1, float* dgamma, float* dbeta,
+                   int R, int C, int dilation, float eps, void* stream);
+int gt_dds_dw_bwd(const float* x, int ldx, const float* dh1, const float* dy, const float* w, const int32_t* utt,
+                  const float* rowmask, float* dx, float* dw, float* db, int R, int C, int dilation, void* stream);
+
+/* ConvFlow (modules.py:792-819), in_channels = 2, on z rows [R, 2]:
+ *   gt_convflow_pre_fwd:    x0 = (w_pre * z[:,0] + b_pre + g1 (+ g2)) * mask          (pre + DDSConv's `x = x + g`)
+ *   gt_convflow_pre_bwd:    dx0 -> d w_pre, d b_pre, dz[:,0] += sum_c dx0 w_pre, dg += dx0      (dz / dg may be NULL)
+ *   gt_convflow_spline_fwd: params = (Wp h + bp) * mask ([R,32], 29 used); z_out = [z0, RQS(z1)] * mask, channels swapped when
+ *                           flip (the torch.flip after every ConvFlow, models.py:317-318); acc[utt] += sign * log|det|
+ *   gt_convflow_spline_bwd: dz_out, gacc -> dh, d Wp [29,C], d bp [29], dz_in
+ *   gt_convflow_spline_inv: synthesis direction (transforms.py:152-180): z_out = [z0, RQS^-1(z1)] * mask
+ * The spline is transforms.piecewise_rational_quadratic_transform with 10 bins, linear tails, tail_bound 5. */
+int gt_convflow_pre_fwd(const float* z, int ldz, const float* w_pre, const float* b_pre, const float* g1, const float* g2,
+                        const float* rowmask, float* out, int R, int C, void* stream);
+int gt_convflow_pre_bwd(const float* dx0, const float* z, int ldz, const float* w_pre, const float* rowmask,
+                        float* dw_pre, float* db_pre, float* dz, int lddz, float* dg, int R, int C, void* stream);
+int gt_convflow_spline_fwd(const float* h, const float* Wp, const float* bp, const float* z_in, const float* rowmask,
+                           const int32_t* utt, float* z_out, float* params, float* acc, float sign, int flip, int R, int C, void* stream);
+int gt_convflow_spline_bwd(const float* h, const float* Wp, const float* params, const float* z_in, const float* dz_out,
+                           const float* gacc, const float* rowmask, const int32_t* utt, float* dh, float* dWp, float* dbp,
+                           float* dz_in, float sign, int flip, int R, int C, void* stream);
+int gt_convflow_spline_inv(const float* h, const float* Wp, const float* bp, const float* z_in, const float* rowmask,
+                           float* z_out, int R, int C, void* stream);
+
+/* ElementwiseAffine (modules.py:750-756) on [R,2]: y = (x * exp(log_scale) + translation) * mask (reverse: the inverse),
+ * acc[utt] += sign * (log_scale_0 + log_scale_1) per valid row (acc may be NULL). */
+int gt_ea_fwd(const float* x, const float* log_scale, const float* translation, const float* rowmask, const int32_t* utt,
+              float* y, float* acc, float sign, int reverse, int R, void* stream);
+int gt_ea_bwd(const float* x, const float* log_scale, const float* dy, const float* gacc, const float* rowmask, const int32_t* utt,
+              float* dx, float* dlog_scale, float* dtranslation, float sign, int R, void* stream);
+
+/* StochasticDurationPredictor between its posterior flows and its flows (models.py:299-311): z_q = [z_u, z_v], durations w [R],
+ * noise e_q [R,2] -> z = [log(max(w - sigmoid(z_u), 1e-5)), z_v];  acc[utt] += -0.5 (2 log 2pi + |e_q|^2)
+ * - (logsigmoid(z_u) + logsigmoid(-z_u)) + z[:,0].   gt_nll_gauss_*: acc[utt] += 0.5 (2 log 2pi + |z|^2) (models.py:321, 395, 469). */
+int gt_sdp_mid_fwd(const float* z_q, const float* w, const float* e_q, const float* rowmask, const int32_t* utt, float* z, float* acc,
+                   int R, void* stream);
+int gt_sdp_mid_bwd(const float* z_q, const float* w, const float* dz, const float* gacc, const float* rowmask, const int32_t* utt,
+                   float* dz_q, int R, void* stream);
+int gt_nll_gauss_fwd(const float* z, const float* rowmask, const int32_t* utt, float* acc, int R, void* stream);
+int gt_nll_gauss_bwd(const float* z, const float* gacc, const float* rowmask, const int32_t* utt, float* dz, int R, void* stream);
+
+/* x_feature = x @ attn (models.py:1094) for the hard MAS path: frame row m of utterance b takes the token row
+ * frame2token[b, t] (bf16 rows, C % 8 == 0); *_x describe the text-side rows, *_f the frame-rate rows. */
+int gt_rows_gather_tokens(const void* x_rows, int ldx, const int32_t* frame2token, int Ty, const int32_t* row0_x, int Tp_x,
+                          const int32_t* utt_f, const int32_t* row0_f, int Tp_f, const float* rowmask_f, void* out, int R_f, int C,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,7 +204,7 @@ def test_infer_generates_mel_through_the_reverse_flow(built):
     """FlowGenerator.infer: predicted durations -> generate_path (== the oracle's, commons.py:127-143) -> prior expansion
     -> reverse decoder; with noise_scale = 0 the mel equals the oracle's reverse decoder of the expanded means."""
     from glow_tts_amd import models
-    gen = fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1,
+    gen = fill_module(models.FlowGenerator(148, 192, 768, 256, 80, use_sdp=False, kernel_size=3, n_heads=2, n_layers_enc=2, p_dropout=0.1,
                                            n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                                            p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True), "").eval()
     P = cpu_state(gen)

@@ -205,7 +205,7 @@ HP = dict(hidden_channels=192, n_layers_enc=2, n_heads=2, window_size=4, kernel_
 
 def _make_generator(n_layers_enc=2, gin_channels=0, with_prosody_wn=False, n_lang=0, lin_channels=0):
     from glow_tts_amd import models
-    return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, kernel_size=3, n_heads=2, n_layers_enc=n_layers_enc, p_dropout=0.1,
+    return fill_module(models.FlowGenerator(148, 192, 768, 256, 80, use_sdp=False, kernel_size=3, n_heads=2, n_layers_enc=n_layers_enc, p_dropout=0.1,
                                             n_blocks_dec=2, kernel_size_dec=5, dilation_rate=1, n_block_layers=4,
                                             p_dropout_dec=0.05, n_sqz=2, window_size=4, mean_only=True, prenet=True,
                                             gin_channels=gin_channels, with_prosody_wn=with_prosody_wn, n_lang=n_lang,
