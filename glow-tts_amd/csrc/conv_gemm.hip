@@ -219,11 +219,20 @@ __device__ __forceinline__ void pack_one_row(
   }
   // flag 2 / 4: forward / data-gradient image in MFMA-fragment order for gt_conv_gemm2_bf16:
   //   [tap][n / 32][k / 16][lane = n % 32 + 32 * ((k % 16) / 8)][k % 8]   (one 1-KB A-fragment per (n/32, k/16))
-  const bool ffrag = gate & 2, dfrag = gate & 4;
+  const bool ffrag = gate & 2, dfrag = gate & 4, split3 = gate & 8;
   const int NBf = Npf >> 5, KSf = Kpf >> 4, NBd = Npd >> 5, KSd = Kpd >> 4;
   for (int i = tid; i < n; i += 256) {
     const int ci = i / taps, tap = i - ci * taps;
-    const bf16_t w = f2bf(vr[i] * scale);
+    const float wf = vr[i] * scale;
+    const bf16_t w = f2bf(wf);
+    if (split3) {
+      // bf16x3 GEMM (near-fp32 product from three bf16 MFMA passes): the reduction axis is K-concatenated as
+      // [w_hi ; w_lo ; w_hi] against activations [x_hi | x_hi | x_lo]  ->  x_hi w_hi + x_hi w_lo + x_lo w_hi
+      const bf16_t wl = f2bf(wf - bf2f(w));
+      if (Pf) { bf16_t* r = Pf + ((size_t)tap * Npf + pn) * Kpf; r[ci] = w; r[Cin + ci] = wl; r[2 * Cin + ci] = w; }
+      if (Pd) { bf16_t* r = Pd + ((size_t)(taps - 1 - tap) * Npd + ci) * Kpd; r[co] = w; r[Cout + co] = wl; r[2 * Cout + co] = w; }
+      continue;
+    }
     if (Pf) {
       if (ffrag) Pf[((((size_t)tap * NBf + (pn >> 5)) * KSf + (ci >> 4)) * 64 + (pn & 31) + 32 * ((ci & 15) >> 3)) * 8 + (ci & 7)] = w;
       else       Pf[((size_t)tap * Npf + pn) * Kpf + ci] = w;
@@ -421,8 +430,10 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
 {
   if (Cout <= 0 || Cin <= 0 || taps < 1 || taps > MAXTAPS) return GT_E_INVAL;
   if (!v || (!pack_fwd && !pack_dgrad && !(g && inv_norm))) return GT_E_INVAL;
-  if (pack_fwd && (Np_fwd < Cout || Kp_fwd < Cin)) return GT_E_INVAL;
-  if (pack_dgrad && (Np_dgrad < Cin || Kp_dgrad < Cout)) return GT_E_INVAL;
+  const int km = (gate & 8) ? 3 : 1;          // split3: K-concatenated [hi; lo; hi] images
+  if ((gate & 8) && (gate & 7)) return GT_E_UNSUPPORTED;
+  if (pack_fwd && (Np_fwd < Cout || Kp_fwd < km * Cin)) return GT_E_INVAL;
+  if (pack_dgrad && (Np_dgrad < Cin || Kp_dgrad < km * Cout)) return GT_E_INVAL;
   if ((gate & 1) && (Cout % 64)) return GT_E_UNSUPPORTED;
   hipLaunchKernelGGL(gt_pack_conv_weights_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream),
                      v, g, static_cast<bf16_t*>(pack_fwd), static_cast<bf16_t*>(pack_dgrad), inv_norm,

@@ -32,6 +32,12 @@ __device__ __forceinline__ void ld3(const float* p, int lane, float (&v)[NC])
 #pragma unroll
   for (int j = 0; j < NC; ++j) v[j] = p[lane + 64 * j];
 }
+// bf16x3 operand of a split GEMM (gt_pack_conv_weights flag 8): row = [hi | hi | lo], each PC wide
+__device__ __forceinline__ void split3_store(bf16_t* row, int c, float v)
+{
+  const bf16_t hi = f2bf(v);
+  row[c] = hi; row[PC + c] = hi; row[2 * PC + c] = f2bf(v - bf2f(hi));
+}
 // (mean, rstd) of one row held as NC values per lane
 __device__ __forceinline__ void ln_stats(const float (&v)[NC], float eps, float& mean, float& rstd)
 {
@@ -99,14 +105,14 @@ __global__ __launch_bounds__(256) void gt_dds_sep_fwd_kernel(
     bf16_t* o = a1 + (size_t)m * lda;
     if (rowmask[m] == 0.f) {
 #pragma unroll
-      for (int j = 0; j < NC; ++j) o[lane + 64 * j] = 0;
+      for (int j = 0; j < NC; ++j) split3_store(o, lane + 64 * j, 0.f);
       continue;
     }
     float h1[NC], mean, rstd;
     sep_row(x, ldx, wk, bb, utt, rowmask, m, d, R, lane, h1);
     ln_stats(h1, eps, mean, rstd);
 #pragma unroll
-    for (int j = 0; j < NC; ++j) o[lane + 64 * j] = f2bf(gelu_f((h1[j] - mean) * rstd * g[j] + be[j]));
+    for (int j = 0; j < NC; ++j) split3_store(o, lane + 64 * j, gelu_f((h1[j] - mean) * rstd * g[j] + be[j]));
   }
 }
 
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void gt_dds_out_bwd_kernel(
       ln_bwd_row(du, xh, g, rstd, o);
     }
 #pragma unroll
-    for (int j = 0; j < NC; ++j) dh2[(size_t)m * PC + lane + 64 * j] = f2bf(o[j]);
+    for (int j = 0; j < NC; ++j) split3_store(dh2 + (size_t)m * 3 * PC, lane + 64 * j, o[j]);
   }
 #pragma unroll
   for (int j = 0; j < NC; ++j) { atomicAdd(dgamma + lane + 64 * j, ag[j]); atomicAdd(dbeta + lane + 64 * j, ab[j]); }
@@ -331,40 +337,67 @@ constexpr int NB = 10;                        // bins (modules.py:777)
 constexpr int NPAR = 3 * NB - 1;              // 29 parameters per element
 constexpr float TAIL = 5.0f, MINBIN = 1e-3f, MINDER = 1e-3f;
 
-struct Spline {                               // everything the forward and the backward share for one element
+// Everything below indexes its small arrays with compile-time constants only (fully unrolled loops, selects instead of
+// gathers), so they live in registers: no private-memory (scratch) arrays — the build's resource audit enforces it.
+struct Spline {                               // what the forward and the backward share for one element
   float sw[NB], sh[NB];                       // softmax(unnormalised widths / heights)
-  float cw[NB + 1], chh[NB + 1];              // knot positions
-  float der[NB + 1];
   int k; bool inside;
+  float cwk, chk;                             // left knot of the element's bin
   float w, h, delta, d0, d1, theta;
+  float u0, u1;                               // raw derivative parameters of the bin's two knots (backward)
 };
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 
-__device__ void spline_setup(const float* p, float x, float inv_sqrt_c, Spline& s)
+// knots of one axis from the raw parameters: c[0] = -B, c[i] = 2B * cumsum_i - B, c[K] = B (transforms.py:113-134)
+__device__ __forceinline__ void spline_knots(const float* p, float inv_sqrt_c, float (&sm)[NB], float (&c)[NB + 1])
 {
-  // transforms.py:113-134: widths / heights = min + (1 - min*K) softmax(.), knots by cumulative sums scaled to [-B, B] with
-  // the end knots pinned; derivatives = min + softplus(.), the two outer ones pinned to 1 (linear tails, :66-69)
-  float mw = -1e30f, mh = -1e30f;
-  for (int i = 0; i < NB; ++i) { mw = fmaxf(mw, p[i] * inv_sqrt_c); mh = fmaxf(mh, p[NB + i] * inv_sqrt_c); }
-  float zw = 0.f, zh = 0.f;
-  for (int i = 0; i < NB; ++i) { s.sw[i] = __expf(p[i] * inv_sqrt_c - mw); zw += s.sw[i]; s.sh[i] = __expf(p[NB + i] * inv_sqrt_c - mh); zh += s.sh[i]; }
-  float aw = 0.f, ah = 0.f;
-  s.cw[0] = -TAIL; s.chh[0] = -TAIL;
+  float mx = -1e30f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) mx = fmaxf(mx, p[i] * inv_sqrt_c);
+  float z = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) { sm[i] = __expf(p[i] * inv_sqrt_c - mx); z += sm[i]; }
+  const float iz = 1.f / z;
+  float acc = 0.f;
+  c[0] = -TAIL;
+#pragma unroll
   for (int i = 0; i < NB; ++i) {
-    s.sw[i] /= zw; s.sh[i] /= zh;
-    aw += MINBIN + (1.f - MINBIN * NB) * s.sw[i]; ah += MINBIN + (1.f - MINBIN * NB) * s.sh[i];
-    s.cw[i + 1] = 2.f * TAIL * aw - TAIL; s.chh[i + 1] = 2.f * TAIL * ah - TAIL;
+    sm[i] *= iz;
+    acc += MINBIN + (1.f - MINBIN * NB) * sm[i];
+    c[i + 1] = 2.f * TAIL * acc - TAIL;
   }
-  s.cw[NB] = TAIL; s.chh[NB] = TAIL;
-  s.der[0] = 1.0f; s.der[NB] = 1.0f;            // min_derivative + softplus(log(exp(1 - min_derivative) - 1)) == 1
-  for (int i = 1; i < NB; ++i) s.der[i] = MINDER + softplus_f(p[2 * NB + i - 1]);
+  c[NB] = TAIL;
+}
+
+// x: the value the bin is searched with (forward: the input, on the width knots; inverse: the output, on the height knots)
+template <bool INVERSE>
+__device__ __forceinline__ void spline_setup(const float* p, float x, float inv_sqrt_c, Spline& s)
+{
+  float cw[NB + 1], chh[NB + 1];
+  spline_knots(p, inv_sqrt_c, s.sw, cw);
+  spline_knots(p + NB, inv_sqrt_c, s.sh, chh);
   s.inside = x >= -TAIL && x <= TAIL;
   int k = -1;                                   // transforms.searchsorted: #(x >= knot) - 1, last knot + 1e-6
-  for (int i = 0; i <= NB; ++i) k += (x >= (i == NB ? s.cw[i] + 1e-6f : s.cw[i])) ? 1 : 0;
-  s.k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
-  s.w = s.cw[s.k + 1] - s.cw[s.k]; s.h = s.chh[s.k + 1] - s.chh[s.k];
-  s.delta = s.h / s.w; s.d0 = s.der[s.k]; s.d1 = s.der[s.k + 1];
-  s.theta = (x - s.cw[s.k]) / s.w;
+#pragma unroll
+  for (int i = 0; i <= NB; ++i) { const float kn = INVERSE ? chh[i] : cw[i]; k += (x >= (i == NB ? kn + 1e-6f : kn)) ? 1 : 0; }
+  k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
+  s.k = k;
+  float cwk = 0.f, cwk1 = 0.f, chk = 0.f, chk1 = 0.f, u0 = 0.f, u1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+    if (i == k) {
+      cwk = cw[i]; cwk1 = cw[i + 1]; chk = chh[i]; chk1 = chh[i + 1];
+      u0 = i >= 1 ? p[2 * NB + (i >= 1 ? i - 1 : 0)] : 0.f;
+      u1 = i + 1 <= NB - 1 ? p[2 * NB + (i + 1 <= NB - 1 ? i : 0)] : 0.f;
+    }
+  // derivatives = min + softplus(.), the two outer ones pinned: min + softplus(log(exp(1 - min) - 1)) == 1 (transforms.py:66-69)
+  s.u0 = u0; s.u1 = u1;
+  s.d0 = k >= 1 ? MINDER + softplus_f(u0) : 1.0f;
+  s.d1 = k + 1 <= NB - 1 ? MINDER + softplus_f(u1) : 1.0f;
+  s.cwk = cwk; s.chk = chk;
+  s.w = cwk1 - cwk; s.h = chk1 - chk;
+  s.delta = s.h / s.w;
+  s.theta = (x - cwk) / s.w;
 }
 __device__ __forceinline__ void spline_eval(const Spline& s, float x, float& y, float& lad)
 {
@@ -372,14 +405,23 @@ __device__ __forceinline__ void spline_eval(const Spline& s, float x, float& y, 
   const float th = s.theta, t1 = th * (1.f - th);
   const float num = s.h * (s.delta * th * th + s.d0 * t1);
   const float den = s.delta + (s.d0 + s.d1 - 2.f * s.delta) * t1;
-  y = s.chh[s.k] + num / den;
+  y = s.chk + num / den;
   const float q2 = s.d1 * th * th + 2.f * s.delta * t1 + s.d0 * (1.f - th) * (1.f - th);
   lad = logf(s.delta * s.delta * q2) - 2.f * logf(den);
 }
-// gradients of (y, lad) w.r.t. the input and the 29 raw parameters, given gy = dL/dy and gl = dL/dlad
-__device__ void spline_grad(const Spline& s, float gy, float gl, float inv_sqrt_c, const float* p, float& gx, float* gp)
+__device__ __forceinline__ float spline_inverse(const Spline& s, float y)
 {
-  for (int i = 0; i < NPAR; ++i) gp[i] = 0.f;
+  if (!s.inside) return y;
+  const float yy = y - s.chk, sd = s.d0 + s.d1 - 2.f * s.delta;
+  const float a = yy * sd + s.h * (s.delta - s.d0), b = s.h * s.d0 - yy * sd, c = -s.delta * yy;
+  const float root = (2.f * c) / (-b - sqrtf(b * b - 4.f * a * c));
+  return root * s.w + s.cwk;
+}
+// gradients of (y, lad) w.r.t. the input and the 29 raw parameters, given gy = dL/dy and gl = dL/dlad
+__device__ __forceinline__ void spline_grad(const Spline& s, float gy, float gl, float inv_sqrt_c, float& gx, float (&gp)[32])
+{
+#pragma unroll
+  for (int i = 0; i < 32; ++i) gp[i] = 0.f;
   if (!s.inside) { gx = gy; return; }
   const float th = s.theta, t1 = th * (1.f - th), omt = 1.f - th;
   const float sd = s.d0 + s.d1 - 2.f * s.delta;
@@ -400,22 +442,26 @@ __device__ void spline_grad(const Spline& s, float gy, float gl, float inv_sqrt_
   const float iw = 1.f / s.w;
   gx = G_th * iw;
   const float g_cw = -G_th * iw, g_w = -G_th * th * iw - G_de * s.delta * iw, g_h = G_h + G_de * iw, g_ch = gy;
-  // knots: cw_k, w = cw_{k+1} - cw_k (end knots are constants); cw_j = 2B * cumsum_j - B for 1 <= j <= K-1
+  // knots: cw_k, w = cw_{k+1} - cw_k (the end knots are constants); cw_j = 2B * cumsum_j - B for 1 <= j <= K-1
   const int k = s.k;
-  const float gk_w = g_cw - g_w, gk1_w = g_w, gk_h = g_ch - g_h, gk1_h = g_h;
-  float gcs_w[NB + 1] = {}, gcs_h[NB + 1] = {};
-  if (k >= 1) { gcs_w[k] = 2.f * TAIL * gk_w; gcs_h[k] = 2.f * TAIL * gk_h; }
-  if (k + 1 <= NB - 1) { gcs_w[k + 1] = 2.f * TAIL * gk1_w; gcs_h[k + 1] = 2.f * TAIL * gk1_h; }
-  // normalised width i enters every cumsum j > i;  then the softmax Jacobian and the 1/sqrt(C) scale (modules.py:801-802)
+  const float gk_w = 2.f * TAIL * (g_cw - g_w), gk1_w = 2.f * TAIL * g_w, gk_h = 2.f * TAIL * (g_ch - g_h), gk1_h = 2.f * TAIL * g_h;
+  // normalised width i enters every cumsum j > i; then the softmax Jacobian and the 1/sqrt(C) scale (modules.py:801-802)
   float gsw[NB], gsh[NB], dotw = 0.f, doth = 0.f, runw = 0.f, runh = 0.f;
+#pragma unroll
   for (int i = NB - 1; i >= 0; --i) {
-    runw += gcs_w[i + 1]; runh += gcs_h[i + 1];
+    const int j = i + 1;                                              // gradient at cumsum_j, j in [1, K-1]
+    if (j <= NB - 1) {
+      if (j == k) { runw += gk_w; runh += gk_h; }
+      if (j == k + 1) { runw += gk1_w; runh += gk1_h; }
+    }
     gsw[i] = (1.f - MINBIN * NB) * runw; gsh[i] = (1.f - MINBIN * NB) * runh;
     dotw += gsw[i] * s.sw[i]; doth += gsh[i] * s.sh[i];
   }
+#pragma unroll
   for (int i = 0; i < NB; ++i) { gp[i] = s.sw[i] * (gsw[i] - dotw) * inv_sqrt_c; gp[NB + i] = s.sh[i] * (gsh[i] - doth) * inv_sqrt_c; }
-  if (k >= 1) gp[2 * NB + k - 1] += G_d0 * sigmoidf_(p[2 * NB + k - 1]);
-  if (k + 1 <= NB - 1) gp[2 * NB + k] += G_d1 * sigmoidf_(p[2 * NB + k]);
+  const float g_u0 = k >= 1 ? G_d0 * sigmoidf_(s.u0) : 0.f, g_u1 = k + 1 <= NB - 1 ? G_d1 * sigmoidf_(s.u1) : 0.f;
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i) gp[2 * NB + i] = (i == k - 1 ? g_u0 : 0.f) + (i == k ? g_u1 : 0.f);
 }
 
 constexpr int SPR = 32;                       // rows per workgroup of the spline kernels
@@ -468,7 +514,10 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_fwd_kernel(
       if (on) {
         Spline s;
         const float x1 = zin[(size_t)m * 2 + 1];
-        spline_setup(Ps[r], x1, rsqrtf((float)PC), s);
+        float p[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) p[i] = Ps[r][i];
+        spline_setup<false>(p, x1, rsqrtf((float)PC), s);
         spline_eval(s, x1, y1, lad);
         y0 = zin[(size_t)m * 2];
       }
@@ -495,6 +544,7 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_bwd_kernel(
   if (tid < SPR) {
     const int r = tid, m = m0 + r;
     float gp[32];
+#pragma unroll
     for (int i = 0; i < 32; ++i) gp[i] = 0.f;
     if (m < R) {
       const bool on = rowmask[m] != 0.f;
@@ -502,15 +552,20 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_bwd_kernel(
       if (on) {
         Spline s;
         const float x1 = zin[(size_t)m * 2 + 1];
-        float p[NPAR];
-        for (int i = 0; i < NPAR; ++i) p[i] = par[(size_t)m * 32 + i];
-        spline_setup(p, x1, rsqrtf((float)PC), s);
+        float p[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 v4 = *reinterpret_cast<const float4*>(par + (size_t)m * 32 + 4 * i);
+          p[4 * i] = v4.x; p[4 * i + 1] = v4.y; p[4 * i + 2] = v4.z; p[4 * i + 3] = v4.w;
+        }
+        spline_setup<false>(p, x1, rsqrtf((float)PC), s);
         const float gy = dzout[(size_t)m * 2 + (flip ? 0 : 1)];
-        spline_grad(s, gy, sign * gacc[utt[m]], rsqrtf((float)PC), p, g1, gp);
+        spline_grad(s, gy, sign * gacc[utt[m]], rsqrtf((float)PC), g1, gp);
         g0 = dzout[(size_t)m * 2 + (flip ? 1 : 0)];
       }
       dzin[(size_t)m * 2] = g0; dzin[(size_t)m * 2 + 1] = g1;
     }
+#pragma unroll
     for (int i = 0; i < 32; ++i) Gs[r][i] = gp[i];
   }
   __syncthreads();
@@ -569,19 +624,12 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_inv_kernel(
     if (rowmask[m] != 0.f) {
       x0 = zin[(size_t)m * 2];
       const float y = zin[(size_t)m * 2 + 1];
+      float p[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) p[i] = Ps[tid][i];
       Spline s;
-      spline_setup(Ps[tid], 0.f, rsqrtf((float)PC), s);
-      if (y < -TAIL || y > TAIL) x1 = y;
-      else {
-        int k = -1;
-        for (int i = 0; i <= NB; ++i) k += (y >= (i == NB ? s.chh[i] + 1e-6f : s.chh[i])) ? 1 : 0;
-        k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
-        const float w = s.cw[k + 1] - s.cw[k], hh = s.chh[k + 1] - s.chh[k], de = hh / w, d0 = s.der[k], d1 = s.der[k + 1];
-        const float yy = y - s.chh[k], sd = d0 + d1 - 2.f * de;
-        const float a = yy * sd + hh * (de - d0), b = hh * d0 - yy * sd, c = -de * yy;
-        const float root = (2.f * c) / (-b - sqrtf(b * b - 4.f * a * c));
-        x1 = root * w + s.cw[k];
-      }
+      spline_setup<true>(p, y, rsqrtf((float)PC), s);
+      x1 = spline_inverse(s, y);
     }
     zout[(size_t)m * 2] = x0; zout[(size_t)m * 2 + 1] = x1;
   }
@@ -708,6 +756,19 @@ __global__ __launch_bounds__(256) void gt_rows_gather_tokens_kernel(const bf16_t
   *reinterpret_cast<uint4*>(out + (size_t)m * (C8 * 8) + c) = v;
 }
 
+__global__ __launch_bounds__(256) void gt_rows_split3_kernel(const void* __restrict__ in, int ldi, int is_f32, bf16_t* __restrict__ out, int ldo,
+                                                             const float* __restrict__ rowmask, int R, int C)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * C) return;
+  const int m = idx / C, c = idx - m * C;
+  float v = is_f32 ? static_cast<const float*>(in)[(size_t)m * ldi + c] : bf2f(static_cast<const bf16_t*>(in)[(size_t)m * ldi + c]);
+  if (rowmask) v *= rowmask[m];
+  const bf16_t hi = f2bf(v);
+  bf16_t* o = out + (size_t)m * ldo;
+  o[c] = hi; o[C + c] = hi; o[2 * C + c] = f2bf(v - bf2f(hi));
+}
+
 #define GT_ST(s) static_cast<hipStream_t>(s)
 #define GT_RET() return gt_launch_status(__func__)
 inline int wg_rows(int R) { return (R + 4 * RPW - 1) / (4 * RPW); }
@@ -715,10 +776,16 @@ inline void fill_drop(float p, uint32_t& th, float& sc) { th = p > 0.f ? (uint32
 
 }  // namespace
 
+extern "C" int gt_rows_split3(const void* in, int ldi, int is_f32, void* out, int ldo, const float* rowmask, int R, int C, void* stream)
+{
+  if (!in || !out || R <= 0 || C <= 0 || ldo < 3 * C) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_split3_kernel, dim3((R * C + 255) / 256), dim3(256), 0, GT_ST(stream), in, ldi, is_f32, static_cast<bf16_t*>(out), ldo, rowmask, R, C);
+  GT_RET();
+}
 extern "C" int gt_dds_sep_fwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
                               const int32_t* utt, const float* rowmask, void* a1_bf16, int lda, int R, int C, int dilation, float eps, void* stream)
 {
-  if (!x || !w || !b || !gamma || !beta || !utt || !rowmask || !a1_bf16 || R <= 0 || dilation <= 0) return GT_E_INVAL;
+  if (!x || !w || !b || !gamma || !beta || !utt || !rowmask || !a1_bf16 || R <= 0 || dilation <= 0 || lda < 3 * C) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
   hipLaunchKernelGGL(gt_dds_sep_fwd_kernel, dim3(wg_rows(R)), dim3(256), 0, GT_ST(stream), x, ldx, w, b, gamma, beta, utt, rowmask,
                      static_cast<bf16_t*>(a1_bf16), lda, R, dilation, eps);

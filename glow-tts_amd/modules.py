@@ -20,9 +20,10 @@ class ConvP(nn.Module):
     """Parameters of a plain nn.Conv1d (state_dict keys `weight`, `bias`) + packed bf16 images."""
     weight_norm = False
 
-    def __init__(self, in_channels, out_channels, kernel_size, gate=False, zero_init=False):
+    def __init__(self, in_channels, out_channels, kernel_size, gate=False, zero_init=False, split3=False):
         super().__init__()
         self.in_channels, self.out_channels, self.kernel_size, self.gate = in_channels, out_channels, kernel_size, gate
+        self.split3 = split3                       # bf16x3 images (ops.PackedConv(split3=True)): near-fp32 1x1 GEMM
         w = torch.empty(out_channels, in_channels, kernel_size)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))                 # nn.Conv1d default init
         bound = 1 / math.sqrt(in_channels * kernel_size)
@@ -42,7 +43,7 @@ class ConvP(nn.Module):
 
     def _new_pc(self, Cout=None):
         return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device,
-                          norm_only=self.cat_slice is not None)
+                          norm_only=self.cat_slice is not None, split3=self.split3)
 
     def _ensure_pcs(self):
         if self._pc is None or self._pc.inv_norm.device != self.weight.device:
@@ -104,9 +105,10 @@ def _pack_one(pc, v, g):
     L = _lib.lib()
     v = v.detach().contiguous().float()
     gg = None if g is None else g.detach().reshape(-1).contiguous().float()
+    km = getattr(pc, "km", 1)
     _lib.check(L.gt_pack_conv_weights(_lib.ptr(v), _lib.ptr(gg), _lib.ptr(pc.fwd), _lib.ptr(pc.dgrad), _lib.ptr(pc.inv_norm),
-                                      pc.Cout, pc.Cin, pc.taps, max(pc.Np_f, pc.Cout), max(pc.Kp_f, pc.Cin),
-                                      max(pc.Np_d, pc.Cin), max(pc.Kp_d, pc.Cout), pc.flags,
+                                      pc.Cout, pc.Cin, pc.taps, max(pc.Np_f, pc.Cout), max(pc.Kp_f, km * pc.Cin),
+                                      max(pc.Np_d, pc.Cin), max(pc.Kp_d, km * pc.Cout), pc.flags,
                                       _lib.current_stream(v.device)), "gt_pack_conv_weights")
 
 
@@ -128,31 +130,37 @@ class _PackPlan:
         self.n = len(entries)
         self.key = tuple(e[0].data_ptr() for e in entries)
         self.keep = entries
+        self.tables = []                                 # (device table, n, rows, group8)
         if self.n == 0:
             return
-        arr = (_lib.PackDesc * self.n)()
-        row = 0
-        for d, (v, g, pc) in zip(arr, entries):
-            d.v, d.g = v.data_ptr(), (g.data_ptr() if g is not None else None)
-            d.pack_fwd = pc.fwd.data_ptr() if pc.fwd is not None else None
-            d.pack_dgrad = pc.dgrad.data_ptr() if pc.dgrad is not None else None
-            d.inv_norm = pc.inv_norm.data_ptr() if pc.inv_norm is not None else None
-            d.Cout, d.Cin, d.taps = pc.Cout, pc.Cin, pc.taps
-            d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, pc.flags, row
-            row += pc.Cout
-        self.rows = row
-        # 8 output channels per workgroup (coalesced 16-byte stores of both images) when every conv allows it
-        self.group8 = int(all(pc.Cout % 8 == 0 and pc.Cin % 8 == 0 and pc.Cin * pc.taps <= 2304 for _, _, pc in entries))
         dev = entries[0][0].device
-        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        self.table = raw.to(dev)
+        # the bf16x3 (split) images are written by the one-row-per-workgroup kernel: a table of their own
+        for part in ([e for e in entries if not getattr(e[2], "split3", False)], [e for e in entries if getattr(e[2], "split3", False)]):
+            if not part:
+                continue
+            arr = (_lib.PackDesc * len(part))()
+            row = 0
+            for d, (v, g, pc) in zip(arr, part):
+                d.v, d.g = v.data_ptr(), (g.data_ptr() if g is not None else None)
+                d.pack_fwd = pc.fwd.data_ptr() if pc.fwd is not None else None
+                d.pack_dgrad = pc.dgrad.data_ptr() if pc.dgrad is not None else None
+                d.inv_norm = pc.inv_norm.data_ptr() if pc.inv_norm is not None else None
+                d.Cout, d.Cin, d.taps = pc.Cout, pc.Cin, pc.taps
+                d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, pc.flags, row
+                row += pc.Cout
+            # 8 output channels per workgroup (coalesced 16-byte stores of both images) when every conv allows it
+            group8 = int(all(pc.Cout % 8 == 0 and pc.Cin % 8 == 0 and pc.Cin * pc.taps <= 2304 and not getattr(pc, "split3", False)
+                             for _, _, pc in part))
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.tables.append((raw.to(dev), len(part), row, group8))
 
     def run(self):
         if self.n == 0:
             return
         dev = self.keep[0][0].device
-        _lib.check(_lib.lib().gt_pack_conv_weights_multi(_lib.ptr(self.table), self.n, self.rows, self.group8, _lib.current_stream(dev)),
-                   "gt_pack_conv_weights_multi")
+        for table, n, rows, group8 in self.tables:
+            _lib.check(_lib.lib().gt_pack_conv_weights_multi(_lib.ptr(table), n, rows, group8, _lib.current_stream(dev)),
+                       "gt_pack_conv_weights_multi")
 
 
 def prepare_all(module):

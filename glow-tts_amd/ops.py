@@ -332,25 +332,30 @@ class PackSliceN:
 class PackedConv:
     """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing (row-major [taps][Np][Kp])."""
 
-    def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False):
+    def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False, split3=False):
         """norm_only: only the per-row 1/||v|| is wanted (the weight itself is packed elsewhere, e.g. into the
-        K-concatenated skip GEMM of a WN): no bf16 images."""
+        K-concatenated skip GEMM of a WN): no bf16 images.
+        split3: bf16x3 images ([w_hi; w_lo; w_hi] along the reduction axis, gt_pack_conv_weights flag 8) for a near-fp32
+        product against [x_hi | x_hi | x_lo] activations — the stochastic predictors' 1x1 convs."""
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, taps, gate
+        self.split3 = bool(split3)
+        self.km = 3 if split3 else 1                # reduction-axis multiplier of the packed images
         self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
         self.fwd = self.dgrad = None
         self.Kp_f = self.Np_f = self.Kp_d = self.Np_d = 0
         if norm_only:
             return
-        self.Kp_f = _round_up(Cin, 64)
+        assert not (split3 and (gate or taps != 1))
+        self.Kp_f = _round_up(self.km * Cin, 64)
         self.Np_f = Cout if gate else (_round_up(Cout, 128) if Cout % 128 == 0 else _round_up(Cout, 64))
-        self.Kp_d = _round_up(Cout, 64)
+        self.Kp_d = _round_up(self.km * Cout, 64)
         self.Np_d = _round_up(Cin, 128) if _round_up(Cin, 64) % 128 == 0 else _round_up(Cin, 64)
         self.fwd = torch.zeros(taps * self.Np_f * self.Kp_f, dtype=torch.int16, device=device)
         self.dgrad = torch.zeros(taps * self.Np_d * self.Kp_d, dtype=torch.int16, device=device)
 
     @property
     def flags(self):
-        return int(bool(self.gate))
+        return int(bool(self.gate)) + 8 * int(self.split3)
 
     def pack(self, v, g=None):
         """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""
@@ -374,10 +379,12 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
     L = _lib.lib()
     assert x.dtype == torch.bfloat16 and x.stride(1) == 1
     R = x.shape[0] if R is None else R
+    km = getattr(pc, "km", 1)                       # bf16x3 split images: x is [hi | hi | lo], three times as wide
     if dgrad:
-        N, Cin, Np, Kp, W = pc.Cin, pc.Cout, pc.Np_d, pc.Kp_d, pc.dgrad
+        N, Cin, Np, Kp, W = pc.Cin, km * pc.Cout, pc.Np_d, pc.Kp_d, pc.dgrad
     else:
-        N, Cin, Np, Kp, W = pc.Cout, pc.Cin, pc.Np_f, pc.Kp_f, pc.fwd
+        N, Cin, Np, Kp, W = pc.Cout, km * pc.Cin, pc.Np_f, pc.Kp_f, pc.fwd
+    assert x.shape[1] >= Cin, (x.shape, Cin)
     n_out = N // 2 if gate is True or gate == 1 else (2 * N if gate == 2 else N)
     if out is None:
         out = torch.empty(R, n_out, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)

@@ -30,11 +30,23 @@ def _st(dev):
     return _lib.current_stream(dev)
 
 
-def _bf16_rows(x, rc):
-    """fp32 rows -> bf16 rows (GEMM operand)"""
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.lib().gt_rows_f32_to_bf16(_lib.ptr(x), x.stride(0), _lib.ptr(out), out.stride(0), None, x.shape[0], x.shape[1],
-                                              _st(x.device)), "gt_rows_f32_to_bf16")
+def _bias_grad_f32(conv, dy, grads):
+    """bias gradient of a 1x1 conv from the fp32 output-gradient rows (column sums, gt_colsum): the bf16 copy that feeds
+    the weight-gradient GEMM would cost the bias ~2^-8 per summand for nothing"""
+    db = grad_accumulator(conv.bias)
+    _lib.check(_lib.lib().gt_colsum(_lib.ptr(dy), dy.stride(0), 1, _lib.ptr(db), dy.shape[0], dy.shape[1], _st(dy.device)), "gt_colsum")
+    grads[conv.bias] = db
+
+
+def _split3_rows(x, rc=None):
+    """fp32 (or bf16) rows [R, C] -> bf16x3 rows [R, 3C] = [hi | hi | lo]: the operand layout of the split (near-fp32) 1x1
+    GEMMs.  The predictors' spline flows amplify bf16 rounding of their conditioning chaotically (relative L2
+    errors > 1 on parameter gradients with plain bf16 operands, < 1e-2 with the split), so every 192x192 product here is
+    x_hi w_hi + x_hi w_lo + x_lo w_hi on the bf16 MFMA GEMM — three passes of a tiny GEMM instead of an fp32 kernel."""
+    R, C = x.shape
+    out = torch.empty(R, 3 * C, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.lib().gt_rows_split3(_lib.ptr(x), x.stride(0), int(x.dtype == torch.float32), _lib.ptr(out), 3 * C, None, R, C, _st(x.device)),
+               "gt_rows_split3")
     return out
 
 
@@ -51,7 +63,7 @@ class DilatedDepthSeparableConv(nn.Module):
             sep = ConvP(1, channels, kernel_size)            # depthwise: weight [C, 1, k] (groups = C, modules.py:710-712)
             sep.no_pack = True
             self.convs_sep.append(sep)
-            self.convs_1x1.append(ConvP(channels, channels, 1))
+            self.convs_1x1.append(ConvP(channels, channels, 1, split3=True))
             self.norms_1.append(LayerNorm(channels, eps=LN_EPS))
             self.norms_2.append(LayerNorm(channels, eps=LN_EPS))
 
@@ -74,20 +86,20 @@ def dds_fwd(rc, dds, x, train, seed, want_bf16=False):
     outb = None
     for i in range(dds.num_layers):
         sep, n1, c1, n2 = dds.convs_sep[i], dds.norms_1[i], dds.convs_1x1[i], dds.norms_2[i]
-        a1 = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        a1 = torch.empty(R, 3 * C, dtype=torch.bfloat16, device=dev)              # bf16x3: [hi | hi | lo]
         _lib.check(L.gt_dds_sep_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(sep.weight), _lib.ptr(sep.bias), _lib.ptr(n1.gamma), _lib.ptr(n1.beta),
-                                    _lib.ptr(utt), _lib.ptr(rc.rowmask), _lib.ptr(a1), C, R, C, dds.kernel_size ** i, LN_EPS, _st(dev)),
+                                    _lib.ptr(utt), _lib.ptr(rc.rowmask), _lib.ptr(a1), 3 * C, R, C, dds.kernel_size ** i, LN_EPS, _st(dev)),
                    "gt_dds_sep_fwd")
         h2 = conv_rows(a1, c1.pc, rc, bias=c1.bias, out_f32=True)
         out = torch.empty(R, C, dtype=torch.float32, device=dev)
         last = i == dds.num_layers - 1
-        if want_bf16 and last:
-            outb = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
         _lib.check(L.gt_dds_out_fwd(_lib.ptr(h2), _lib.ptr(x), x.stride(0), _lib.ptr(n2.gamma), _lib.ptr(n2.beta), _lib.ptr(rc.rowmask),
-                                    _lib.ptr(out), _lib.ptr(outb) if last else None, R, C, LN_EPS, float(p), int(seed + i),
+                                    _lib.ptr(out), None, R, C, LN_EPS, float(p), int(seed + i),
                                     _lib.ptr(ops.seed_word(dev)) if p > 0 else None, _st(dev)), "gt_dds_out_fwd")
         saved.append((x, a1, h2))
         x = out
+    if want_bf16:
+        outb = _split3_rows(x)
     return x, outb, (saved, p, seed)
 
 
@@ -102,12 +114,12 @@ def dds_bwd(rc, dds, saved_all, dy, grads):
         sep, n1, c1, n2 = dds.convs_sep[i], dds.norms_1[i], dds.convs_1x1[i], dds.norms_2[i]
         x, a1, h2 = saved[i]
         dg2, db2 = grad_accumulator(n2.gamma), grad_accumulator(n2.beta)
-        dh2 = torch.empty(R, C, dtype=torch.bfloat16, device=dev)
+        dh2 = torch.empty(R, 3 * C, dtype=torch.bfloat16, device=dev)             # bf16x3
         _lib.check(L.gt_dds_out_bwd(_lib.ptr(h2), _lib.ptr(dy), _lib.ptr(n2.gamma), _lib.ptr(n2.beta), _lib.ptr(rc.rowmask), _lib.ptr(dh2),
                                     _lib.ptr(dg2), _lib.ptr(db2), R, C, LN_EPS, float(p), int(seed + i),
                                     _lib.ptr(ops.seed_word(dev)) if p > 0 else None, _st(dev)), "gt_dds_out_bwd")
         grads[n2.gamma], grads[n2.beta] = dg2, db2
-        grads.update(conv_param_grads(c1, a1, dh2, R))
+        grads.update(conv_param_grads(c1, a1[:, :C], dh2[:, :C], R))               # weight gradient from the hi parts
         da1 = conv_rows(dh2, c1.pc, rc, dgrad=True, out_f32=True)
         dg1, db1 = grad_accumulator(n1.gamma), grad_accumulator(n1.beta)
         dh1 = torch.empty(R, C, dtype=torch.float32, device=dev)
@@ -279,9 +291,9 @@ class _PredictorBase(nn.Module):
         C = in_channels                                     # filter_channels = in_channels (models.py:223, 339, 413)
         self.in_channels, self.filter_channels, self.kernel_size, self.p_dropout, self.n_flows = C, C, kernel_size, p_dropout, n_flows
         self.gin_channels, self.lin_channels = gin_channels, lin_channels
-        self.pre = ConvP(C, C, 1)
+        self.pre = ConvP(C, C, 1, split3=True)
         self.convs = DilatedDepthSeparableConv(C, kernel_size, num_layers=3, dropout_p=p_dropout)
-        self.proj = ConvP(C, C, 1)
+        self.proj = ConvP(C, C, 1, split3=True)
         self.flows = nn.ModuleList([ElementwiseAffine(2)] + [ConvFlow(2, C, kernel_size, num_layers=3) for _ in range(n_flows)])
         self._step = 0
 
@@ -303,7 +315,8 @@ class _PredictorBase(nn.Module):
     # ---- shared pieces on rows ----------------------------------------------------------------------------------------
     def _cond_fwd(self, rc, xb, vec, train, seed):
         """xb: bf16 rows of the (detached) text-side features -> conditioning rows fp32 [R, C] (masked) + saved"""
-        x0 = conv_rows(xb, self.pre.pc, rc, bias=self.pre.bias, cond=None if vec is None else vec.detach().float().contiguous(),
+        xb3 = _split3_rows(xb)
+        x0 = conv_rows(xb3, self.pre.pc, rc, bias=self.pre.bias, cond=None if vec is None else vec.detach().float().contiguous(),
                        mask=True, out_f32=True)
         x1, x1b, sv = dds_fwd(rc, self.convs, x0, train, seed, want_bf16=True)
         xc = conv_rows(x1b, self.proj.pc, rc, bias=self.proj.bias, mask=True, out_f32=True)
@@ -311,13 +324,15 @@ class _PredictorBase(nn.Module):
 
     def _cond_bwd(self, rc, saved, dxc, grads, want_dvec):
         xb, sv, x1b = saved
-        R = dxc.shape[0]
-        dxcb = _bf16_rows(dxc, rc)
-        grads.update(conv_param_grads(self.proj, x1b, dxcb, R))
+        R, C = dxc.shape
+        dxcb = _split3_rows(dxc)
+        grads.update(conv_param_grads(self.proj, x1b[:, :C], dxcb[:, :C], R, want_bias=False))
+        _bias_grad_f32(self.proj, dxc, grads)
         dx1 = conv_rows(dxcb, self.proj.pc, rc, dgrad=True, out_f32=True, mask=True)
         dx0 = dds_bwd(rc, self.convs, sv, dx1, grads)
-        dx0b = _bf16_rows(dx0, rc)
-        grads.update(conv_param_grads(self.pre, xb, dx0b, R))
+        dx0b = _split3_rows(dx0)
+        grads.update(conv_param_grads(self.pre, xb, dx0b[:, :C], R, want_bias=False))
+        _bias_grad_f32(self.pre, dx0, grads)
         return ops.cond_grad(rc, dx0) if want_dvec else None
 
     def _reverse_rows(self, rc, xb, vec, noise_rows):
@@ -367,7 +382,7 @@ class StochasticDurationPredictor(_PredictorBase):
         self.post_pre = ConvP(1, C, 1)
         self.post_pre.no_pack = True
         self.post_convs = DilatedDepthSeparableConv(C, kernel_size, num_layers=3, dropout_p=p_dropout)
-        self.post_proj = ConvP(C, C, 1)
+        self.post_proj = ConvP(C, C, 1, split3=True)
         self.post_flows = nn.ModuleList([ElementwiseAffine(2)] + [ConvFlow(2, C, kernel_size, num_layers=3) for _ in range(n_flows)])
         if gin_channels != 0:
             self.cond = nn.Conv1d(gin_channels, C, 1)
@@ -410,8 +425,9 @@ class StochasticDurationPredictor(_PredictorBase):
         flows_bwd(rc, self.post_flows, s_q, dzq, gacc, dsum, grads)
         dxc += dsum
         # h = post_proj(post_convs(post_pre(w))) * mask
-        dhb = _bf16_rows(dsum, rc)
-        grads.update(conv_param_grads(self.post_proj, hw1b, dhb, R))
+        dhb = _split3_rows(dsum)
+        grads.update(conv_param_grads(self.post_proj, hw1b[:, :C], dhb[:, :C], R, want_bias=False))
+        _bias_grad_f32(self.post_proj, dsum, grads)
         dhw1 = conv_rows(dhb, self.post_proj.pc, rc, dgrad=True, out_f32=True, mask=True)
         dhw0 = dds_bwd(rc, self.post_convs, s_h, dhw1, grads)
         dwp, dbp = grad_accumulator(self.post_pre.weight), grad_accumulator(self.post_pre.bias)

@@ -143,7 +143,12 @@ int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
  * the norms are wanted).  Padding entries are not touched: zero the buffers once.
  * `gate` is a bit set: 1 = WaveNet-gate row interleave of the forward image ([32 tanh | 32 sigmoid] per 64 rows),
  * 2 = forward image in MFMA-fragment order [tap][n/32][k/16][lane = n%32 + 32*((k%16)/8)][k%8] (one 1-KB MFMA A-fragment per (n/32, k/16): the fused WaveNet-layer kernels),
- * 4 = the same for the data-gradient image (Np, Kp multiples of 32 / 16 then). */
+ * 4 = the same for the data-gradient image (Np, Kp multiples of 32 / 16 then),
+ * 8 = bf16x3 ("split") images for a near-fp32 product out of three bf16 MFMA passes: the reduction axis is K-concatenated
+ *     as [w_hi ; w_lo ; w_hi] (Kp >= 3*Cin resp. 3*Cout; w_hi = bf16(w), w_lo = bf16(w - w_hi)) and meets activations laid
+ *     out as [x_hi | x_hi | x_lo] (gt_rows_split3): x_hi w_hi + x_hi w_lo + x_lo w_hi.  The stochastic predictors' 1x1 convs
+ *     use it (their spline flows amplify bf16 rounding of the conditioning chaotically); not with 1, 2, 4;
+ *     only through the one-row-per-workgroup packing (group8 == 0). */
 int gt_pack_conv_weights(const float* v, const float* g, void* pack_fwd, void* pack_dgrad,
                          float* inv_norm, int Cout, int Cin, int taps,
                          int Np_fwd, int Kp_fwd, int Np_dgrad, int Kp_dgrad, int gate, void* stream);
@@ -345,11 +350,15 @@ int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const 
  * and their incoming gradient.
  *
  * DilatedDepthSeparableConv layer i (modules.py:726-734), dilation = kernel_size^i, kernel_size = 3:
- *   gt_dds_sep_fwd:  a1 = gelu(LayerNorm2(dwconv_d(x) + b))                -> bf16 rows, operand of the 1x1 conv (gt_conv_gemm_bf16)
+ *   gt_dds_sep_fwd:  a1 = gelu(LayerNorm2(dwconv_d(x) + b))                -> bf16x3 rows [R, 3C], operand of the split 1x1 GEMM
  *   gt_dds_out_fwd:  out = (x + dropout(gelu(LayerNorm2(h2)))) * mask       h2 = 1x1 conv output incl. bias (fp32 rows)
- *   gt_dds_out_bwd:  dy -> d h2 (bf16), d gamma2 / d beta2
+ *   gt_dds_out_bwd:  dy -> d h2 (bf16x3 rows [R, 3C]), d gamma2 / d beta2
  *   gt_dds_sep_bwd:  d a1 (fp32, from the 1x1 data-gradient GEMM) -> d h1, d gamma1 / d beta1   (h1 recomputed from x)
  *   gt_dds_dw_bwd:   dx = (dy + dwconv_d^T(d h1)) * mask, d w [C,3], d b [C] */
+/* bf16x3 operand layout for a split GEMM (gt_pack_conv_weights flag 8): out[m] = [hi | hi | lo] of in[m, :C]
+ * (in fp32: hi = bf16(x), lo = bf16(x - hi); in bf16: lo = 0), out bf16 [R, ldo >= 3C], rows masked by rowmask if given.
+ * gt_dds_sep_fwd's a1 and gt_dds_out_bwd's d h2 are written in this layout directly (lda / row pitch 3C). */
+int gt_rows_split3(const void* in, int ldi, int is_f32, void* out, int ldo, const float* rowmask, int R, int C, void* stream);
 int gt_dds_sep_fwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
                    const int32_t* utt, const float* rowmask, void* a1_bf16, int lda, int R, int C, int dilation, float eps, void* stream);
 int gt_dds_out_fwd(const float* h2, const float* x, int ldx, const float* gamma, const float* beta, const float* rowmask,

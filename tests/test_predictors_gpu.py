@@ -5,7 +5,7 @@ pinned to the reference's own modules by tests/golden/float_golden.npz: dds_*, s
 
 Tolerances: the 192x192 1x1 convs run in bf16 with fp32 accumulation, everything else (depthwise convs, LayerNorms, GELU,
 the 29-row proj, the spline, the likelihood sums) in fp32: activations 2e-2 of max-abs, nll 1e-2 relative, parameter
-gradients 6e-2 of max-abs (the decoder's bound)."""
+gradients 8e-2 of max-abs (bf16 operands of the weight-gradient GEMMs)."""
 import os
 import sys
 
@@ -42,7 +42,7 @@ def lens_mask(lengths, T):
     return (torch.arange(T)[None, :] < l[:, None]).unsqueeze(1).float()
 
 
-def _check_param_grads(mod, P, prefix, tol=6e-2, skip=()):
+def _check_param_grads(mod, P, prefix, tol=8e-2, skip=()):
     worst = ("", 0.0)
     n = 0
     for name, p in mod.named_parameters():
@@ -83,23 +83,39 @@ def test_dds_conv_module_fwd_bwd(built):
 
 
 def test_dds_dropout_replays_in_backward(built):
-    """train mode: the dropout mask of the forward is replayed by the backward (finite-difference check along one direction)."""
-    from glow_tts_amd import predictors
-    dds = fill_module(predictors.DilatedDepthSeparableConv(192, 3, 3, 0.5), "dds.").train().to(dev())
-    m = lens_mask([40, 17], 40).to(dev())
-    x = (torch.randn(2, 192, 40, device=dev()) * m).requires_grad_(True)
-    o1 = dds(x, m)
-    o2 = dds(x, m)
-    assert torch.equal(o1, o2)                                   # same seed word, same step seed: same mask (module-level call)
-    assert not torch.equal(o1, dds.eval()(x, m))
-    dds.train()
-    r = torch.randn_like(o1) * m
-    (o1 * r).sum().backward()
-    d = torch.randn_like(x) * m * 5e-2
-    with torch.no_grad():
-        fd = ((dds(x + d, m) - dds(x - d, m)) * r).sum().item() / 2
-    an = (x.grad * d).sum().item()
-    assert abs(fd - an) <= 0.1 * max(1.0, abs(an)), (fd, an)
+    """The dropout of modules.py:733 inside gt_dds_out_fwd is a counter-based mask of (seed, row, channel): the mask read
+    off the forward (train output vs evaluation output) is exactly the one gt_dds_out_bwd applies — d h2 equals autograd
+    through x + mask / (1 - p) * gelu(LayerNorm(h2)) with that mask (fp32 kernels: 1e-4)."""
+    import torch.nn.functional as F
+    from glow_tts_amd import _lib, ops
+    L = _lib.lib()
+    R_, C, p, seed = 70, 192, 0.5, 1234
+    g = torch.Generator().manual_seed(2)
+    h2 = torch.randn(R_, C, generator=g).to(dev()); x = torch.randn(R_, C, generator=g).to(dev()); dy = torch.randn(R_, C, generator=g).to(dev())
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev()); beta = (0.1 * torch.randn(C, generator=g)).to(dev())
+    mask = torch.ones(R_, device=dev()); mask[:3] = 0; mask[40:44] = 0
+    st = _lib.current_stream(dev())
+    outs = []
+    for pp in (p, 0.0):
+        o = torch.empty(R_, C, device=dev())
+        _lib.check(L.gt_dds_out_fwd(_lib.ptr(h2), _lib.ptr(x), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mask), _lib.ptr(o), None, R_, C, 1e-5,
+                                    pp, seed, None, st), "gt_dds_out_fwd")
+        outs.append(o)
+    y_eval = outs[1] - x * mask[:, None]
+    keep = ((outs[0] - x * mask[:, None]).abs() > 0) | (y_eval.abs() < 1e-12)
+    frac = keep[mask.bool()].float().mean().item()
+    assert 0.42 < frac < 0.58, frac
+    assert torch.allclose(outs[0], (x + keep * y_eval * 2.0) * mask[:, None], atol=1e-5)
+    hh = h2.clone().requires_grad_(True)
+    ref = (x + keep * 2.0 * F.gelu(F.layer_norm(hh, (C,), gamma, beta, 1e-5))) * mask[:, None]
+    (ref * dy).sum().backward()
+    dh = torch.empty(R_, 3 * C, dtype=torch.bfloat16, device=dev())
+    dg, db = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    _lib.check(L.gt_dds_out_bwd(_lib.ptr(h2), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mask), _lib.ptr(dh), _lib.ptr(dg), _lib.ptr(db),
+                                R_, C, 1e-5, p, seed, None, st), "gt_dds_out_bwd")
+    got = dh[:, :C].float() + dh[:, 2 * C:].float()                   # bf16x3 layout: hi + lo
+    assert torch.equal(dh[:, :C], dh[:, C:2 * C])
+    assert relerr(got, hh.grad) < 1e-4, relerr(got, hh.grad)
 
 
 @pytest.mark.parametrize("which", ["sdp", "spp", "sep"])
@@ -265,7 +281,7 @@ def test_cfg5_trainer_eager_and_graph_steps(built):
     pitch / energy predictors included; the predictors' noise is drawn inside the step, so the two are not compared
     number by number): finite losses, one Adam step per step(), every predictor / front-end parameter moves."""
     from glow_tts_amd import train
-    cfg = dict(CFG5, n_blocks_dec=2, n_layers_enc=2, p_dropout=0.0, p_dropout_dec=0.0)
+    cfg = dict(CFG5, n_blocks_dec=2, n_layers_enc=2, p_dropout=0.0, p_dropout_dec=0.0, n_lang=10)
 
     def make():
         torch.manual_seed(0)
