@@ -431,8 +431,10 @@ class FlowGenerator(nn.Module):
             raise ValueError("use_emo_embeds: forward needs g, emo [b] and emo_cartesian [b, 3] (models.py:1018-1042)")
         emos_proj = self.emo_proj(self.emo_id_proj(emo))
         intens = self.emo_VAD_inten_proj(emo_cartesian[:, :1])
-        ele = self.elevation_emb(torch.bucketize(emo_cartesian[:, 1].contiguous(), self.elevation_bins))
-        azi = self.azimuth_emb(torch.bucketize(emo_cartesian[:, 2].contiguous(), self.azimuth_bins))
+        # bucketize can return len(bins) for a coordinate above the last edge — one past the embedding table (the reference
+        # then fails with an index error / a device-side fault); such out-of-range coordinates share the last bucket here
+        ele = self.elevation_emb(torch.bucketize(emo_cartesian[:, 1].contiguous(), self.elevation_bins).clamp_(max=self.elevation_emb.num_embeddings - 1))
+        azi = self.azimuth_emb(torch.bucketize(emo_cartesian[:, 2].contiguous(), self.azimuth_bins).clamp_(max=self.azimuth_emb.num_embeddings - 1))
         style = self.sty_proj(torch.cat((ele, azi), dim=-1))
         emosty = self.emosty_layer_norm(F.softplus(torch.cat((emos_proj, style), dim=-1)))
         return torch.cat((g, intens + emosty), dim=-1).unsqueeze(-1)

@@ -629,11 +629,15 @@ def train_forward(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g=None, pit
                 attn=attn, logp=logp, l_length=l_length, l_mle=l_mle, loss=l_mle + torch.sum(l_length))
 
 
-def train_forward_full(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g, emo, emo_cartesian, pitch, energy, lids, noises):
+def train_forward_full(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g, emo, emo_cartesian, pitch, energy, lids, noises,
+                       x_for_predictors=None):
     """models.FlowGenerator.forward as the fork runs it for configs/base_blank_emo_lang_pitch.json (models.py:1007-1133):
     speaker / emotion front end, language embedding, TextEncoder, FlowSpecDecoder with the pitch / energy WaveNets, logp,
     MAS, StochasticDurationPredictor loss, x_feature = x @ attn, stochastic pitch / energy predictor losses, prior expansion.
     noises = (e_w [b,2,t_x], e_p [b,1,t_y], e_e [b,1,t_y]) replace the three torch.randn draws (models.py:288,383,457).
+    x_for_predictors: the text-encoder output the three predictors read (they detach it, models.py:262,365,439); a test may
+    hand in the product's own (bf16-stored) encoder output so that the predictors — whose spline flows are chaotically
+    sensitive to their conditioning — are compared on identical inputs.
     Returns the reference's 5-tuple entries by name plus the training loss of train_ms_emo_lang_pitch.py:295-306."""
     n_sqz = hp.get("n_sqz", 2)
     gv = emotion_speaker_vector(P, g, emo, emo_cartesian)                     # [b, gin, 1]
@@ -653,8 +657,9 @@ def train_forward_full(P, ids, x_lengths, y, y_lengths, maximum_path, hp, g, emo
         logp = logp_lattice(x_m, x_logs, z)
         attn = maximum_path(logp, attn_mask.squeeze(1)).unsqueeze(1).detach()
     w = attn.squeeze(1).sum(2).unsqueeze(1)
-    l_length = sdp_fwd(P, "encoder.proj_w.", x, x_mask, w, noises[0], g=gv, l=lv) / torch.sum(x_mask)
-    x_feature = torch.matmul(x, attn.squeeze(1))
+    xp = x if x_for_predictors is None else x_for_predictors
+    l_length = sdp_fwd(P, "encoder.proj_w.", xp, x_mask, w, noises[0], g=gv, l=lv) / torch.sum(x_mask)
+    x_feature = torch.matmul(xp, attn.squeeze(1))
     l_pitch = torch.sum(spp_fwd(P, "proj_pitch.", x_feature, z_mask, pitch_norm, noises[1], g=gv) / torch.sum(z_mask))
     l_energy = torch.sum(spp_fwd(P, "proj_energy.", x_feature, z_mask, energy_norm, noises[2], g=gv) / torch.sum(z_mask))
     z_m = torch.matmul(attn.squeeze(1).transpose(1, 2), x_m.transpose(1, 2)).transpose(1, 2)
