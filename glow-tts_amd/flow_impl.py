@@ -9,7 +9,7 @@ backward mirrors what autograd derives for the reference modules:
 import torch
 
 from . import _lib
-from .ops import RowsCtx, conv_rows, grad_accumulator, seed_word, zeros_small  # noqa: F401
+from .ops import KERNEL_TIMER, RowsCtx, conv_rows, grad_accumulator, seed_word, zeros_small  # noqa: F401
 
 _SCRATCH = {}
 
@@ -128,14 +128,23 @@ def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
 
 
 # ----------------------------------------------------------------------------- WN
-def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
+def _fused_ok(wn):
+    """the one-kernel-per-layer path (csrc/wn_layer.hip): H = 192, k = 5, packed images exactly N rows high"""
+    if not getattr(wn, "fused", True) or wn.hidden_channels != 192 or wn.kernel_size != 5:
+        return False
+    pc = wn.in_layers[0].pc
+    return pc.Np_f == 2 * wn.hidden_channels and pc.Np_d == wn.hidden_channels
+
+
+def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
     it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
     Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
 
-    The gated activations of all layers live side by side in ONE [R, n*H] buffer: the residual 1x1 reads its
-    own window, and output = sum_i skip_i(acts_i) (modules.py:168-170) is a single K = n*H GEMM at the end
-    instead of n read-modify-write passes over an fp32 accumulator."""
+    One kernel per layer (gt_wn_layer_fwd: k=5 conv + gate + residual 1x1 on the gated tile).  The gated activations of
+    all layers live side by side in ONE [R, n*H] buffer, and output = sum_i skip_i(acts_i) (modules.py:168-170) is a
+    single K = n*H GEMM at the end instead of n read-modify-write passes over an fp32 accumulator."""
+    L = _lib.lib()
     R, H = h0.shape
     dev = h0.device
     n = wn.n_layers
@@ -143,9 +152,34 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
     xs, ts, ss = [h0], [], []
     acts_all = torch.empty(R, n * H, dtype=torch.bfloat16, device=dev)
     x = h0
+    fused = _fused_ok(wn)
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts = acts_all[:, i * H:(i + 1) * H]
+        last = i == n - 1
+        if fused:
+            il = wn.in_layers[i]
+            rs = None if last else wn.res_skip_layers[i]
+            t = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+            s = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+            xn = None if last else torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+            _ev = KERNEL_TIMER.start("wn_layer_fwd")
+            rcode = L.gt_wn_layer_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(il.pc.fwd), il.pc.Kp_f, _lib.ptr(il.bias),
+                                      _lib.ptr(ci), 0 if ci is None else ci.stride(0),
+                                      _lib.ptr(rc.row0) if (ci is not None and not cond_per_row) else None,
+                                      0 if (cond_per_row or ci is None) else rc.B, rc.Tp, _lib.ptr(rc.rowmask),
+                                      _lib.ptr(acts), acts.stride(0), _lib.ptr(t), _lib.ptr(s), H,
+                                      None if last else _lib.ptr(rs.pc_res.fwd), 0 if last else rs.pc_res.Kp_f,
+                                      None if last else rs.bias.data_ptr(), _lib.ptr(xn), H,
+                                      R, H, wn.kernel_size, float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None,
+                                      _lib.ptr(stamps[0]) if stamps else None, (stamps[1] + i) if stamps else 0, _st(dev))
+            KERNEL_TIMER.stop(_ev)
+            _lib.check(rcode, "gt_wn_layer_fwd")
+            ts.append(t); ss.append(s)
+            if not last:
+                x = xn
+                xs.append(x)
+            continue
         _, t, s = conv_rows(x, wn.in_layers[i].pc, rc, bias=wn.in_layers[i].bias, cond=ci, gate=True, out=acts,
                             drop_p=p, seed=seed + i, tag="in_layer_gate_conv", cond_per_row=cond_per_row)
         ts.append(t); ss.append(s)
@@ -162,6 +196,70 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
     """dskip: [R,H] bf16, the MASKED gradient of the wn output (= d skip of every layer, since out = skip*mask).
     Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond); dcond is [B, 2*H*n] (per-utterance sums) or, with
     cond_per_row, the per-frame gradient [R, 2*H*n] fp32."""
+    if _fused_ok(wn):
+        return _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row)
+    return _wn_bwd_unfused(rc, wn, saved, dskip, want_dcond, cond_per_row)
+
+
+def _dcond_store(rc, dcond, i, H, src, cond_per_row):
+    if cond_per_row:
+        dcond[:, 2 * H * i:2 * H * (i + 1)] = src
+    else:
+        rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
+
+
+def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
+    """One kernel per layer boundary (gt_wn_layer_bwd): the k=5 data gradient of layer i+1's in_layer gives dX_{i+1} (the
+    gradient at x_{i+1}); on that tile the residual 1x1's data gradient + the skip-path gradient + the gate backward of
+    layer i follow, and d pre_i leaves for the next launch and for the weight gradients."""
+    L = _lib.lib()
+    xs, ts, ss, acts_all, p, seed = saved
+    R, H = dskip.shape
+    dev = dskip.device
+    n = wn.n_layers
+    grads = {}
+    dcond = None if not want_dcond else torch.empty(R if cond_per_row else rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    need_c = want_dcond and p > 0                     # cond is added after the dropout: its gradient is d pre BEFORE the mask
+    # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
+    dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
+    # top layer: no residual output, d acts = skip path only
+    i = n - 1
+    dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
+    dpre_c = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if need_c else None
+    via = dacts_skip[:, i * H:(i + 1) * H]
+    _lib.check(L.gt_gate_bwd(_lib.ptr(via), via.stride(0), _lib.ptr(ts[i]), _lib.ptr(ss[i]), ts[i].stride(0), _lib.ptr(dpre), 2 * H,
+                             _lib.ptr(dpre_c), R, H, float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)),
+               "gt_gate_bwd")
+    grads.update(conv_param_grads(wn.res_skip_layers[i], acts_all[:, i * H:(i + 1) * H], dskip, R))
+    grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
+    if want_dcond:
+        _dcond_store(rc, dcond, i, H, dpre_c if need_c else dpre, cond_per_row)
+    dX = None                                          # gradient at x_{i+1} (None above the top layer)
+    for i in reversed(range(n - 1)):
+        rs = wn.res_skip_layers[i]
+        nxt = wn.in_layers[i + 1]
+        dXn = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+        dpre_i = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
+        dpre_ci = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if need_c else None
+        via = dacts_skip[:, i * H:(i + 1) * H]
+        _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(nxt.pc.dgrad), nxt.pc.Kp_d, _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
+                                     _lib.ptr(dXn), H, _lib.ptr(rs.pc_res.dgrad), rs.pc_res.Kp_d, _lib.ptr(via), via.stride(0),
+                                     _lib.ptr(ts[i]), _lib.ptr(ss[i]), H, _lib.ptr(dpre_i), _lib.ptr(dpre_ci), 2 * H, R, H, wn.kernel_size,
+                                     float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None, None, 0, _st(dev)),
+                   "gt_wn_layer_bwd")
+        acts = acts_all[:, i * H:(i + 1) * H]
+        grads.update(conv_param_grads(rs, acts, None, R, parts=[(dXn, 0, H), (dskip, H, H)]))
+        grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre_i, R))
+        if want_dcond:
+            _dcond_store(rc, dcond, i, H, dpre_ci if need_c else dpre_i, cond_per_row)
+        dX, dpre = dXn, dpre_i
+    # d x_0 = dgrad(in_layer_0) + (residual path), through the mask of x_0's producer
+    dh0 = conv_rows(dpre, wn.in_layers[0].pc, rc, dgrad=True, addend=dX, mask=True)
+    return dh0, grads, dcond
+
+
+def _wn_bwd_unfused(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
+    """round 1's launch sequence (two GEMM kernels per layer), kept as the reference the fused path is tested against"""
     L = _lib.lib()
     xs, ts, ss, acts_all, p, seed = saved
     R, H = dskip.shape
@@ -197,11 +295,7 @@ def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
                                      _lib.ptr(seed_word(dev)) if p > 0 else None, _st(dev)), "gt_gate_bwd")
         grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre, R))
         if want_dcond:
-            src = dpre_c if dpre_c is not None else dpre
-            if cond_per_row:
-                dcond[:, 2 * H * i:2 * H * (i + 1)] = src
-            else:
-                rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
+            _dcond_store(rc, dcond, i, H, dpre_c if dpre_c is not None else dpre, cond_per_row)
         # d x_i = dgrad(in_layer) + (residual path), then through the mask of x_i's producer
         dres = conv_rows(dpre, wn.in_layers[i].pc, rc, dgrad=True, addend=dres, mask=True)
     return dres, grads, dcond

@@ -343,6 +343,35 @@ int gt_coupling_rev(const float* out, const float* z, float* x, const float* row
 int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                   float* gnorm_sq, void* stream);
 
+/* ---- One WaveNet layer as ONE kernel (modules.WN.forward, one loop iteration, modules.py:151-170; csrc/wn_layer.hip).
+ * H = 192 hidden channels, k = 5, dilation 1; a workgroup owns 64 rows and all channels, so the 1x1 residual conv runs on the
+ * gated tile the k=5 conv just produced (and, in the backward, the gate backward on the tile the data gradient just produced).
+ * Weights are the packed images of gt_pack_conv_weights with Np == N exactly.
+ *
+ * gt_wn_layer_fwd:  x_in = drop(conv_k5(x) + bias_in) + cond;  T = tanh(x_in[:H]), S = sigmoid(x_in[H:]), acts = T*S
+ *                   (acts / T / S bf16 rows out, as gt_conv_gemm_bf16 gate == 1 writes them; same dropout hash);
+ *                   w_res != NULL:  x_next = (x + acts @ W_res^T + bias_res) * rowmask     (rows [0,H) of res_skip_i)
+ *   w_in: forward image [5][2H][K1p] with the gate interleave;  w_res: forward image [H][K2p] of the residual rows.
+ * gt_wn_layer_bwd:  dX = (conv_k5^T(dpre_next) + resid) * rowmask  -> dx [R, H]   (data gradient of the NEXT layer's in_layer,
+ *                   resid = gradient arriving at that layer's output through the residual path, NULL for the top layer);
+ *                   d acts = dX @ W_res + via_skip;  dpre = gate backward of (T, S) with the forward's dropout replayed,
+ *                   [R, 2H] = [d tanh-half | d sigmoid-half];  dpre_c (optional): the same before the dropout mask
+ *                   (the gradient of the conditioning term, which is added after the dropout).
+ *   w_in_dgrad: data-gradient image [5][H][K1p >= 2H] of the next layer's in_layer;  w_res_dgrad: [H][K2p] of this layer's res rows.
+ * stamps (optional, bench.py): device uint64 pairs [2*slot] = min start / [2*slot+1] = max end of the launch in
+ * wall_clock64() ticks (100 MHz) — the kernel's duration inside a replayed HIP graph; init to ~0 / 0. */
+int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in, int K1p, const float* bias_in,
+                    const float* cond, int ldc, const int32_t* row0, int B, int Tp, const float* rowmask,
+                    void* acts, int ldacts, void* gate_t, void* gate_s, int ldts,
+                    const void* w_res, int K2p, const float* bias_res, void* x_next, int ldxn,
+                    int R, int H, int taps, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
+                    unsigned long long* stamps, int stamp_slot, void* stream);
+int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad, int K1p, const void* resid, int ldres,
+                    const float* rowmask, void* dx, int lddx, const void* w_res_dgrad, int K2p,
+                    const void* via_skip, int ldvs, const void* gate_t, const void* gate_s, int ldts,
+                    void* dpre, void* dpre_c, int lddp, int R, int H, int taps, float drop_p, uint32_t drop_seed,
+                    const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, void* stream);
+
 /* ---- Stochastic duration / pitch / energy predictors (models.py:217-481, modules.py:683-819,
  * transforms.py:12-202) on the rows layout.  C = 192 (filter_channels = in_channels, models.py:223).  `utt` is the
  * int32 utterance index of every row ([R]); rows with rowmask == 0 are zero on input and on output.  Gradient outputs

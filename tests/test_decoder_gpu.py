@@ -421,3 +421,50 @@ def test_decoder_full_size_cfg3_batch(built):
     """cfg 3 (configs/base_blank.json shapes): B = 32, T_y <= 872."""
     rows = _full_size_case(32, 872, seed=77, n_check=2)
     assert rows > 8000
+
+
+@pytest.mark.parametrize("mode", ["plain", "speaker", "per_row"])
+def test_fused_wn_layer_kernels_match_the_two_kernel_path(built, mode):
+    """gt_wn_layer_fwd / gt_wn_layer_bwd (one kernel per WaveNet layer: k=5 conv + gate + residual 1x1, and the mirror in
+    the backward) against round 1's launch sequence (gate conv kernel + 1x1 GEMM kernel per layer) on the same weights,
+    inputs and dropout seeds (train mode, p = 0.05: the masks are the same counter hash): outputs, saved T / S, input
+    gradient, conditioning gradient and every parameter gradient, ragged rows with R not a multiple of 64."""
+    from glow_tts_amd import flow_impl, modules, ops, wgrad
+    H, n = 192, 4
+    gin = 256 if mode == "speaker" else 0
+    wn = fill_module(modules.WN(160, H, 5, 1, n, gin, 0.05), "wn.").to(dev())
+    modules.prepare_all(wn)
+    lens = [70, 33, 1, 64]
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev())
+    rc = ops.RowsCtx(lt, 70, lengths_host=lens, round_to=8)
+    assert rc.R % 64 != 0
+    g = torch.Generator().manual_seed(12)
+    h0 = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    dskip = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    cond = None
+    if mode == "speaker":
+        cond = (torch.randn(rc.B, 2 * H * n, generator=g) * 0.3).to(dev())
+    elif mode == "per_row":
+        cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
+    res = []
+    for fused in (True, False):
+        wn.fused = fused
+        out, saved = flow_impl.wn_fwd(rc, wn, h0, cond, True, 77, cond_per_row=mode == "per_row")
+        with wgrad.WgradQueue(dev(), site=wn):
+            dh0, grads, dcond = flow_impl.wn_bwd(rc, wn, saved, dskip, want_dcond=cond is not None, cond_per_row=mode == "per_row")
+        torch.cuda.synchronize()
+        res.append((out.float(), [t.float() for t in saved[1]], [s.float() for s in saved[2]], saved[3].float(), dh0.float(),
+                    None if dcond is None else dcond.clone(), {id(k): v.float().clone() for k, v in grads.items()}))
+    wn.fused = True
+    (o1, t1, s1, a1, d1, c1, g1), (o2, t2, s2, a2, d2, c2, g2) = res
+    valid = rc.rowmask.bool()
+    assert relerr(o1[valid], o2[valid]) < 1e-2
+    for u, v in zip(t1 + s1, t2 + s2):
+        assert (u[valid] - v[valid]).abs().max().item() < 2e-2          # bf16 x_i differ by an ulp here and there -> gate inputs move
+    assert relerr(a1[valid], a2[valid]) < 2e-2
+    assert relerr(d1[valid], d2[valid]) < 2e-2, relerr(d1[valid], d2[valid])
+    if c1 is not None:
+        assert relerr(c1, c2) < 2e-2, relerr(c1, c2)
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        assert relerr(g1[k], g2[k]) < 2e-2, relerr(g1[k], g2[k])

@@ -304,3 +304,62 @@ def test_train_forward_backward_vs_oracle(built, Tx, Ty, xl, yl, ragged, gin):
     worst.sort(reverse=True)
     print("worst grad errors:", worst[:5])
     assert not bad, bad
+
+
+@pytest.mark.parametrize("T,ragged", [(150, False), (161, True), (200, False), (200, True), (256, True), (300, True), (384, False), (400, True)])
+def test_attention_keeps_to_its_rows_in_merged_buffers(built, T, ragged):
+    """q / k / v as windows of ONE [R, 3C] buffer and dq / dk / dv as windows of one gradient buffer (ld = 3C: how the encoder
+    calls the kernels since round 1's `4715eb8`), each EXACTLY R rows long and embedded between guard rows: NaN guards around
+    every input (a read outside the R rows poisons the output), canary guards around every output (a write outside them is
+    seen), for every kernel variant by length (<= 160, <= 256, <= 384 MFMA; generic above), last utterance full length and,
+    ragged, the last utterance owning the rounding rows.  This is the addressing audit of the round-1 memory fault
+     as a test: results must equal the same call on separately allocated, generously padded buffers."""
+    from glow_tts_amd import _lib, ops
+    L = _lib.lib()
+    H, D, C, win, GUARD = 2, 96, 192, 4, 8
+    lens = [T - 7, 1, T]                                             # the LAST utterance is the longest
+    lens_t = torch.tensor(lens, dtype=torch.int32, device=dev())
+    rc = ops.RowsCtx(lens_t, T, lengths_host=lens, round_to=128) if ragged else ops.RowsCtx(lens_t, T)
+    R_ = rc.R
+    g = torch.Generator().manual_seed(T + int(ragged))
+    qkv = (torch.randn(R_, 3 * C, generator=g) * 0.5).to(dev()) * rc.rowmask[:, None]
+    do = (torch.randn(R_, C, generator=g)).to(dev()) * rc.rowmask[:, None]
+    Ek = (torch.randn(2 * win + 1, D, generator=g) * 0.1).to(dev()); Ev = (torch.randn(2 * win + 1, D, generator=g) * 0.1).to(dev())
+    st = _lib.current_stream(dev())
+    row0 = _lib.ptr(rc.row0)
+
+    def guarded(t, fill):
+        """t [R, n] -> a [GUARD + R + GUARD, n] buffer with `fill` in the guard rows; returns (buffer, view of the middle)"""
+        buf = torch.full((R_ + 2 * GUARD, t.shape[1]), fill, dtype=t.dtype, device=dev())
+        buf[GUARD:GUARD + R_] = t
+        return buf, buf[GUARD:GUARD + R_]
+
+    def run(guard):
+        nan, can = (float("nan"), 777.0) if guard else (0.0, 0.0)
+        qb, qv = guarded(qkv.to(torch.bfloat16), nan)
+        dob, dov = guarded(do.to(torch.bfloat16), nan)
+        ob, ov = guarded(torch.zeros(R_, C, dtype=torch.bfloat16, device=dev()), can)
+        db, dv_ = guarded(torch.zeros(R_, 3 * C, dtype=torch.bfloat16, device=dev()), can)
+        P = torch.empty(rc.B, H, T, T, dtype=torch.float32, device=dev())
+        q, k, v = qv[:, :C], qv[:, C:2 * C], qv[:, 2 * C:]
+        _lib.check(L.gt_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 3 * C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(ov), C,
+                                 _lib.ptr(P), rc.B, T, rc.Tp, row0, H, D, win, 0.0, 0, None, st), "gt_attn_fwd")
+        wsb = L.gt_attn_bwd_workspace_bytes(rc.B, T, H)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev())
+        dEk, dEv = torch.zeros_like(Ek), torch.zeros_like(Ev)
+        dq, dk, dvv = dv_[:, :C], dv_[:, C:2 * C], dv_[:, 2 * C:]
+        _lib.check(L.gt_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 3 * C, _lib.ptr(Ek), _lib.ptr(Ev), _lib.ptr(rc.lengths), _lib.ptr(dov), C,
+                                 _lib.ptr(P), _lib.ptr(ws), wsb, _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dvv), 3 * C, _lib.ptr(dEk), _lib.ptr(dEv),
+                                 rc.B, T, rc.Tp, row0, H, D, win, 0.0, 0, None, st), "gt_attn_bwd")
+        torch.cuda.synchronize()
+        return ob, db, dEk, dEv
+
+    ob, db, dEk, dEv = run(True)
+    for buf in (ob, db):                                             # canaries intact: nothing was written outside the R rows
+        assert (buf[:GUARD].float() == 777.0).all() and (buf[GUARD + R_:].float() == 777.0).all()
+    assert torch.isfinite(ob[GUARD:GUARD + R_].float()).all() and torch.isfinite(db[GUARD:GUARD + R_].float()).all()   # no NaN guard row was read
+    assert torch.isfinite(dEk).all() and torch.isfinite(dEv).all()
+    ob0, db0, dEk0, dEv0 = run(False)
+    assert torch.equal(ob[GUARD:GUARD + R_], ob0[GUARD:GUARD + R_]) and torch.equal(db[GUARD:GUARD + R_], db0[GUARD:GUARD + R_])
+    assert torch.allclose(dEk, dEk0, rtol=1e-3, atol=1e-4) and torch.allclose(dEv, dEv0, rtol=1e-3, atol=1e-4)
+    assert db[GUARD:GUARD + R_].float().abs().max().item() > 0
