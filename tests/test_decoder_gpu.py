@@ -212,7 +212,8 @@ def test_infer_generates_mel_through_the_reverse_flow(built):
     ids = torch.randint(1, 148, (2, 19), generator=g); xl = torch.tensor([19, 11])
     ids = ids * (torch.arange(19)[None, :] < xl[:, None])
     gen = gen.to(dev())
-    (y, z_m, z_logs, ld, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_) = gen.infer(ids.to(dev()), xl.to(dev()), noise_scale=0.0)
+    (y, z_m, z_logs, ld, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_), (pit, ene) = gen.infer(ids.to(dev()), xl.to(dev()), noise_scale=0.0)
+    assert pit is None and ene is None                               # models.py:1231: the 4-tuple of the reference's infer
     assert ld is None and torch.isfinite(y).all() and z_logs.abs().max().item() == 0
     dur = torch.ceil(torch.exp(logw) * x_mask).squeeze(1).cpu()
     assert torch.equal(attn.squeeze(1).sum(-1).cpu(), dur)

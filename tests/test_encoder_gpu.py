@@ -335,7 +335,7 @@ def test_attention_keeps_to_its_rows_in_merged_buffers(built, T, ragged):
         return buf, buf[GUARD:GUARD + R_]
 
     def run(guard):
-        nan, can = (float("nan"), 777.0) if guard else (0.0, 0.0)
+        nan, can = (float("nan"), 768.0) if guard else (0.0, 0.0)
         qb, qv = guarded(qkv.to(torch.bfloat16), nan)
         dob, dov = guarded(do.to(torch.bfloat16), nan)
         ob, ov = guarded(torch.zeros(R_, C, dtype=torch.bfloat16, device=dev()), can)
@@ -356,7 +356,7 @@ def test_attention_keeps_to_its_rows_in_merged_buffers(built, T, ragged):
 
     ob, db, dEk, dEv = run(True)
     for buf in (ob, db):                                             # canaries intact: nothing was written outside the R rows
-        assert (buf[:GUARD].float() == 777.0).all() and (buf[GUARD + R_:].float() == 777.0).all()
+        assert (buf[:GUARD].float() == 768.0).all() and (buf[GUARD + R_:].float() == 768.0).all()
     assert torch.isfinite(ob[GUARD:GUARD + R_].float()).all() and torch.isfinite(db[GUARD:GUARD + R_].float()).all()   # no NaN guard row was read
     assert torch.isfinite(dEk).all() and torch.isfinite(dEv).all()
     ob0, db0, dEk0, dEv0 = run(False)

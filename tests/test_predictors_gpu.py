@@ -324,3 +324,20 @@ def _assert_moved(moved):
                 "encoder.proj_w.post_flows.0.log_scale", "proj_pitch.flows.1.convs.norms_1.0.gamma", "proj_energy.pre.weight",
                 "decoder.flows.2.wn_pitch.in_layers.0.weight_v"):
         assert key in moved, key
+
+
+def test_cfg5_infer_runs_the_predictors_in_reverse(built):
+    """FlowGenerator.infer for cfg 5 (models.py:1135-1231): speaker / emotion front end, the StochasticDurationPredictor in
+    reverse for the durations, predicted pitch / energy contours into the reverse decoder; the 4-tuple of the reference."""
+    from glow_tts_amd import models
+    cfg = dict(CFG5, n_blocks_dec=2, n_layers_enc=2)
+    gen = fill_module(models.FlowGenerator(n_vocab=187, out_channels=80, n_lang=10, **cfg), "").eval().to(dev())
+    ids, xl, y, yl, graw, emo, cart, pitch, energy, lid, _ = _cfg5_inputs(2, 15, 40, seed=2)
+    d = lambda v: v.to(dev())                                         # noqa: E731
+    gen.store_inverse()
+    (mel, z_m, z_logs, ld, z_mask), (x_m, x_logs, x_mask), (attn, logw, logw_), (pit, ene) = \
+        gen.infer(d(ids), d(xl), g=d(graw), emo=d(emo), emo_cartesian=d(cart), l=d(lid), noise_scale=0.5, length_scale=1.0)
+    Ty = mel.shape[2]
+    assert ld is None and mel.shape[:2] == (2, 80) and pit.shape == (2, Ty) and ene.shape == (2, Ty)
+    assert torch.isfinite(mel).all() and torch.isfinite(pit).all() and torch.isfinite(ene).all() and torch.isfinite(logw).all()
+    assert torch.equal(attn.squeeze(1).sum(1), z_mask.squeeze(1))            # every valid frame belongs to exactly one token
