@@ -216,6 +216,10 @@ __device__ __forceinline__ void pack_one_row(
     const int half = Cout >> 1;
     const int c = co < half ? co : co - half;
     pn = (c >> 5) * 64 + (co < half ? 0 : 32) + (c & 31);
+  } else if (gate & 16) {                       // [16 tanh | 16 sigmoid] per 32 packed rows: every MFMA block is self-contained
+    const int half = Cout >> 1;
+    const int c = co < half ? co : co - half;
+    pn = (c >> 4) * 32 + (co < half ? 0 : 16) + (c & 15);
   }
   // flag 2 / 4: forward / data-gradient image in MFMA-fragment order for gt_conv_gemm2_bf16:
   //   [tap][n / 32][k / 16][lane = n % 32 + 32 * ((k % 16) / 8)][k % 8]   (one 1-KB A-fragment per (n/32, k/16))
@@ -292,6 +296,7 @@ __device__ __forceinline__ void pack_rows8(
       const int co = co0 + rr;
       int pn = co;
       if (gate & 1) { const int half = Cout >> 1, c = co < half ? co : co - half; pn = (c >> 5) * 64 + (co < half ? 0 : 32) + (c & 31); }
+      else if (gate & 16) { const int half = Cout >> 1, c = co < half ? co : co - half; pn = (c >> 4) * 32 + (co < half ? 0 : 16) + (c & 15); }
       const bf16_t* t = tile + rr * n + (c8 * 8) * taps + tap;
       uint32_t u[4];
 #pragma unroll
@@ -435,6 +440,7 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
   if (pack_fwd && (Np_fwd < Cout || Kp_fwd < km * Cin)) return GT_E_INVAL;
   if (pack_dgrad && (Np_dgrad < Cin || Kp_dgrad < km * Cout)) return GT_E_INVAL;
   if ((gate & 1) && (Cout % 64)) return GT_E_UNSUPPORTED;
+  if ((gate & 16) && ((Cout % 32) || (gate & 1))) return GT_E_UNSUPPORTED;
   hipLaunchKernelGGL(gt_pack_conv_weights_kernel, dim3(Cout), dim3(256), 0, static_cast<hipStream_t>(stream),
                      v, g, static_cast<bf16_t*>(pack_fwd), static_cast<bf16_t*>(pack_dgrad), inv_norm,
                      Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate);

@@ -7,18 +7,27 @@
 // backward); every launch on the decoder's dependent chain cost ~10 us beyond its arithmetic.  Here a workgroup owns
 // 64 rows and ALL channels of them, so the second contraction runs on the tile the first one just produced:
 //
-//   forward   stage 1: x_in = conv_k5(x)           N = 2H = 384, K = 5 * 192      MFMA, 4 waves x (64 rows x 96 columns)
-//             epilogue: bias, dropout, cond, gate -> T, S, acts (HBM, for the backward) and acts -> LDS (bf16)
-//             stage 2: res = acts @ W_res^T         N = 192, K = 192               MFMA on the LDS tile
-//             epilogue: x_next = (x + res + b_res) * mask
-//   backward  stage 1: dX = conv_k5^T(d pre_{i+1}) N = 192, K = 5 * 384           data gradient of the NEXT layer's in_layer
+//   forward   stage 1: x_in = conv_k5(x)           N = 2H = 384, K = 5 * 192      4 waves x (64 rows x 96 columns)
+//             epilogue (in registers): bias, dropout, cond, gate -> T, S, acts (HBM, for the backward); acts -> LDS (bf16)
+//             stage 2: res = acts @ W_res^T         N = 192, K = 192               2 x 2 waves x (32 rows x 96 columns)
+//             epilogue (in registers): x_next = (x + res + b_res) * mask
+//   backward  stage 1: dX = conv_k5^T(d pre_{i+1}) N = 192, K = 5 * 384           2 (columns) x 2 (K halves) waves, partial
+//                                                                                  sums exchanged through LDS
 //             epilogue: dX = (dX + residual-path gradient) * mask -> HBM (the res conv's weight gradient reads it) and LDS
 //             stage 2: d acts_i = dX @ W_res_i      N = 192, K = 192
 //             epilogue: + skip-path gradient, gate backward with the forward's dropout replayed -> d pre_i [R, 2H]
 //
+// Operand paths.  MFMA A = weights: the packed images are in MFMA-FRAGMENT order (gt_pack_conv_weights flags 2 / 4: one
+// contiguous 1-KB fragment per (32 output channels, 16 k)), so a wave fetches exactly the fragments of its own columns
+// straight from L2 into registers with one fully coalesced 16-byte load per lane — the weights never pass through LDS,
+// no workgroup barrier is spent on them, and they are double-buffered one (slice, tap) step ahead in registers.  MFMA B =
+// activations: 68-row x 64-channel slices staged in LDS (double buffer, ONE barrier per K slice of 5 taps).  With this
+// split a 64-row tile moves each weight byte once per workgroup through the vector-memory path (737 KB per workgroup,
+// the same 64 B/clk/CU budget as its 47 MFLOP of MFMA issue), and LDS only carries the small activation operand.
+// The gate's packed column order is [16 tanh | 16 sigmoid] per 32-column MFMA block (pack flag 16): both halves of a
+// gate channel sit in the same lane's accumulators, so bias / dropout / cond / tanh * sigmoid run in registers.
+//
 // The skip half of res_skip stays what round 1 made it: ONE K = n*H GEMM per WaveNet over the layers' gated activations.
-// Weights stream L2 -> registers -> LDS double buffers (the packed images of gt_pack_conv_weights); activations keep the
-// rows layout (zero halo rows between utterances, so the 5 taps are 5 shifted row-block GEMMs with no boundary logic).
 #include "common.h"
 #include "../../include/glowtts_hip.h"
 
@@ -26,16 +35,17 @@ namespace {
 
 constexpr int H = 192;                        // hidden channels (configs/*.json hidden_channels_dec)
 constexpr int BM = 64;                        // rows per workgroup
-constexpr int BK = 64;                        // K slice
-constexpr int LDP = 72;                       // halfs per LDS operand row (64 + 8: conflict-free ds_read_b128 over 16 rows)
+constexpr int BK = 64;                        // K slice (activation channels per LDS stage)
+constexpr int LDP = 72;                       // halfs per LDS activation row (64 + 8: conflict-free ds_read_b128 over 16 rows)
 constexpr int TAPS = 5;
 constexpr int XROWS = BM + TAPS - 1;          // 68 activation rows per slice
+constexpr int XCH = (XROWS * 8 + 255) / 256;  // 16-byte activation chunks per thread per slice
 constexpr int AP = H + 8;                     // pitch (halfs) of the stage-2 activation tile
 
 struct WnArgs {
   const bf16_t* X; int ldx;                   // stage-1 operand rows (fwd: layer input [R, H]; bwd: d pre of the next layer [R, 2H])
-  const bf16_t* W1;                           // stage-1 packed weights [5][N1p][K1p]
-  const bf16_t* W2;                           // stage-2 packed weights [H][H(p)] (NULL: no second stage)
+  const bf16_t* W1;                           // stage-1 weights, fragment order [5][N/32][K/16][64 lanes][8]
+  const bf16_t* W2;                           // stage-2 weights, fragment order [H/32][H/16][64][8] (NULL: no second stage)
   const float* bias1; const float* bias2;     // fwd: in_layer bias [2H], res bias [H]
   const float* cond; int ldc; int B; const int32_t* row0; int Tp;     // fwd: conditioning of the gate (per utterance B > 0, per row B == 0)
   const float* rowmask;
@@ -46,9 +56,9 @@ struct WnArgs {
   const bf16_t* viaskip; int ldvs;            // bwd: skip-path gradient of the layer's acts [R, H]
   bf16_t* dpre; int lddp;                     // bwd out: [R, 2H]
   bf16_t* dpre_c;                             // bwd out (optional): the same BEFORE the dropout mask = gradient of the gate's cond term
-  int R, K1p, K2p;
+  int R;
   uint32_t drop_thresh, drop_seed; float drop_scale; const uint32_t* seed_dev;
-  // live timing of the dominant kernel inside a captured graph (bench.py): stamps[2*launch] = min start, [2*launch+1] = max end
+  // live timing of the dominant kernel inside a captured graph (bench.py): stamps[2*slot] = min start, [2*slot+1] = max end
   unsigned long long* stamps; int stamp_slot;
 };
 
@@ -61,306 +71,342 @@ __device__ __forceinline__ void stamp_end(const WnArgs& a)
   if (a.stamps && threadIdx.x == 0) atomicMax(a.stamps + 2 * a.stamp_slot + 1, (unsigned long long)wall_clock64());
 }
 
-// One K loop of an implicit GEMM on a 64-row tile: Y[64, N] = sum_tap sum_k Xs[row + tap, k] * W[tap][n][k].
-//   NW x MW waves (NW * MW == 4); a wave owns NBW 32-column blocks x MBW 32-row blocks.
-//   W image [taps][Np][Kp] row-major; the weight slice of step `it` and the activation slice of K-slice `sl` are fetched
-//   L2 -> registers while the MFMAs of the previous step run, then dropped into the other LDS buffer (one barrier per step).
-//   XS == true: activations come from global memory (rows m0 - 2 .. m0 + 65 of X, clamped), staged in Xs[2];
-//   XS == false: they are already in LDS (`Atile`, pitch AP, the whole K), taps == 1.
-template <int N, int NW, int MW, int NBW, int MBW, bool XS, int taps>
-__device__ __forceinline__ void gemm_tile(const bf16_t* __restrict__ W, int Np, int Kp,
-                                          const bf16_t* __restrict__ X, int ldx, int Kx, int R, int m0,
-                                          bf16_t* Ws, bf16_t* Xs, const bf16_t* Atile, f32x16_t (&acc)[NBW][MBW])
+__device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
 {
-  static_assert(NW * MW == 4 && NW * NBW * 32 == N && MW * MBW * 32 == BM, "wave tiling");
-  constexpr int WCH = N * 8 / 256;            // 16-byte weight chunks per thread per step
-  constexpr int XCH = (XROWS * 8 + 255) / 256;
-  constexpr int WS_HALFS = N * LDP, XS_HALFS = XROWS * LDP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave % NW, wm = wave / NW;
-  const int r = lane & 31, h = lane >> 5;
-  const int NS = Kp / BK, NIT = NS * taps;
-  const int padl = taps >> 1;
-  const int xrows = BM + taps - 1;
+  return *reinterpret_cast<const uint4*>(W + ((size_t)f * 64 + lane) * 8);
+}
+__device__ __forceinline__ bf16x8_t asfrag(const uint4& u) { return __builtin_bit_cast(bf16x8_t, u); }
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2bf(a, b), pack2bf(c, d)); }
+__device__ __forceinline__ void unpack4(const uint2& u, float (&v)[4])
+{
+  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+}
 
-  uint4 wreg[WCH], xreg[XCH];
-  auto load_w = [&](int it) {
-    const int slice = it / taps, tap = it - slice * taps;
+// activation slice `slice` (64 channels) of rows m0 - 2 .. m0 + 65 -> registers -> LDS
+__device__ __forceinline__ void x_load(const bf16_t* __restrict__ X, int ldx, int Kx, int R, int m0, int slice, uint4 (&xr)[XCH])
+{
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-      wreg[i] = *reinterpret_cast<const uint4*>(W + ((size_t)(tap * Np + row) * Kp + slice * BK + c8 * 8));
-    }
-  };
-  auto store_w = [&](int buf) {
+  for (int i = 0; i < XCH; ++i) {
+    const int chunk = threadIdx.x + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    int gm = m0 - (TAPS >> 1) + (row < XROWS ? row : XROWS - 1);
+    gm = gm < 0 ? 0 : (gm >= R ? R - 1 : gm);
+    const int ch = slice * BK + c8 * 8;
+    xr[i] = make_uint4(0, 0, 0, 0);
+    if (ch < Kx) xr[i] = *reinterpret_cast<const uint4*>(X + (size_t)gm * ldx + ch);
+  }
+}
+__device__ __forceinline__ void x_store(bf16_t* Xs, const uint4 (&xr)[XCH])
+{
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-      *reinterpret_cast<uint4*>(Ws + buf * WS_HALFS + row * LDP + c8 * 8) = wreg[i];
-    }
-  };
-  auto load_x = [&](int slice) {
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-      int gm = m0 - padl + (row < xrows ? row : xrows - 1);
-      gm = gm < 0 ? 0 : (gm >= R ? R - 1 : gm);
-      const int ch = slice * BK + c8 * 8;
-      xreg[i] = make_uint4(0, 0, 0, 0);
-      if (ch < Kx) xreg[i] = *reinterpret_cast<const uint4*>(X + (size_t)gm * ldx + ch);
-    }
-  };
-  auto store_x = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < XCH; ++i) {
-      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-      if (row < xrows) *reinterpret_cast<uint4*>(Xs + buf * XS_HALFS + row * LDP + c8 * 8) = xreg[i];
-    }
-  };
-
-#pragma unroll
-  for (int i = 0; i < NBW; ++i)
-#pragma unroll
-    for (int j = 0; j < MBW; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  load_w(0); store_w(0);
-  if (XS) { load_x(0); store_x(0); }
-  __syncthreads();
-
-  // Every prefetch below is unconditional (the last step / slice re-fetches itself into the buffer nobody reads again):
-  // staging registers that are defined on one side of a branch only end up in scratch memory.
-  for (int slice = 0; slice < NS; ++slice) {
-    if (XS) load_x(slice + 1 < NS ? slice + 1 : NS - 1);
-#pragma unroll
-    for (int tap = 0; tap < taps; ++tap) {
-      const int it = slice * taps + tap;
-      load_w(it + 1 < NIT ? it + 1 : NIT - 1);
-
-      const bf16_t* wsb = Ws + (it & 1) * WS_HALFS + (32 * NBW * wn + r) * LDP + 8 * h;
-      const bf16_t* xsb = XS ? Xs + (slice & 1) * XS_HALFS + (32 * MBW * wm + r + tap) * LDP + 8 * h
-                             : Atile + (32 * MBW * wm + r) * AP + slice * BK + 8 * h;
-      constexpr int XP = XS ? LDP : AP;
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8_t af[NBW], bfm[MBW];
-#pragma unroll
-        for (int bn = 0; bn < NBW; ++bn) af[bn] = *reinterpret_cast<const bf16x8_t*>(wsb + bn * 32 * LDP + ks * 16);
-#pragma unroll
-        for (int bm = 0; bm < MBW; ++bm) bfm[bm] = *reinterpret_cast<const bf16x8_t*>(xsb + bm * 32 * XP + ks * 16);
-#pragma unroll
-        for (int bn = 0; bn < NBW; ++bn)
-#pragma unroll
-          for (int bm = 0; bm < MBW; ++bm)
-            acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[bn], bfm[bm], acc[bn][bm], 0, 0, 0);
-      }
-      store_w((it + 1) & 1);
-      if (XS && tap == taps - 1) store_x((slice + 1) & 1);
-      __syncthreads();
-    }
+  for (int i = 0; i < XCH; ++i) {
+    const int chunk = threadIdx.x + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+    if (row < XROWS) *reinterpret_cast<uint4*>(Xs + row * LDP + c8 * 8) = xr[i];
   }
 }
 
-// accumulators -> fp32 LDS tile [BM][EP] (a lane's 16 values are 4 groups of 4 consecutive columns of one row)
-template <int NW, int NBW, int MBW>
-__device__ __forceinline__ void acc_to_lds(float* es, int EP, const f32x16_t (&acc)[NBW][MBW])
+// 1x1 stage on the LDS tile At [64][AP] (K = H): this wave's 32 rows (wm) x 96 columns (wn); weights W2 in fragment order.
+// The first half of the K steps is fetched by `s2_prefetch` (before the caller's epilogue, so the loads fly under it).
+constexpr int KK2 = H / 16;                   // 12 k-steps
+__device__ __forceinline__ void s2_prefetch(const bf16_t* __restrict__ W2, int wn, int lane, uint4 (&ring)[KK2 / 2][3])
 {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wn = wave % NW, wm = wave / NW, r = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int bm = 0; bm < MBW; ++bm)
+  for (int kk = 0; kk < KK2 / 2; ++kk)
 #pragma unroll
-    for (int bn = 0; bn < NBW; ++bn)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(&es[(32 * MBW * wm + 32 * bm + r) * EP + 32 * NBW * wn + 32 * bn + 8 * g + 4 * h]) =
-            make_float4(acc[bn][bm][4 * g], acc[bn][bm][4 * g + 1], acc[bn][bm][4 * g + 2], acc[bn][bm][4 * g + 3]);
+    for (int bn = 0; bn < 3; ++bn) ring[kk][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk, lane);
 }
-
-// LDS plan (bytes): stage-1 operands | epilogue tiles alias them once the K loop has drained
-constexpr int S1F_BYTES = 2 * (2 * H * LDP + XROWS * LDP) * 2;              // fwd stage 1: W [2][384][72] + X [2][68][72]
-constexpr int S1B_BYTES = 2 * (H * LDP + XROWS * LDP) * 2;                  // bwd stage 1: W [2][192][72] + X [2][68][72]
-constexpr int EP1 = 2 * H + 4, EP2 = H + 4;
-constexpr int ES1_BYTES = BM * EP1 * 4;                                     // [64][388] fp32
-constexpr int ES2_BYTES = BM * EP2 * 4;                                     // [64][196] fp32
-constexpr int AT_BYTES = BM * AP * 2;                                       // stage-2 activation tile bf16
-constexpr int W2_BYTES = 2 * H * LDP * 2;                                   // stage-2 weights [2][192][72]
-constexpr int FWD_LDS = (S1F_BYTES > ES1_BYTES + AT_BYTES ? S1F_BYTES : ES1_BYTES + AT_BYTES);
-constexpr int BWD_LDS = (S1B_BYTES > ES2_BYTES + AT_BYTES + 2 * 0 ? S1B_BYTES : ES2_BYTES + AT_BYTES) + W2_BYTES;
-
-__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8])
+__device__ __forceinline__ void s2_gemm(const bf16_t* __restrict__ W2, const bf16_t* At, int wn, int wm, int lane,
+                                        uint4 (&ring)[KK2 / 2][3], f32x16_t (&acc)[3])
 {
-  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
-  v[4] = bf2f(u.z & 0xffff); v[5] = bf2f(u.z >> 16); v[6] = bf2f(u.w & 0xffff); v[7] = bf2f(u.w >> 16);
-}
-__device__ __forceinline__ uint4 pack8(const float (&v)[8])
-{
-  return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[bn][e] = 0.0f;
+  const bf16_t* ab = At + (32 * wm + r) * AP + 8 * h;
+#pragma unroll
+  for (int kk = 0; kk < KK2; ++kk) {
+    const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn) {
+      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[kk % (KK2 / 2)][bn]), bfm, acc[bn], 0, 0, 0);
+      if (kk + KK2 / 2 < KK2) ring[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk + KK2 / 2, lane);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+constexpr int FWD_LDS = 2 * XROWS * LDP * 2 + BM * AP * 2;                  // X [2][68][72] + At [64][200] = 45 184 B
+
 template <bool RES>
-__global__ __launch_bounds__(256, 1) void gt_wn_layer_fwd_kernel(WnArgs a)
+__global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
   stamp_begin(a);
   if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * BM;
-  bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Xs = Ws + 2 * (2 * H) * LDP;
-  float* es = reinterpret_cast<float*>(smem);
-  bf16_t* At = reinterpret_cast<bf16_t*>(smem + ES1_BYTES);
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* At = Xs + 2 * XROWS * LDP;
+  constexpr int NS = H / BK, NIT = NS * TAPS, KS = H / 16, NBT = 2 * H / 32;  // 3 slices, 15 steps, 12 k-steps per tap, 12 column blocks
 
-  {
-    f32x16_t acc[3][2];
-    gemm_tile<2 * H, 4, 1, 3, 2, true, TAPS>(a.W1, 2 * H, a.K1p, a.X, a.ldx, H, a.R, m0, Ws, Xs, nullptr, acc);
-    acc_to_lds<4, 3, 2>(es, EP1, acc);
-  }
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+    for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
+
+  // weight fragments of step `it` (slice, tap): 4 k-steps x this wave's 3 column blocks
+  uint4 ring[2][4][3];
+  auto w_load = [&](int it, uint4 (&dst)[4][3]) {
+    const int slice = it / TAPS, tap = it - slice * TAPS;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = ldfrag(a.W1, (tap * NBT + 3 * wave + bn) * KS + slice * 4 + ks, lane);
+  };
+  uint4 xr[XCH];
+  x_load(a.X, a.ldx, H, a.R, m0, 0, xr);
+  w_load(0, ring[0]);
+  x_store(Xs, xr);
   __syncthreads();
 
-  // gate epilogue: a thread owns (row, 8 gate channels); packed columns are [32 tanh | 32 sigmoid] per 64
-  constexpr int CPR = H / 8;                                       // 24 chunks per row
 #pragma unroll
-  for (int j = 0; j < BM * CPR / 256; ++j) {
-    const int q = tid + 256 * j, row = q / CPR, c = (q - row * CPR) * 8;
-    const int m = m0 + row;
-    const float* et = &es[row * EP1 + (c >> 5) * 64 + (c & 31)];
-    const float4 t0 = *reinterpret_cast<const float4*>(et), t1 = *reinterpret_cast<const float4*>(et + 4);
-    const float4 s0 = *reinterpret_cast<const float4*>(et + 32), s1 = *reinterpret_cast<const float4*>(et + 36);
-    float pt[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w}, ps[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    float aa[8] = {}, tt[8] = {}, ss[8] = {};
-    if (m < a.R) {
-      const float* cp = nullptr;
-      if (a.cond) cp = a.cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, m, a.Tp) : m) * a.ldc + c;
+  for (int slice = 0; slice < NS; ++slice) {
+    x_load(a.X, a.ldx, H, a.R, m0, slice + 1 < NS ? slice + 1 : NS - 1, xr);       // unconditional: no branch-defined staging registers
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float vt = pt[i] + a.bias1[c + i], vs = ps[i] + a.bias1[H + c + i];
-        if (a.drop_thresh) {                                         // x_in = drop(conv(x)) (modules.py:153)
-          vt = drop_keep(a.drop_seed, m, c + i, a.drop_thresh) ? vt * a.drop_scale : 0.0f;
-          vs = drop_keep(a.drop_seed, m, H + c + i, a.drop_thresh) ? vs * a.drop_scale : 0.0f;
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int it = slice * TAPS + tap;
+      w_load(it + 1 < NIT ? it + 1 : NIT - 1, ring[(it + 1) & 1]);
+      const bf16_t* xsb = Xs + (slice & 1) * XROWS * LDP + (r + tap) * LDP + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16);
+        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * LDP + ks * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][ks][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][ks][bn]), b1, acc[bn][1], 0, 0, 0);
         }
-        if (cp) { vt += cp[i]; vs += cp[H + i]; }
-        tt[i] = tanhf_(vt); ss[i] = sigmoidf_(vs); aa[i] = tt[i] * ss[i];
       }
-      *reinterpret_cast<uint4*>(a.Tt + (size_t)m * a.ldts + c) = pack8(tt);
-      *reinterpret_cast<uint4*>(a.Ss + (size_t)m * a.ldts + c) = pack8(ss);
-      *reinterpret_cast<uint4*>(a.acts + (size_t)m * a.ldacts + c) = pack8(aa);
     }
-    if (RES) *reinterpret_cast<uint4*>(At + row * AP + c) = pack8(aa);
+    x_store(Xs + ((slice + 1) & 1) * XROWS * LDP, xr);
+    __syncthreads();
   }
-  if (!RES) { stamp_end(a); return; }
-  __syncthreads();                                                   // es dead, At complete
 
-  {
-    bf16_t* W2s = reinterpret_cast<bf16_t*>(smem);                   // aliases es
-    f32x16_t acc2[3][1];
-    gemm_tile<H, 2, 2, 3, 1, false, 1>(a.W2, H, a.K2p, nullptr, 0, H, a.R, m0, W2s, nullptr, At, acc2);
-    float* es2 = reinterpret_cast<float*>(smem);                     // the K loop's last barrier has retired the W2s reads
-    acc_to_lds<2, 3, 1>(es2, EP2, acc2);
-  }
-  __syncthreads();
-  {
-    const float* es2 = reinterpret_cast<const float*>(smem);
+  // second-stage weights start flying now, under the gate epilogue
+  const int wn2 = wave & 1, wm2 = wave >> 1;
+  uint4 ring2[KK2 / 2][3];
+  if (RES) s2_prefetch(a.W2, wn2, lane, ring2);
+
+  // gate epilogue in registers: block (3*wave + bn) holds [16 tanh | 16 sigmoid] of gate channels 16*(3*wave+bn) .. +15;
+  // a lane's accumulator e = 4g + j is row r, packed column 8g + 4h + j -> tanh for g < 2, sigmoid (same channel) at e + 8
 #pragma unroll
-    for (int j = 0; j < BM * CPR / 256; ++j) {
-      const int q = tid + 256 * j, row = q / CPR, c = (q - row * CPR) * 8;
-      const int m = m0 + row;
-      if (m >= a.R) continue;
+  for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int c = 16 * (3 * wave + bn) + 8 * g + 4 * h;             // first of 4 consecutive gate channels
+      const float4 bt = *reinterpret_cast<const float4*>(a.bias1 + c), bs = *reinterpret_cast<const float4*>(a.bias1 + H + c);
+      const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+      for (int bm = 0; bm < 2; ++bm) {
+        const int row = 32 * bm + r, m = m0 + row;
+        float tt[4] = {}, ss[4] = {}, aa[4] = {};
+        if (m < a.R) {
+          float ctv[4] = {}, csv[4] = {};
+          if (a.cond) {
+            const float* cp = a.cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, m, a.Tp) : m) * a.ldc + c;
+            const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
+            ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
+            if (a.drop_thresh) {                                       // x_in = drop(conv(x)) (modules.py:153)
+              vt = drop_keep(a.drop_seed, m, c + j, a.drop_thresh) ? vt * a.drop_scale : 0.0f;
+              vs = drop_keep(a.drop_seed, m, H + c + j, a.drop_thresh) ? vs * a.drop_scale : 0.0f;
+            }
+            vt += ctv[j]; vs += csv[j];
+            tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
+          }
+          *reinterpret_cast<uint2*>(a.Tt + (size_t)m * a.ldts + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
+          *reinterpret_cast<uint2*>(a.Ss + (size_t)m * a.ldts + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
+          *reinterpret_cast<uint2*>(a.acts + (size_t)m * a.ldacts + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
+        }
+        if (RES) *reinterpret_cast<uint2*>(At + row * AP + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
+      }
+    }
+  if (!RES) { stamp_end(a); return; }
+  __syncthreads();                                                   // At complete
+
+  f32x16_t acc2[3];
+  s2_gemm(a.W2, At, wn2, wm2, lane, ring2, acc2);
+  // x_next = (x + res + b_res) * mask: accumulator e = 4g + j is row r, channel 32*(3*wn2 + bn) + 8g + 4h + j
+  {
+    const int m = m0 + 32 * wm2 + r;
+    if (m < a.R) {
       const float rm = a.rowmask[m];
-      const float4 e0 = *reinterpret_cast<const float4*>(&es2[row * EP2 + c]), e1 = *reinterpret_cast<const float4*>(&es2[row * EP2 + c + 4]);
-      float v[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w}, xr[8];
-      unpack8(*reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.ldres + c), xr);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (v[i] + a.bias2[c + i] + xr[i]) * rm;
-      *reinterpret_cast<uint4*>(a.Xnext + (size_t)m * a.ldxn + c) = pack8(v);
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * (3 * wn2 + bn) + 8 * g + 4 * h;
+          const float4 b2 = *reinterpret_cast<const float4*>(a.bias2 + n);
+          float xv[4];
+          unpack4(*reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldres + n), xv);
+          *reinterpret_cast<uint2*>(a.Xnext + (size_t)m * a.ldxn + n) =
+              pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
+                    (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
+        }
     }
   }
   stamp_end(a);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-__global__ __launch_bounds__(256, 1) void gt_wn_layer_bwd_kernel(WnArgs a)
+constexpr int EX_BYTES = 4 * 3 * 16 * 64 * 4;                                // partial-sum exchange: [4 waves][3 blocks][16][64 lanes] fp32
+constexpr int BWD_XS = 2 * XROWS * LDP * 2;
+constexpr int BWD_LDS = (EX_BYTES > BWD_XS ? EX_BYTES : BWD_XS) + BM * AP * 2;   // Ex aliases the activation slices; + At
+
+template <bool S2>
+__global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   stamp_begin(a);
   if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave & 1, wk = wave >> 1;     // stage 1: column half, K half;  afterwards wk doubles as the row half
   const int m0 = blockIdx.x * BM;
-  // stage-2 weights have their own region at the end, so that their first slice can be fetched under stage 1's tail
-  bf16_t* Ws = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Xs = Ws + 2 * H * LDP;
-  float* es = reinterpret_cast<float*>(smem);
-  bf16_t* At = reinterpret_cast<bf16_t*>(smem + ES2_BYTES);
-  bf16_t* W2s = reinterpret_cast<bf16_t*>(smem + (BWD_LDS - W2_BYTES));
-  constexpr int CPR = H / 8;
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
+  float* Ex = reinterpret_cast<float*>(smem);
+  bf16_t* At = reinterpret_cast<bf16_t*>(smem + (EX_BYTES > BWD_XS ? EX_BYTES : BWD_XS));
+  constexpr int NS = 2 * H / BK, NIT = NS * TAPS, KS = 2 * H / 16, NBT = H / 32;  // 6 slices, 30 steps, 24 k-steps per tap, 6 column blocks
 
-  {
-    f32x16_t acc[3][1];
-    gemm_tile<H, 2, 2, 3, 1, true, TAPS>(a.W1, H, a.K1p, a.X, a.ldx, 2 * H, a.R, m0, Ws, Xs, nullptr, acc);
-    acc_to_lds<2, 3, 1>(es, EP2, acc);
-  }
-  __syncthreads();
-  // dX = (conv^T(d pre) + residual-path gradient) * mask -> HBM and the stage-2 tile
+  f32x16_t acc[3][2];
 #pragma unroll
-  for (int j = 0; j < BM * CPR / 256; ++j) {
-    const int q = tid + 256 * j, row = q / CPR, c = (q - row * CPR) * 8;
-    const int m = m0 + row;
-    float v[8] = {};
-    if (m < a.R) {
-      const float rm = a.rowmask[m];
-      const float4 e0 = *reinterpret_cast<const float4*>(&es[row * EP2 + c]), e1 = *reinterpret_cast<const float4*>(&es[row * EP2 + c + 4]);
-      float ad[8] = {};
-      if (a.resid) unpack8(*reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.ldres + c), ad);
-      const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+  for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = (ev[i] + ad[i]) * rm;
-      *reinterpret_cast<uint4*>(a.Xnext + (size_t)m * a.ldxn + c) = pack8(v);
-    }
-    *reinterpret_cast<uint4*>(At + row * AP + c) = pack8(v);
-  }
+    for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
+
+  // this wave's K half of step `it`: k-steps 2*wk, 2*wk + 1 of the slice, 3 column blocks
+  uint4 ring[2][2][3];
+  auto w_load = [&](int it, uint4 (&dst)[2][3]) {
+    const int slice = it / TAPS, tap = it - slice * TAPS;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) dst[k2][bn] = ldfrag(a.W1, (tap * NBT + 3 * wn + bn) * KS + slice * 4 + 2 * wk + k2, lane);
+  };
+  uint4 xr[XCH];
+  x_load(a.X, a.ldx, 2 * H, a.R, m0, 0, xr);
+  w_load(0, ring[0]);
+  x_store(Xs, xr);
   __syncthreads();
 
-  {
-    f32x16_t acc2[3][1];
-    gemm_tile<H, 2, 2, 3, 1, false, 1>(a.W2, H, a.K2p, nullptr, 0, H, a.R, m0, W2s, nullptr, At, acc2);
-    __syncthreads();
-    acc_to_lds<2, 3, 1>(es, EP2, acc2);                              // At no longer needed: es may overlap nothing live
-  }
-  __syncthreads();
-  // d acts = dX W_res + skip-path gradient; d pre_t = d S (1 - T^2), d pre_s = d T S (1 - S), times the forward's dropout mask
 #pragma unroll
-  for (int j = 0; j < BM * CPR / 256; ++j) {
-    const int q = tid + 256 * j, row = q / CPR, c = (q - row * CPR) * 8;
-    const int m = m0 + row;
-    if (m >= a.R) continue;
-    const float4 e0 = *reinterpret_cast<const float4*>(&es[row * EP2 + c]), e1 = *reinterpret_cast<const float4*>(&es[row * EP2 + c + 4]);
-    float d[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w}, vs[8], t[8], s[8], gt[8], gs[8];
-    unpack8(*reinterpret_cast<const uint4*>(a.viaskip + (size_t)m * a.ldvs + c), vs);
-    unpack8(*reinterpret_cast<const uint4*>(a.Tt + (size_t)m * a.ldts + c), t);
-    unpack8(*reinterpret_cast<const uint4*>(a.Ss + (size_t)m * a.ldts + c), s);
+  for (int slice = 0; slice < NS; ++slice) {
+    x_load(a.X, a.ldx, 2 * H, a.R, m0, slice + 1 < NS ? slice + 1 : NS - 1, xr);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      // round 1 formed d acts as a bf16 GEMM output before the gate backward; keep fp32 here (strictly more accurate)
-      const float dd = d[i] + vs[i];
-      gt[i] = dd * s[i] * (1.0f - t[i] * t[i]); gs[i] = dd * t[i] * s[i] * (1.0f - s[i]);
-    }
-    if (a.dpre_c) {                                                  // cond enters after the dropout (modules.py:153-156)
-      bf16_t* cp = a.dpre_c + (size_t)m * a.lddp + c;
-      *reinterpret_cast<uint4*>(cp) = pack8(gt);
-      *reinterpret_cast<uint4*>(cp + H) = pack8(gs);
-    }
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int it = slice * TAPS + tap;
+      w_load(it + 1 < NIT ? it + 1 : NIT - 1, ring[(it + 1) & 1]);
+      const bf16_t* xsb = Xs + (slice & 1) * XROWS * LDP + (r + tap) * LDP + 8 * h + 32 * wk;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (a.drop_thresh) {
-        gt[i] = drop_keep(a.drop_seed, m, c + i, a.drop_thresh) ? gt[i] * a.drop_scale : 0.0f;
-        gs[i] = drop_keep(a.drop_seed, m, H + c + i, a.drop_thresh) ? gs[i] * a.drop_scale : 0.0f;
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + k2 * 16);
+        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * LDP + k2 * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][k2][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][k2][bn]), b1, acc[bn][1], 0, 0, 0);
+        }
       }
     }
-    bf16_t* yp = a.dpre + (size_t)m * a.lddp + c;
-    *reinterpret_cast<uint4*>(yp) = pack8(gt);
-    *reinterpret_cast<uint4*>(yp + H) = pack8(gs);
+    x_store(Xs + ((slice + 1) & 1) * XROWS * LDP, xr);
+    __syncthreads();
+  }
+
+  // second-stage weights: this wave's 96 columns (wn), rows 32*wk
+  uint4 ring2[KK2 / 2][3];
+  if (S2) s2_prefetch(a.W2, wn, lane, ring2);
+
+  // K halves meet: a wave keeps row block bm == wk and hands the other one to its partner (same columns, other K half)
+  {
+    float* mine = Ex + wave * (3 * 16 * 64);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mine[(bn * 16 + e) * 64 + lane] = wk ? acc[bn][0][e] : acc[bn][1][e];
+  }
+  __syncthreads();
+  f32x16_t sum[3];
+  {
+    const float* theirs = Ex + (wave ^ 2) * (3 * 16 * 64);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum[bn][e] = (wk ? acc[bn][1][e] : acc[bn][0][e]) + theirs[(bn * 16 + e) * 64 + lane];
+  }
+  // dX = (conv^T(d pre) + residual-path gradient) * mask -> HBM and the stage-2 tile
+  const int row = 32 * wk + r, m = m0 + row;
+  {
+    const float rm = m < a.R ? a.rowmask[m] : 0.0f;
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        float ad[4] = {};
+        if (a.resid && m < a.R) unpack4(*reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldres + n), ad);
+        const uint2 v = pack4((sum[bn][4 * g] + ad[0]) * rm, (sum[bn][4 * g + 1] + ad[1]) * rm,
+                              (sum[bn][4 * g + 2] + ad[2]) * rm, (sum[bn][4 * g + 3] + ad[3]) * rm);
+        if (m < a.R) *reinterpret_cast<uint2*>(a.Xnext + (size_t)m * a.ldxn + n) = v;
+        if (S2) *reinterpret_cast<uint2*>(At + row * AP + n) = v;
+      }
+  }
+  if (!S2) { stamp_end(a); return; }                                 // bottom layer: only the data gradient (no gate below it)
+  __syncthreads();
+
+  f32x16_t acc2[3];
+  s2_gemm(a.W2, At, wn, wk, lane, ring2, acc2);
+  // d acts = dX W_res + skip-path gradient; d pre_t = d S (1 - T^2), d pre_s = d T S (1 - S), times the forward's dropout mask
+  if (m < a.R) {
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        float vs[4], t[4], s[4], gt[4], gs[4];
+        unpack4(*reinterpret_cast<const uint2*>(a.viaskip + (size_t)m * a.ldvs + n), vs);
+        unpack4(*reinterpret_cast<const uint2*>(a.Tt + (size_t)m * a.ldts + n), t);
+        unpack4(*reinterpret_cast<const uint2*>(a.Ss + (size_t)m * a.ldts + n), s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // round 1 formed d acts as a bf16 GEMM output before the gate backward; it stays fp32 here
+          const float dd = acc2[bn][4 * g + j] + vs[j];
+          gt[j] = dd * s[j] * (1.0f - t[j] * t[j]); gs[j] = dd * t[j] * s[j] * (1.0f - s[j]);
+        }
+        if (a.dpre_c) {                                              // cond enters after the dropout (modules.py:153-156)
+          bf16_t* cp = a.dpre_c + (size_t)m * a.lddp + n;
+          *reinterpret_cast<uint2*>(cp) = pack4(gt[0], gt[1], gt[2], gt[3]);
+          *reinterpret_cast<uint2*>(cp + H) = pack4(gs[0], gs[1], gs[2], gs[3]);
+        }
+        if (a.drop_thresh) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            gt[j] = drop_keep(a.drop_seed, m, n + j, a.drop_thresh) ? gt[j] * a.drop_scale : 0.0f;
+            gs[j] = drop_keep(a.drop_seed, m, H + n + j, a.drop_thresh) ? gs[j] * a.drop_scale : 0.0f;
+          }
+        }
+        bf16_t* yp = a.dpre + (size_t)m * a.lddp + n;
+        *reinterpret_cast<uint2*>(yp) = pack4(gt[0], gt[1], gt[2], gt[3]);
+        *reinterpret_cast<uint2*>(yp + H) = pack4(gs[0], gs[1], gs[2], gs[3]);
+      }
   }
   stamp_end(a);
 }
@@ -378,45 +424,39 @@ inline bool al16(const void* p) { return !((uintptr_t)p & 15); }
 
 }  // namespace
 
-extern "C" int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in, int K1p, const float* bias_in,
+extern "C" int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, const float* bias_in,
                                const float* cond, int ldc, const int32_t* row0, int B, int Tp, const float* rowmask,
                                void* acts, int ldacts, void* gate_t, void* gate_s, int ldts,
-                               const void* w_res, int K2p, const float* bias_res, void* x_next, int ldxn,
+                               const void* w_res_frag, const float* bias_res, void* x_next, int ldxn,
                                int R, int Hc, int taps, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
                                unsigned long long* stamps, int stamp_slot, void* stream)
 {
   if (R < 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
   if (Hc != H || taps != TAPS) return GT_E_UNSUPPORTED;
-  if (!x || !w_in || !bias_in || !rowmask || !acts || !gate_t || !gate_s) return GT_E_INVAL;
-  if (w_res && (!bias_res || !x_next)) return GT_E_INVAL;
-  if ((ldx & 7) || (ldacts & 7) || (ldts & 7) || (w_res && (ldxn & 7)) || (K1p % BK) || K1p < H || (w_res && ((K2p % BK) || K2p < H))) return GT_E_ALIGN;
-  if (!al16(x) || !al16(w_in) || !al16(acts) || !al16(gate_t) || !al16(gate_s) || !al16(w_res) || !al16(x_next)) return GT_E_ALIGN;
+  if (!x || !w_in_frag || !bias_in || !rowmask || !acts || !gate_t || !gate_s) return GT_E_INVAL;
+  if (w_res_frag && (!bias_res || !x_next)) return GT_E_INVAL;
+  if ((ldx & 7) || (ldacts & 3) || (ldts & 3) || (w_res_frag && (ldxn & 3)) || (cond && (ldc & 3))) return GT_E_ALIGN;
+  if (!al16(x) || !al16(w_in_frag) || !al16(acts) || !al16(gate_t) || !al16(gate_s) || !al16(w_res_frag) || !al16(x_next) ||
+      !al16(bias_in) || !al16(bias_res) || !al16(cond)) return GT_E_ALIGN;
   if (cond && (Tp <= 0 || (row0 && B <= 0))) return GT_E_INVAL;
   WnArgs a = {};
-  a.X = static_cast<const bf16_t*>(x); a.ldx = ldx; a.W1 = static_cast<const bf16_t*>(w_in); a.W2 = static_cast<const bf16_t*>(w_res);
+  a.X = static_cast<const bf16_t*>(x); a.ldx = ldx; a.W1 = static_cast<const bf16_t*>(w_in_frag); a.W2 = static_cast<const bf16_t*>(w_res_frag);
   a.bias1 = bias_in; a.bias2 = bias_res; a.cond = cond; a.ldc = ldc; a.B = B; a.row0 = row0; a.Tp = Tp > 0 ? Tp : 1; a.rowmask = rowmask;
   a.acts = static_cast<bf16_t*>(acts); a.ldacts = ldacts; a.Tt = static_cast<bf16_t*>(gate_t); a.Ss = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
   a.Xnext = static_cast<bf16_t*>(x_next); a.ldxn = ldxn; a.resid = a.X; a.ldres = ldx;
-  a.R = R; a.K1p = K1p; a.K2p = K2p; a.stamps = stamps; a.stamp_slot = stamp_slot;
+  a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot;
   const int rc = fill_drop(a, drop_p, drop_seed, seed_dev);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid((R + BM - 1) / BM), block(256);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_layer_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_layer_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS) != hipSuccess)
-      return GT_E_LAUNCH;
-    attr = true;
-  }
-  if (w_res) hipLaunchKernelGGL(gt_wn_layer_fwd_kernel<true>, grid, block, FWD_LDS, st, a);
-  else       hipLaunchKernelGGL(gt_wn_layer_fwd_kernel<false>, grid, block, FWD_LDS, st, a);
+  if (w_res_frag) hipLaunchKernelGGL(gt_wn_layer_fwd_kernel<true>, grid, block, 0, st, a);
+  else            hipLaunchKernelGGL(gt_wn_layer_fwd_kernel<false>, grid, block, 0, st, a);
   return gt_launch_status(__func__);
 }
 
-extern "C" int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad, int K1p, const void* resid, int ldres,
-                               const float* rowmask, void* dx, int lddx, const void* w_res_dgrad, int K2p,
+extern "C" int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad_frag, const void* resid, int ldres,
+                               const float* rowmask, void* dx, int lddx, const void* w_res_dgrad_frag,
                                const void* via_skip, int ldvs, const void* gate_t, const void* gate_s, int ldts,
                                void* dpre, void* dpre_c, int lddp, int R, int Hc, int taps, float drop_p, uint32_t drop_seed,
                                const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, void* stream)
@@ -424,23 +464,30 @@ extern "C" int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in
   if (R < 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
   if (Hc != H || taps != TAPS) return GT_E_UNSUPPORTED;
-  if (!dpre_next || !w_in_dgrad || !rowmask || !dx || !w_res_dgrad || !via_skip || !gate_t || !gate_s || !dpre) return GT_E_INVAL;
-  if ((lddn & 7) || (ldres & 7) || (lddx & 7) || (ldvs & 7) || (ldts & 7) || (lddp & 7) || (K1p % BK) || K1p < 2 * H || (K2p % BK) || K2p < H) return GT_E_ALIGN;
-  if (!al16(dpre_next) || !al16(w_in_dgrad) || !al16(resid) || !al16(dx) || !al16(w_res_dgrad) || !al16(via_skip) || !al16(gate_t) || !al16(gate_s) || !al16(dpre) || !al16(dpre_c))
-    return GT_E_ALIGN;
+  if (!dpre_next || !w_in_dgrad_frag || !rowmask || !dx) return GT_E_INVAL;
+  if (w_res_dgrad_frag && (!via_skip || !gate_t || !gate_s || !dpre)) return GT_E_INVAL;
+  if ((lddn & 7) || (ldres & 3) || (lddx & 3) || (ldvs & 3) || (ldts & 3) || (lddp & 3)) return GT_E_ALIGN;
+  if (!al16(dpre_next) || !al16(w_in_dgrad_frag) || !al16(resid) || !al16(dx) || !al16(w_res_dgrad_frag) || !al16(via_skip) || !al16(gate_t) ||
+      !al16(gate_s) || !al16(dpre) || !al16(dpre_c)) return GT_E_ALIGN;
   WnArgs a = {};
-  a.X = static_cast<const bf16_t*>(dpre_next); a.ldx = lddn; a.W1 = static_cast<const bf16_t*>(w_in_dgrad); a.W2 = static_cast<const bf16_t*>(w_res_dgrad);
+  a.X = static_cast<const bf16_t*>(dpre_next); a.ldx = lddn; a.W1 = static_cast<const bf16_t*>(w_in_dgrad_frag);
+  a.W2 = static_cast<const bf16_t*>(w_res_dgrad_frag);
   a.rowmask = rowmask; a.Xnext = static_cast<bf16_t*>(dx); a.ldxn = lddx; a.resid = static_cast<const bf16_t*>(resid); a.ldres = ldres;
   a.viaskip = static_cast<const bf16_t*>(via_skip); a.ldvs = ldvs;
   a.Tt = const_cast<bf16_t*>(static_cast<const bf16_t*>(gate_t)); a.Ss = const_cast<bf16_t*>(static_cast<const bf16_t*>(gate_s)); a.ldts = ldts;
-  a.dpre = static_cast<bf16_t*>(dpre); a.dpre_c = static_cast<bf16_t*>(dpre_c); a.lddp = lddp; a.R = R; a.K1p = K1p; a.K2p = K2p; a.stamps = stamps; a.stamp_slot = stamp_slot;
+  a.dpre = static_cast<bf16_t*>(dpre); a.dpre_c = static_cast<bf16_t*>(dpre_c); a.lddp = lddp; a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot;
   const int rc = fill_drop(a, drop_p, drop_seed, seed_dev);
   if (rc) return rc;
-  static bool attr = false;
+  static bool attr = false;                    // > 64 KB of LDS: opt in once (per process; the attribute is per device function)
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_layer_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess) return GT_E_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_layer_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_layer_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BWD_LDS) != hipSuccess)
+      return GT_E_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(gt_wn_layer_bwd_kernel, dim3((R + BM - 1) / BM), dim3(256), BWD_LDS, static_cast<hipStream_t>(stream), a);
+  const dim3 grid((R + BM - 1) / BM), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (w_res_dgrad_frag) hipLaunchKernelGGL(gt_wn_layer_bwd_kernel<true>, grid, block, BWD_LDS, st, a);
+  else                  hipLaunchKernelGGL(gt_wn_layer_bwd_kernel<false>, grid, block, BWD_LDS, st, a);
   return gt_launch_status(__func__);
 }

@@ -130,10 +130,12 @@ def actnorm_invconv_bwd(rc, saved, dy, dlogdet, logs, bias, W):
 # ----------------------------------------------------------------------------- WN
 def _fused_ok(wn):
     """the one-kernel-per-layer path (csrc/wn_layer.hip): H = 192, k = 5, packed images exactly N rows high"""
-    if not getattr(wn, "fused", True) or wn.hidden_channels != 192 or wn.kernel_size != 5:
+    if not getattr(wn, "fused", False):
         return False
     pc = wn.in_layers[0].pc
-    return pc.Np_f == 2 * wn.hidden_channels and pc.Np_d == wn.hidden_channels
+    assert pc.frag and pc.gate16 and pc.Np_f == 2 * wn.hidden_channels and pc.Kp_f == wn.hidden_channels and \
+        pc.Np_d == wn.hidden_channels and pc.Kp_d == 2 * wn.hidden_channels, "fused WN: fragment-ordered images expected (prepare_all after set_fused)"
+    return True
 
 
 def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
@@ -164,12 +166,12 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
             s = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
             xn = None if last else torch.empty(R, H, dtype=torch.bfloat16, device=dev)
             _ev = KERNEL_TIMER.start("wn_layer_fwd")
-            rcode = L.gt_wn_layer_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(il.pc.fwd), il.pc.Kp_f, _lib.ptr(il.bias),
+            rcode = L.gt_wn_layer_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(il.pc.fwd), _lib.ptr(il.bias),
                                       _lib.ptr(ci), 0 if ci is None else ci.stride(0),
                                       _lib.ptr(rc.row0) if (ci is not None and not cond_per_row) else None,
                                       0 if (cond_per_row or ci is None) else rc.B, rc.Tp, _lib.ptr(rc.rowmask),
                                       _lib.ptr(acts), acts.stride(0), _lib.ptr(t), _lib.ptr(s), H,
-                                      None if last else _lib.ptr(rs.pc_res.fwd), 0 if last else rs.pc_res.Kp_f,
+                                      None if last else _lib.ptr(rs.pc_res.fwd),
                                       None if last else rs.bias.data_ptr(), _lib.ptr(xn), H,
                                       R, H, wn.kernel_size, float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None,
                                       _lib.ptr(stamps[0]) if stamps else None, (stamps[1] + i) if stamps else 0, _st(dev))
@@ -242,8 +244,8 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
         dpre_i = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
         dpre_ci = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev) if need_c else None
         via = dacts_skip[:, i * H:(i + 1) * H]
-        _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(nxt.pc.dgrad), nxt.pc.Kp_d, _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
-                                     _lib.ptr(dXn), H, _lib.ptr(rs.pc_res.dgrad), rs.pc_res.Kp_d, _lib.ptr(via), via.stride(0),
+        _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(nxt.pc.dgrad), _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
+                                     _lib.ptr(dXn), H, _lib.ptr(rs.pc_res.dgrad), _lib.ptr(via), via.stride(0),
                                      _lib.ptr(ts[i]), _lib.ptr(ss[i]), H, _lib.ptr(dpre_i), _lib.ptr(dpre_ci), 2 * H, R, H, wn.kernel_size,
                                      float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None, None, 0, _st(dev)),
                    "gt_wn_layer_bwd")
@@ -253,8 +255,11 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
         if want_dcond:
             _dcond_store(rc, dcond, i, H, dpre_ci if need_c else dpre_i, cond_per_row)
         dX, dpre = dXn, dpre_i
-    # d x_0 = dgrad(in_layer_0) + (residual path), through the mask of x_0's producer
-    dh0 = conv_rows(dpre, wn.in_layers[0].pc, rc, dgrad=True, addend=dX, mask=True)
+    # d x_0 = dgrad(in_layer_0) + (residual path), through the mask of x_0's producer: the same kernel without its second stage
+    dh0 = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(wn.in_layers[0].pc.dgrad), _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
+                                 _lib.ptr(dh0), H, None, None, 0, None, None, 0, None, None, 0, R, H, wn.kernel_size, 0.0, 0, None, None, 0,
+                                 _st(dev)), "gt_wn_layer_bwd")
     return dh0, grads, dcond
 
 

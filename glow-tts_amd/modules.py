@@ -75,14 +75,16 @@ class WNConvP(ConvP):
         self.split_res_skip = split_res_skip       # res_skip layer of a WN: rows [0,h) residual, [h,2h) skip
         self.skip_slice = None                     # set by the owning WN: where the skip rows are packed
         self.pc_res = None
+        self.frag = False                          # set by the owning WN (fused layer kernels): fragment-ordered images
 
     def _ensure_pcs(self):
         dev = self.weight_v.device
         if self._pc is None or self._pc.inv_norm.device != dev:
             in_wn = self.skip_slice is not None
-            self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev, norm_only=in_wn)
+            self._pc = PackedConv(self.out_channels, self.in_channels, self.kernel_size, self.gate, device=dev, norm_only=in_wn,
+                                  frag=self.frag and not in_wn, gate16=self.frag and self.gate)
             if self.split_res_skip:
-                self.pc_res = PackedConv(self.out_channels // 2, self.in_channels, self.kernel_size, False, device=dev)
+                self.pc_res = PackedConv(self.out_channels // 2, self.in_channels, self.kernel_size, False, device=dev, frag=self.frag)
 
     def _pack_entries(self):
         out = [(self.weight_v, self.weight_g, self._pc)]                 # inv_norm (+ images unless norm_only)
@@ -128,7 +130,7 @@ class _PackPlan:
             elif hasattr(m, "_pack_entries_extra"):
                 entries += m._pack_entries_extra()
         self.n = len(entries)
-        self.key = tuple(e[0].data_ptr() for e in entries)
+        self.key = tuple((e[0].data_ptr(), id(e[2])) for e in entries)
         self.keep = entries
         self.tables = []                                 # (device table, n, rows, group8)
         if self.n == 0:
@@ -191,8 +193,16 @@ def prepare_all(module):
                 a.qkv_bias = row
     plan = getattr(module, "_pack_plan", None)
     if plan is not None:
-        cur = tuple(e[0].data_ptr() for e in plan.keep)
-        if cur != plan.key:
+        cur = []
+        for m in module.modules():                       # same walk as _PackPlan: parameter storage AND packed-image identity
+            if isinstance(m, ConvP):
+                if getattr(m, "no_pack", False):
+                    continue
+                m._ensure_pcs()
+                cur += [(e[0].data_ptr(), id(e[2])) for e in m._pack_entries()]
+            elif hasattr(m, "_pack_entries_extra"):
+                cur += [(e[0].data_ptr(), id(e[2])) for e in m._pack_entries_extra()]
+        if tuple(cur) != plan.key:
             plan = None
     if plan is None:
         plan = _PackPlan(module)
@@ -292,8 +302,24 @@ class WN(nn.Module):
         # every layer's skip rows are packed into a window of pc_skipcat ([H, n_layers*H])
         self._pc_skipcat = None
         self.skip_bias = None
+        # one kernel per layer (csrc/wn_layer.hip) for the shape every reference config has; set_fused(False) gives round 1's
+        # two-kernels-per-layer launch sequence (kept as the reference the fused kernels are tested against)
+        self.fused = False
+        self.set_fused(hidden_channels == 192 and kernel_size == 5)
         for i, rs in enumerate(self.res_skip_layers):
             rs.skip_slice = (lambda i=i: PackSlice(self.pc_skipcat, i * self.hidden_channels, self.hidden_channels, self.hidden_channels))
+
+    def set_fused(self, on):
+        """Switch between the fused layer kernels (fragment-ordered weight images) and the two-kernel path (row-major
+        images); the packed images are rebuilt by the next prepare_all()."""
+        on = bool(on) and self.hidden_channels == 192 and self.kernel_size == 5
+        if on == self.fused and getattr(self, "_fused_set", False):
+            return
+        self.fused, self._fused_set = on, True
+        for il in self.in_layers:
+            il.frag, il._pc = on, None
+        for rs in self.res_skip_layers:
+            rs.frag, rs._pc, rs.pc_res = on, None, None
 
     @property
     def pc_skipcat(self):

@@ -332,7 +332,7 @@ class PackSliceN:
 class PackedConv:
     """bf16 MFMA-ready images of one conv's weight: forward and data-gradient packing (row-major [taps][Np][Kp])."""
 
-    def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False, split3=False):
+    def __init__(self, Cout, Cin, taps, gate=False, device="cuda", norm_only=False, split3=False, frag=False, gate16=False):
         """norm_only: only the per-row 1/||v|| is wanted (the weight itself is packed elsewhere, e.g. into the
         K-concatenated skip GEMM of a WN): no bf16 images.
         split3: bf16x3 images ([w_hi; w_lo; w_hi] along the reduction axis, gt_pack_conv_weights flag 8) for a near-fp32
@@ -340,6 +340,10 @@ class PackedConv:
         self.Cout, self.Cin, self.taps, self.gate = Cout, Cin, taps, gate
         self.split3 = bool(split3)
         self.km = 3 if split3 else 1                # reduction-axis multiplier of the packed images
+        # frag: both images in MFMA-fragment order (flags 2 | 4: one 1-KB A-fragment per (32 channels, 16 k)); gate16: the
+        # gate interleave at MFMA-block granularity (flag 16) — what the fused WaveNet-layer kernels read (csrc/wn_layer.hip)
+        self.frag, self.gate16 = bool(frag), bool(gate16)
+        assert not (frag and split3) and not (gate16 and not gate)
         self.inv_norm = torch.zeros(Cout, dtype=torch.float32, device=device)
         self.fwd = self.dgrad = None
         self.Kp_f = self.Np_f = self.Kp_d = self.Np_d = 0
@@ -355,7 +359,8 @@ class PackedConv:
 
     @property
     def flags(self):
-        return int(bool(self.gate)) + 8 * int(self.split3)
+        g = 16 if (self.gate and self.gate16) else int(bool(self.gate))
+        return g + 6 * int(self.frag) + 8 * int(self.split3)
 
     def pack(self, v, g=None):
         """v: [Cout, Cin, taps] fp32 (weight_v or plain weight), g: [Cout,1,1] or None."""

@@ -144,6 +144,8 @@ int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
  * `gate` is a bit set: 1 = WaveNet-gate row interleave of the forward image ([32 tanh | 32 sigmoid] per 64 rows),
  * 2 = forward image in MFMA-fragment order [tap][n/32][k/16][lane = n%32 + 32*((k%16)/8)][k%8] (one 1-KB MFMA A-fragment per (n/32, k/16): the fused WaveNet-layer kernels),
  * 4 = the same for the data-gradient image (Np, Kp multiples of 32 / 16 then),
+ * 16 = the gate interleave at MFMA-block granularity, [16 tanh | 16 sigmoid] per 32 packed rows (instead of 1): every 32-column
+ *     accumulator block then holds both halves of its 16 gate channels in the same lanes (gt_wn_layer_fwd's in-register gate),
  * 8 = bf16x3 ("split") images for a near-fp32 product out of three bf16 MFMA passes: the reduction axis is K-concatenated
  *     as [w_hi ; w_lo ; w_hi] (Kp >= 3*Cin resp. 3*Cout; w_hi = bf16(w), w_lo = bf16(w - w_hi)) and meets activations laid
  *     out as [x_hi | x_hi | x_lo] (gt_rows_split3): x_hi w_hi + x_hi w_lo + x_lo w_hi.  The stochastic predictors' 1x1 convs
@@ -346,28 +348,27 @@ int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const 
 /* ---- One WaveNet layer as ONE kernel (modules.WN.forward, one loop iteration, modules.py:151-170; csrc/wn_layer.hip).
  * H = 192 hidden channels, k = 5, dilation 1; a workgroup owns 64 rows and all channels, so the 1x1 residual conv runs on the
  * gated tile the k=5 conv just produced (and, in the backward, the gate backward on the tile the data gradient just produced).
- * Weights are the packed images of gt_pack_conv_weights with Np == N exactly.
+ * Weights are images of gt_pack_conv_weights in MFMA-FRAGMENT order (flags 2 / 4) with Np == N, Kp == K exactly; the in_layer's
+ * forward image also carries the block-granular gate interleave (flag 16).  A wave loads its own fragments L2 -> registers.
  *
  * gt_wn_layer_fwd:  x_in = drop(conv_k5(x) + bias_in) + cond;  T = tanh(x_in[:H]), S = sigmoid(x_in[H:]), acts = T*S
  *                   (acts / T / S bf16 rows out, as gt_conv_gemm_bf16 gate == 1 writes them; same dropout hash);
- *                   w_res != NULL:  x_next = (x + acts @ W_res^T + bias_res) * rowmask     (rows [0,H) of res_skip_i)
- *   w_in: forward image [5][2H][K1p] with the gate interleave;  w_res: forward image [H][K2p] of the residual rows.
+ *                   w_res_frag != NULL:  x_next = (x + acts @ W_res^T + bias_res) * rowmask     (rows [0,H) of res_skip_i)
  * gt_wn_layer_bwd:  dX = (conv_k5^T(dpre_next) + resid) * rowmask  -> dx [R, H]   (data gradient of the NEXT layer's in_layer,
  *                   resid = gradient arriving at that layer's output through the residual path, NULL for the top layer);
- *                   d acts = dX @ W_res + via_skip;  dpre = gate backward of (T, S) with the forward's dropout replayed,
- *                   [R, 2H] = [d tanh-half | d sigmoid-half];  dpre_c (optional): the same before the dropout mask
- *                   (the gradient of the conditioning term, which is added after the dropout).
- *   w_in_dgrad: data-gradient image [5][H][K1p >= 2H] of the next layer's in_layer;  w_res_dgrad: [H][K2p] of this layer's res rows.
+ *                   w_res_dgrad_frag != NULL:  d acts = dX @ W_res + via_skip;  dpre = gate backward of (T, S) with the forward's
+ *                   dropout replayed, [R, 2H] = [d tanh-half | d sigmoid-half];  dpre_c (optional): the same before the dropout
+ *                   mask (the gradient of the conditioning term, which is added after the dropout).  NULL: dx only (bottom layer).
  * stamps (optional, bench.py): device uint64 pairs [2*slot] = min start / [2*slot+1] = max end of the launch in
  * wall_clock64() ticks (100 MHz) — the kernel's duration inside a replayed HIP graph; init to ~0 / 0. */
-int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in, int K1p, const float* bias_in,
+int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, const float* bias_in,
                     const float* cond, int ldc, const int32_t* row0, int B, int Tp, const float* rowmask,
                     void* acts, int ldacts, void* gate_t, void* gate_s, int ldts,
-                    const void* w_res, int K2p, const float* bias_res, void* x_next, int ldxn,
+                    const void* w_res_frag, const float* bias_res, void* x_next, int ldxn,
                     int R, int H, int taps, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
                     unsigned long long* stamps, int stamp_slot, void* stream);
-int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad, int K1p, const void* resid, int ldres,
-                    const float* rowmask, void* dx, int lddx, const void* w_res_dgrad, int K2p,
+int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad_frag, const void* resid, int ldres,
+                    const float* rowmask, void* dx, int lddx, const void* w_res_dgrad_frag,
                     const void* via_skip, int ldvs, const void* gate_t, const void* gate_s, int ldts,
                     void* dpre, void* dpre_c, int lddp, int R, int H, int taps, float drop_p, uint32_t drop_seed,
                     const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, void* stream);

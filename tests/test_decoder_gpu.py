@@ -449,14 +449,14 @@ def test_fused_wn_layer_kernels_match_the_two_kernel_path(built, mode):
         cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
     res = []
     for fused in (True, False):
-        wn.fused = fused
+        wn.set_fused(fused)                                          # fragment-ordered vs row-major weight images
+        modules.prepare_all(wn)
         out, saved = flow_impl.wn_fwd(rc, wn, h0, cond, True, 77, cond_per_row=mode == "per_row")
         with wgrad.WgradQueue(dev(), site=wn):
             dh0, grads, dcond = flow_impl.wn_bwd(rc, wn, saved, dskip, want_dcond=cond is not None, cond_per_row=mode == "per_row")
         torch.cuda.synchronize()
         res.append((out.float(), [t.float() for t in saved[1]], [s.float() for s in saved[2]], saved[3].float(), dh0.float(),
                     None if dcond is None else dcond.clone(), {id(k): v.float().clone() for k, v in grads.items()}))
-    wn.fused = True
     (o1, t1, s1, a1, d1, c1, g1), (o2, t2, s2, a2, d2, c2, g2) = res
     valid = rc.rowmask.bool()
     assert relerr(o1[valid], o2[valid]) < 1e-2
