@@ -41,6 +41,10 @@ constexpr int TAPS = 5;
 constexpr int XROWS = BM + TAPS - 1;          // 68 activation rows per slice
 constexpr int XCH = (XROWS * 8 + 255) / 256;  // 16-byte activation chunks per thread per slice
 constexpr int AP = H + 8;                     // pitch (halfs) of the stage-2 activation tile
+#ifndef WN_RING
+#define WN_RING 3
+#endif
+constexpr int RING = WN_RING;                 // weight-fragment register ring: (slice, tap) steps in flight per wave
 
 struct WnArgs {
   const bf16_t* X; int ldx;                   // stage-1 operand rows (fwd: layer input [R, H]; bwd: d pre of the next layer [R, 2H])
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
       for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
 
   // weight fragments of step `it` (slice, tap): 4 k-steps x this wave's 3 column blocks
-  uint4 ring[2][4][3];
+  uint4 ring[RING][4][3];
   auto w_load = [&](int it, uint4 (&dst)[4][3]) {
     const int slice = it / TAPS, tap = it - slice * TAPS;
 #pragma unroll
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
   };
   uint4 xr[XCH];
   x_load(a.X, a.ldx, H, a.R, m0, 0, xr);
-  w_load(0, ring[0]);
+#pragma unroll
+  for (int p = 0; p < RING - 1; ++p) w_load(p < NIT ? p : NIT - 1, ring[p]);
   x_store(Xs, xr);
   __syncthreads();
 
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int it = slice * TAPS + tap;
-      w_load(it + 1 < NIT ? it + 1 : NIT - 1, ring[(it + 1) & 1]);
+      w_load(it + RING - 1 < NIT ? it + RING - 1 : NIT - 1, ring[(it + RING - 1) % RING]);
+      __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RING - 1 steps ahead: the scheduler would sink it next to its use
       const bf16_t* xsb = Xs + (slice & 1) * XROWS * LDP + (r + tap) * LDP + 8 * h;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -187,10 +193,11 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
         const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * LDP + ks * 16);
 #pragma unroll
         for (int bn = 0; bn < 3; ++bn) {
-          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][ks][bn]), b0, acc[bn][0], 0, 0, 0);
-          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][ks][bn]), b1, acc[bn][1], 0, 0, 0);
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     x_store(Xs + ((slice + 1) & 1) * XROWS * LDP, xr);
     __syncthreads();
@@ -294,7 +301,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
       for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
 
   // this wave's K half of step `it`: k-steps 2*wk, 2*wk + 1 of the slice, 3 column blocks
-  uint4 ring[2][2][3];
+  constexpr int RB = 2 * RING - 1;             // half the fragments per step: twice the depth for the same registers
+  uint4 ring[RB][2][3];
   auto w_load = [&](int it, uint4 (&dst)[2][3]) {
     const int slice = it / TAPS, tap = it - slice * TAPS;
 #pragma unroll
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
   };
   uint4 xr[XCH];
   x_load(a.X, a.ldx, 2 * H, a.R, m0, 0, xr);
-  w_load(0, ring[0]);
+#pragma unroll
+  for (int p = 0; p < RB - 1; ++p) w_load(p < NIT ? p : NIT - 1, ring[p]);
   x_store(Xs, xr);
   __syncthreads();
 
@@ -314,7 +323,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int it = slice * TAPS + tap;
-      w_load(it + 1 < NIT ? it + 1 : NIT - 1, ring[(it + 1) & 1]);
+      w_load(it + RB - 1 < NIT ? it + RB - 1 : NIT - 1, ring[(it + RB - 1) % RB]);
+      __builtin_amdgcn_sched_barrier(0);
       const bf16_t* xsb = Xs + (slice & 1) * XROWS * LDP + (r + tap) * LDP + 8 * h + 32 * wk;
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
@@ -322,10 +332,11 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
         const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * LDP + k2 * 16);
 #pragma unroll
         for (int bn = 0; bn < 3; ++bn) {
-          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][k2][bn]), b0, acc[bn][0], 0, 0, 0);
-          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it & 1][k2][bn]), b1, acc[bn][1], 0, 0, 0);
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b1, acc[bn][1], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     x_store(Xs + ((slice + 1) & 1) * XROWS * LDP, xr);
     __syncthreads();
