@@ -114,6 +114,13 @@ def _pack_one(pc, v, g):
                                       _lib.current_stream(v.device)), "gt_pack_conv_weights")
 
 
+def _pack_key(entry):
+    """identity of one pack job: where the parameter lives, where its image goes, in which format (PackSlice views are
+    re-created per call, so object identity would not do)"""
+    v, _, pc = entry
+    return (v.data_ptr(), 0 if pc.fwd is None else pc.fwd.data_ptr(), 0 if pc.dgrad is None else pc.dgrad.data_ptr(), pc.flags)
+
+
 class _PackPlan:
     """All conv weights of a module tree packed by ONE kernel launch (gt_pack_conv_weights_multi).
     The descriptor table lives on the device and is rebuilt only when a parameter's storage moves."""
@@ -130,7 +137,7 @@ class _PackPlan:
             elif hasattr(m, "_pack_entries_extra"):
                 entries += m._pack_entries_extra()
         self.n = len(entries)
-        self.key = tuple((e[0].data_ptr(), id(e[2])) for e in entries)
+        self.key = tuple(_pack_key(e) for e in entries)
         self.keep = entries
         self.tables = []                                 # (device table, n, rows, group8)
         if self.n == 0:
@@ -199,9 +206,9 @@ def prepare_all(module):
                 if getattr(m, "no_pack", False):
                     continue
                 m._ensure_pcs()
-                cur += [(e[0].data_ptr(), id(e[2])) for e in m._pack_entries()]
+                cur += [_pack_key(e) for e in m._pack_entries()]
             elif hasattr(m, "_pack_entries_extra"):
-                cur += [(e[0].data_ptr(), id(e[2])) for e in m._pack_entries_extra()]
+                cur += [_pack_key(e) for e in m._pack_entries_extra()]
         if tuple(cur) != plan.key:
             plan = None
     if plan is None:
