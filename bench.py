@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — Glow-TTS training hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5dec]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5dec|cfg5]
 
-One "step" = one full training step of the hot path (zero_grad, TextEncoder + FlowSpecDecoder
-forward, logp + MAS, mle + duration loss, backward, gradient all-reduce, grad-norm, AdamW) on
-one synthetic LJSpeech-shaped batch resident in HBM (seed 1234 + rank, random-init
-weights of configs/base.json).  With N > 1 the driver launches this file under
-torch.distributed.run, one rank per GPU: the batch is sharded by utterance (weak scaling,
-B per GPU fixed) and the only collective is the RCCL gradient all-reduce.
+One "step" = one full training step of the hot path (zero_grad, TextEncoder + FlowSpecDecoder forward, logp + MAS,
+mle + duration loss [+ pitch / energy predictor losses for cfg 5], backward, gradient all-reduce, grad-norm, AdamW) on one
+synthetic LJSpeech-shaped batch resident in HBM (seed 1234 + rank, random-init weights).  The timed region
+ROTATES over 8 distinct seeded batches (different lengths, several ragged-row buckets), so graph-bucket switches and the
+per-batch refresh of the row contexts are inside it; their graphs are captured once, up front and untimed (a capture is
+set-up cost, like compilation: one per bucket per run).  With N > 1 the driver launches this file under
+torch.distributed.run, one rank per GPU: the batch is sharded by utterance (weak scaling, B per GPU fixed) and the only
+collective is the RCCL gradient all-reduce.
 
 Prints ONE JSON line on rank 0:
-  value            = valid mel-frames / s over all ranks (BASELINE.json metric, first half)
-  mas              = MAS alignments / s of gt_mas_f32 alone on the step's own lattice shape (second half)
-  roofline         = dominant kernel (WaveNet in_layer implicit-GEMM conv, bf16 MFMA), timed live with
-                     HIP events around each of its launches inside the timed steps
-  cpu_baseline     = the oracle's training step (PyTorch-CPU fp32 restatement of the reference,
-                     oracle/glowtts_ref.py + reference Cython MAS from oracle/_ref) on a bounded sample
+  value            = valid mel-frames / s over all ranks (BASELINE.json metric, first half); wall clock of exactly K steps
+  step_ms_median   = median of the K per-step times (HIP events recorded on the step's stream, read after the region)
+  mas              = MAS alignments / s of gt_mas_f32 alone on the step's own lattice shape (second half) + its CPU baselines
+                     (reference Cython core on 1 core — what the reference uses — and the C restatement on all cores)
+  roofline         = the dominant kernel family by time, the fused WaveNet-layer kernel (gt_wn_layer_fwd: k=5 conv + gate +
+                     residual 1x1): algorithmic FLOPs / its duration INSIDE the replayed graph (device-side begin / end
+                     stamps of every one of its launches in the timed steps; `profiles/` holds the rocprofv3 summary of
+                     the same command), plus `step` = whole-step FLOP/s over the bf16 MFMA peak
+  cpu_baseline     = the oracle's training step (PyTorch-CPU fp32 restatement of the reference, oracle/glowtts_ref.py +
+                     reference Cython MAS from oracle/_ref) on a bounded sample
 """
 import argparse
 import json
@@ -32,23 +38,53 @@ import torch  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 HBM_PEAK_GBS = 8000.0
+N_BATCHES = 8                     # distinct batches the timed region rotates over
+
+CFG5_MODEL = dict(hidden_channels=192, filter_channels=768, filter_channels_dp=256, kernel_size=3, p_dropout=0.1, n_blocks_dec=12,
+                  n_layers_enc=10, n_heads=2, p_dropout_dec=0.05, dilation_rate=1, kernel_size_dec=5, n_block_layers=4, n_sqz=2,
+                  prenet=True, mean_only=True, hidden_channels_enc=192, hidden_channels_dec=192, window_size=4, gin_channels=512,
+                  use_sdp=True, use_spk_embeds=True, use_lang_embeds=True, use_emo_embeds=True, lin_channels=4, emoin_channels=1024,
+                  use_spp=True, use_sep=True)     # == reference configs/base_blank_emo_lang_pitch.json "model"
 
 WORKLOADS = {
-    "cfg2": dict(B=32, T_x=150, T_y=800, desc="configs/base.json, LJSpeech-shaped synthetic batch, B=32/GPU, T_x<=150, T_y<=800, bf16 GEMMs"),
-    "cfg3": dict(B=32, T_x=375, T_y=872, desc="configs/base_blank.json-shaped synthetic batch, B=32/GPU, T_x<=375, T_y<=872, bf16 GEMMs"),
+    "cfg2": dict(B=32, T_x=150, T_y=800, desc="configs/base.json, LJSpeech-shaped synthetic batches, B=32/GPU, T_x<=150, T_y<=800, bf16 GEMMs"),
+    "cfg3": dict(B=32, T_x=375, T_y=872, desc="configs/base_blank.json-shaped synthetic batches, B=32/GPU, T_x<=375, T_y<=872, bf16 GEMMs"),
     "cfg4": dict(B=20, T_x=235, T_y=500, gin=256,
-                 desc="configs/base_blank_ms.json-shaped synthetic batch (multi-speaker, gin_channels=256, g ~ N(0,1) [B,256,1]), "
+                 desc="configs/base_blank_ms.json-shaped synthetic batches (multi-speaker, gin_channels=256, g ~ N(0,1) [B,256,1]), "
                       "B=20/GPU, T_x<=235, T_y<=500, bf16 GEMMs"),
     "cfg5dec": dict(B=32, T_x=127, T_y=400, gin=512, n_layers_enc=10, prosody=True, n_lang=10, lin=4,
-                    desc="configs/base_blank_emo_lang_pitch.json-shaped synthetic batch, B=32/GPU, T_x<=127, T_y<=400, gin_channels=512, "
-                         "10 encoder layers, language embedding (10 languages, 4 channels), 3 WaveNets per coupling block (wn + wn_energy + "
-                         "wn_pitch) with g, l, pitch, energy inputs; WITHOUT the emotion embeddings and the stochastic duration / pitch / "
-                         "energy predictors (SURVEY §8 f1)"),
+                    desc="cfg 5's decoder side only (round 1's workload, kept for comparison): gin 512, 10 encoder layers, language "
+                         "embedding, 3 WaveNets per coupling block; no emotion front end, deterministic duration predictor"),
+    "cfg5": dict(B=32, T_x=127, T_y=400, full=True,
+                 desc="configs/base_blank_emo_lang_pitch.json as the reference runs it: FlowGenerator(**hps.model) with the speaker / "
+                      "emotion front end, StochasticDurationPredictor, stochastic pitch / energy predictors, 3 WaveNets per coupling "
+                      "block, 10 encoder layers; B=32/GPU, T_x<=127, T_y<=400, bf16 GEMMs (bf16x3 in the predictors)"),
 }
 
 
+def make_batch(wl, rank, dev, i):
+    """Batch i of the rotation (SURVEY §8d shapes; batch 0 is the seed-1234 batch of round 1's bench) + its conditioning."""
+    from glow_tts_amd import train
+    B, gin = wl["B"], wl.get("gin", 0)
+    ids, t_x, y, t_y = train.synth_batch(B, wl["T_x"], wl["T_y"], rank + 1000 * i, dev, n_vocab=187 if wl.get("full") else 148)
+    g = torch.Generator().manual_seed(4321 + rank + 1000 * i)
+    cond = {}
+    if wl.get("full"):                               # cfg 5: g ~ N(0,1)[B,512], emo ~ U{0..4}, emo_cartesian ~ U[0,1.5)^3, pitch, energy, l
+        cond["g"] = torch.randn(B, 512, generator=g).to(dev)
+        cond["emo"] = torch.randint(0, 5, (B,), generator=g).to(dev)
+        cond["emo_cartesian"] = (torch.rand(B, 3, generator=g) * 1.5).to(dev)
+    elif gin:
+        cond["g"] = torch.randn(B, gin, 1, generator=g).to(dev)
+    if wl.get("prosody") or wl.get("full"):          # pitch ~ U[80,280) Hz with 30 % unvoiced zeros, energy ~ U[1,11)
+        cond["pitch"] = ((80 + 200 * torch.rand(B, 1, wl["T_y"], generator=g)) * (torch.rand(B, 1, wl["T_y"], generator=g) > 0.3)).to(dev)
+        cond["energy"] = (1 + 10 * torch.rand(B, 1, wl["T_y"], generator=g)).to(dev)
+        cond["l"] = torch.randint(0, 3, (B,), generator=g).to(dev)
+    return dict(ids=ids, t_x=t_x, y=y, t_y=t_y, lh=(t_x.tolist(), t_y.tolist()), cond=cond, valid=int(t_y.sum().item()))
+
+
 def mas_leg(dev, wl, rank, iters=100):
-    """MAS alone on a lattice of the workload's shape: alignments/s and achieved HBM GB/s."""
+    """MAS alone on a lattice of the workload's shape: alignments/s and achieved HBM GB/s on the device, and the same lattice
+    through the reference's Cython core (1 core) / the C restatement on all host cores."""
     from glow_tts_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(1234 + rank)
@@ -57,14 +93,15 @@ def mas_leg(dev, wl, rank, iters=100):
     t_y = torch.randint(max(1, T_y * 3 // 16), T_y // 2 + 1, (B,), generator=g, dtype=torch.int32) * 2
     t_y = torch.maximum(t_y, t_x + (t_x % 2))
     t_x[0], t_y[0] = T_x, T_y
-    logp = (torch.randn(B, T_x, T_y, generator=g) * 5.0 - 100.0).to(dev)
-    t_x, t_y = t_x.to(dev), t_y.to(dev)
+    logp_cpu = torch.randn(B, T_x, T_y, generator=g) * 5.0 - 100.0
+    logp = logp_cpu.to(dev)
+    t_xd, t_yd = t_x.to(dev), t_y.to(dev)
     path = torch.empty_like(logp)
     ws_bytes = L.gt_mas_workspace_bytes(B, T_x, T_y)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
 
     def run():
-        rc = L.gt_mas_f32(_lib.ptr(logp), None, _lib.ptr(t_x), _lib.ptr(t_y), _lib.ptr(path), _lib.GT_DT_F32, None, None,
+        rc = L.gt_mas_f32(_lib.ptr(logp), None, _lib.ptr(t_xd), _lib.ptr(t_yd), _lib.ptr(path), _lib.GT_DT_F32, None, None,
                           B, T_x, T_y, logp.stride(0), logp.stride(1), _lib.ptr(ws), ws_bytes, None, _lib.current_stream(dev))
         assert rc == 0, rc
     for _ in range(10):
@@ -79,90 +116,108 @@ def mas_leg(dev, wl, rank, iters=100):
     ms = e0.elapsed_time(e1) / iters
     assert int(path.sum().item()) == int(t_y.sum().item())
     algo_bytes = 8.0 * B * T_x * T_y + 8.0 * B
-    return {"alignments_per_sec": B / (ms * 1e-3), "ms_per_batch": ms, "achieved_GBps": algo_bytes / (ms * 1e-3) / 1e9,
-            "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes, "logp": logp, "t_x": t_x, "t_y": t_y}
+    out = {"alignments_per_sec": B / (ms * 1e-3), "ms_per_batch": ms, "achieved_GBps": algo_bytes / (ms * 1e-3) / 1e9,
+           "hbm_frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": algo_bytes}
+    if rank == 0:
+        out["cpu"] = mas_cpu(logp_cpu.numpy(), t_x.numpy(), t_y.numpy(), path.cpu().numpy())
+    return out
 
 
-def gate_conv_leg(dev, model, lh, T_y, p_drop, ragged, row_round, launches=20, replays=20):
-    """The dominant kernel alone, on the step's own shapes and weights: the WN in_layer k=5 conv + gate of the first
-    coupling block, `launches` back-to-back launches captured in ONE HIP graph (no host launch gaps, as in the step's own
-    graph) and timed with HIP events on the stream they run on.  -> average launch duration in ms."""
-    from glow_tts_amd import ops
-    wn = model.decoder.flows[2].wn
-    conv = wn.in_layers[0]
-    lens = torch.tensor([v // 2 for v in lh[1]], dtype=torch.int32, device=dev)
-    rc = ops.RowsCtx(lens, T_y // 2, lengths_host=[v // 2 for v in lh[1]], round_to=row_round) if ragged else ops.RowsCtx(lens, T_y // 2)
-    H = wn.hidden_channels
-    x = (torch.randn(rc.R, H, device=dev) * rc.rowmask[:, None]).to(torch.bfloat16)
-    y = torch.empty(rc.R, H, dtype=torch.bfloat16, device=dev); t = torch.empty_like(y); s_ = torch.empty_like(y)
-
-    def run():
-        ops.conv_rows(x, conv.pc, rc, bias=conv.bias, gate=True, out=y, gate_t=t, gate_s=s_, drop_p=p_drop, seed=1)
-    run(); torch.cuda.synchronize(dev)
-    g = torch.cuda.CUDAGraph()
-    st = torch.cuda.Stream()
-    st.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(st):
-        run()
-        with torch.cuda.graph(g, stream=st):
-            for _ in range(launches):
-                run()
-    torch.cuda.synchronize(dev)
-    for _ in range(3):
-        g.replay()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(replays):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) / (replays * launches), rc.R
+def mas_cpu(value, t_x, t_y, want_path):
+    """The same lattice on the host: reference core.pyx compiled by oracle/Makefile (oracle/_ref) on ONE core — the reference
+    builds it without OpenMP, so its prange is serial — and the C restatement with one utterance per thread."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import mas as omas
+    B = value.shape[0]
+    use_ref = omas.ref_module() is not None
+    core = omas.ref_maximum_path_c if use_ref else omas.oracle_maximum_path_c
+    times = []
+    for _ in range(5):
+        v = np.ascontiguousarray(value.copy()); p = np.zeros(v.shape, dtype=np.int32)
+        t0 = time.perf_counter()
+        core(p, v, t_x, t_y)
+        times.append(time.perf_counter() - t0)
+    assert np.array_equal(p, want_path.astype(np.int32)), "device MAS path != CPU path on the bench lattice"
+    one = min(times)
+    cores = os.cpu_count() or 1
+    nthr = min(cores, B)
+    with ThreadPoolExecutor(nthr) as pool:
+        best = None
+        for _ in range(5):
+            v = np.ascontiguousarray(value.copy()); p = np.zeros(v.shape, dtype=np.int32)
+            t0 = time.perf_counter()
+            list(pool.map(lambda i: omas.oracle_maximum_path_range(p, v, t_x, t_y, i, i + 1), range(B)))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return {"one_core": {"alignments_per_sec": B / one, "kind": "reference" if use_ref else "port",
+                         "what": ("reference monotonic_align/core.pyx (oracle/_ref), serial as the reference builds it" if use_ref
+                                  else "C restatement oracle/mas_oracle.c"), "cores": 1},
+            "all_cores": {"alignments_per_sec": B / best, "kind": "port", "what": "oracle/mas_oracle.c, one utterance per thread",
+                          "cores": nthr}}
 
 
-def cpu_baseline(ids, t_x, y, t_y, model, budget_utts=4, g=None, n_layers_enc=6, pitch=None, energy=None, lang=None):
-    """The oracle's training step on the host cores: same weights, a bounded sample of the same batch."""
+def cpu_baseline(batch, model, wl, budget_utts=4):
+    """The oracle's training step on the host cores: same weights, a bounded sample of batch 0."""
     from oracle import glowtts_ref as R
     from oracle import mas as omas
-    kind = "port"
     mas_core = omas.ref_maximum_path_c if omas.ref_module() is not None else omas.oracle_maximum_path_c
 
     def mp(logp, mask):
         p = omas.oracle_maximum_path(logp.numpy(), mask.numpy(), core=mas_core)
         return torch.from_numpy(p).float()
+    ids, t_x, y, t_y, cond = batch["ids"], batch["t_x"], batch["y"], batch["t_y"], batch["cond"]
     n = min(budget_utts, ids.shape[0])
-    P = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    hp = dict(hidden_channels=192, n_layers_enc=n_layers_enc, n_heads=2, window_size=4, kernel_size=3, prenet=True, mean_only=True,
-              n_blocks_dec=12, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
+    P = {k: v.detach().cpu().float().clone().requires_grad_(v.dtype.is_floating_point and "bins" not in k) for k, v in model.state_dict().items()}
     ids_c, tx_c, y_c, ty_c = ids[:n].cpu(), t_x[:n].cpu().long(), y[:n].cpu(), t_y[:n].cpu().long()
     Tx, Ty = int(tx_c.max()), int(ty_c.max())
     ids_c, y_c = ids_c[:, :Tx], y_c[:, :, :Ty]
+    c = {k: v[:n].cpu() for k, v in cond.items()}
+    if "pitch" in c:
+        c["pitch"], c["energy"] = c["pitch"][:, :, :Ty], c["energy"][:, :, :Ty]
     cores = torch.get_num_threads()
     times = []
     for it in range(2):
         t0 = time.perf_counter()
-        out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=None if g is None else g[:n].cpu(),
-                              pitch=None if pitch is None else pitch[:n, :, :Ty].cpu(), energy=None if energy is None else energy[:n, :, :Ty].cpu(),
-                              l=None if lang is None else torch.nn.functional.embedding(lang[:n].cpu(), P["emb_l.weight"]).unsqueeze(-1))
+        if wl.get("full"):
+            g = torch.Generator().manual_seed(it)
+            noises = (torch.randn(n, 2, Tx, generator=g), torch.randn(n, 1, Ty, generator=g), torch.randn(n, 1, Ty, generator=g))
+            out = R.train_forward_full(P, ids_c, tx_c, y_c, ty_c, mp, CFG5_MODEL, c["g"], c["emo"], c["emo_cartesian"], c["pitch"], c["energy"],
+                                       c["l"], noises)
+        else:
+            hp = dict(hidden_channels=192, n_layers_enc=wl.get("n_layers_enc", 6), n_heads=2, window_size=4, kernel_size=3, prenet=True,
+                      mean_only=True, n_blocks_dec=12, n_block_layers=4, kernel_size_dec=5, n_sqz=2)
+            out = R.train_forward(P, ids_c, tx_c, y_c, ty_c, mp, hp, g=c.get("g"), pitch=c.get("pitch"), energy=c.get("energy"),
+                                  l=None if "l" not in c else torch.nn.functional.embedding(c["l"], P["emb_l.weight"]).unsqueeze(-1))
         out["loss"].backward()
         times.append(time.perf_counter() - t0)
         for v in P.values():
             v.grad = None
     dt = min(times)
-    return {"value": float(ty_c.sum()) / dt, "unit": "mel-frames/s", "cores": cores, "kind": kind,
-            "sample": f"fwd+loss+bwd (no optimizer) of the first {n} utterances of the batch ({int(ty_c.sum())} valid frames), "
+    return {"value": float(ty_c.sum()) / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"fwd+loss+bwd (no optimizer) of the first {n} utterances of batch 0 ({int(ty_c.sum())} valid frames), "
                       f"PyTorch-CPU fp32 oracle + {'reference Cython' if mas_core is omas.ref_maximum_path_c else 'C port'} MAS, best of 2",
             "s_per_step": dt}
+
+
+def step_flops(wl, batch):
+    """Algorithmic FLOPs of one training step on this batch (3 x forward): decoder 21.35 (62.9 with the three WaveNets
+    of cfg 5) MFLOP per valid mel frame + encoder ~15.0 (23.8 with 10 layers) MFLOP per valid token + logp 2*80 MAC per lattice cell."""
+    dec = 62.9e6 if (wl.get("prosody") or wl.get("full")) else 21.35e6
+    enc = 23.8e6 if (wl.get("n_layers_enc", 6) == 10 or wl.get("full")) else 15.0e6
+    fr, tok = float(batch["valid"]), float(sum(batch["lh"][0]))
+    cells = float(sum(a * b for a, b in zip(*batch["lh"])))
+    return 3.0 * (dec * fr + enc * tok) + 2.0 * 2.0 * 80.0 * cells
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying one HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--one-batch", action="store_true", help="round 1's protocol: the same batch every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,119 +231,128 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from glow_tts_amd import _lib, ops, train
+    from glow_tts_amd import _lib, train
     _lib.lib()                                       # fails loudly if the HIP library is missing
     wl = WORKLOADS[args.workload]
     torch.manual_seed(1234)                          # identical initial weights on every rank
-    gin = wl.get("gin", 0)
-    cfg = dict(train.BASE_MODEL, gin_channels=gin, n_layers_enc=wl.get("n_layers_enc", 6), with_prosody_wn=bool(wl.get("prosody")),
-               n_lang=wl.get("n_lang", 0), lin_channels=wl.get("lin", 0))
-    model = train.build_model(cfg if (gin or wl.get("prosody")) else None, device=dev).train()
+    if wl.get("full"):
+        model = train.build_model(dict(CFG5_MODEL, n_lang=10), n_vocab=187, device=dev).train()
+    else:
+        gin = wl.get("gin", 0)
+        cfg = dict(train.BASE_MODEL, gin_channels=gin, n_layers_enc=wl.get("n_layers_enc", 6), with_prosody_wn=bool(wl.get("prosody")),
+                   n_lang=wl.get("n_lang", 0), lin_channels=wl.get("lin", 0))
+        model = train.build_model(cfg if (gin or wl.get("prosody")) else None, device=dev).train()
     if world > 1:
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
     use_graph = not args.no_graph
-    tr = train.Trainer(model, world=world, graph=use_graph)
-    ids, t_x, y, t_y = train.synth_batch(wl["B"], wl["T_x"], wl["T_y"], rank, dev)
-    spk = torch.randn(wl["B"], gin, 1, generator=torch.Generator().manual_seed(4321 + rank)).to(dev) if gin else None
-    cond = {"g": spk} if spk is not None else {}
-    if wl.get("prosody"):                            # pitch ~ U[80,280) Hz with 30 % unvoiced zeros, energy ~ U[1,11)
-        gp = torch.Generator().manual_seed(977 + rank)
-        cond["pitch"] = ((80 + 200 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)) * (torch.rand(wl["B"], 1, wl["T_y"], generator=gp) > 0.3)).to(dev)
-        cond["energy"] = (1 + 10 * torch.rand(wl["B"], 1, wl["T_y"], generator=gp)).to(dev)
-        if wl.get("n_lang"):
-            cond["l"] = torch.randint(0, 3, (wl["B"],), generator=gp).to(dev)
-    lh = (t_x.tolist(), t_y.tolist())                # host copy of the lengths (a data loader has them): no per-step sync
-    valid_frames = int(t_y.sum().item())
-    padded_frames = wl["B"] * wl["T_y"]
+    tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True)
+    nb = 1 if args.one_batch else N_BATCHES
+    batches = [make_batch(wl, rank, dev, i) for i in range(nb)]
+    call = lambda b: tr.step(b["ids"], b["t_x"], b["y"], b["t_y"], lengths_host=b["lh"], **b["cond"])      # noqa: E731
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        tr.step(ids, t_x, y, t_y, lengths_host=lh, **cond)
+    # graphs of every row bucket the rotation meets: captured up front, untimed, without taking a training step
+    t_cap = time.perf_counter()
+    tr.precapture([(b["ids"], b["t_x"], b["y"], b["t_y"], b["lh"], b["cond"]) for b in batches])
+    torch.cuda.synchronize(dev)
+    t_cap = time.perf_counter() - t_cap
+    for i in range(args.warmup):
+        call(batches[i % nb])
     barrier()
-    if not use_graph:
-        ops.KERNEL_TIMER.enable("in_layer_gate_conv")  # HIP events around every launch of the dominant kernel
+    steps0 = None if tr.stamps is None else int(tr.stamps.base.item()) // tr.stamps.per_step
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    stream = torch.cuda.current_stream(dev)
+    valid_total = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, mle = tr.step(ids, t_x, y, t_y, lengths_host=lh, **cond)
+    evs[0].record(stream)
+    for i in range(args.steps):
+        b = batches[i % nb]
+        loss, mle = call(b)
+        evs[i + 1].record(stream)
+        valid_total += b["valid"]
     barrier()
     wall = time.perf_counter() - t0
-    if use_graph:
-        # a replayed HIP graph has no room for event pairs between its kernel nodes: the dominant kernel is
-        # timed right after the timed region in 3 eager steps of the same trainer on the same batch
-        # (same process, same stream, same data), with HIP events around each of its 48 launches per step.
-        ops.KERNEL_TIMER.enable("in_layer_gate_conv")
-        for _ in range(3):
-            tr._step_impl(ids, t_x, y, t_y, lh, cond=cond)
-    kt = ops.KERNEL_TIMER.collect()
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
     if world > 1:
-        t = torch.tensor([wall, float(valid_frames)], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall, float(valid_total)], device=dev, dtype=torch.float64)
         tmax = t.clone(); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         tsum = t.clone(); torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
         wall, total_valid = float(tmax[0]), float(tsum[1])
     else:
-        total_valid = float(valid_frames)
+        total_valid = float(valid_total)
     assert torch.isfinite(loss).item(), "training step diverged"
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
-        ragged = tr.cfg.ragged
-        if ragged:                                    # utterances packed back to back: only their own frames (+ halos) are rows
-            _, R_dec = ops.RowsCtx.row_starts([v // 2 for v in lh[1]], wl["T_y"] // 2, tr.cfg.row_round)
-        else:
-            R_dec = wl["B"] * (wl["T_y"] // 2 + 2 * ops.HALO)
-        # in_layer 192 -> 384, k = 5: 368 640 MAC per squeezed frame.  Ragged layout: only the VALID squeezed
-        # frames count as algorithmic work (halo / rounding rows the kernel also walks do not)
-        rows_alg = valid_frames // 2 if ragged else R_dec
-        flops_launch = 2.0 * rows_alg * 384 * 192 * 5
+        flops_step = sum(step_flops(wl, batches[i % nb]) for i in range(args.steps)) / args.steps
+        rows_keys = sorted({tr._rows_key(-(-b["ids"].shape[1] // tr.pad_tx) * tr.pad_tx, -(-b["y"].shape[2] // tr.pad_ty) * tr.pad_ty, b["lh"])
+                            for b in batches})
         line = {
             "metric": "mel_frames_per_sec_train_step",
-            "value": total_valid / (wall / args.steps),
+            "value": total_valid / wall,
             "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": wl["B"], "T_x": wl["T_x"], "T_y": wl["T_y"],
-                       "valid_frames_per_gpu_step": valid_frames, "padded_frames_per_gpu_step": padded_frames,
-                       "rows_layout": (f"ragged (decoder rows {R_dec})" if ragged else f"uniform (decoder rows {R_dec})"),
+                       "batches_rotated": nb, "valid_frames_per_gpu_step_mean": valid_total / args.steps,
+                       "padded_frames_per_gpu_step": wl["B"] * wl["T_y"],
+                       "rows_layout": "ragged" if tr.cfg.ragged else "uniform",
+                       "row_buckets_(text, mel, frames)": [list(k) for k in rows_keys], "graphs_captured": tr.n_captures,
+                       "capture_s_untimed": round(t_cap, 2),
                        "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
-                       "launch": (("one HIP graph per step" if world == 1 else "two HIP graphs per step (fwd+bwd | optimizer), RCCL all-reduce between them")
-                                  if tr.graph_mode else "eager launches"),
-                       "sub_graph": "upstream-equivalent live sub-graph of configs/base.json (one WN per coupling block, "
-                                    "deterministic DurationPredictor) — SURVEY F1/F2/F4",
+                       "launch": (("one HIP graph per step (one per ragged-row bucket, captured up front)" if world == 1 else
+                                   "three HIP graphs per step (forward + decoder-side backward | encoder backward | optimizer), the RCCL "
+                                   "all-reduces of the flat gradient buffer launched between them") if tr.graph_mode else "eager launches"),
+                       "sub_graph": ("the reference's own FlowGenerator.forward for this config (models.py:1007-1133)" if wl.get("full") else
+                                     "upstream-equivalent live sub-graph of the base configs (one WN per coupling block, deterministic "
+                                     "DurationPredictor) — SURVEY F1/F2/F4: the fork's class does not construct for them"),
                        "final_loss": float(loss)},
-            "padded_frames_per_sec": world * padded_frames / (wall / args.steps),
+            "step_ms_median": step_ms[len(step_ms) // 2], "step_ms_min": step_ms[0], "step_ms_max": step_ms[-1],
+            "padded_frames_per_sec": world * wl["B"] * wl["T_y"] / (wall / args.steps),
         }
-        avg_ms, rows_launched = gate_conv_leg(dev, model, lh, wl["T_y"], model.decoder.flows[2].wn.p_dropout, ragged, tr.cfg.row_round)
-        tf = flops_launch / (avg_ms * 1e-3) / 1e12
-        traffic = None                               # HBM-side bytes per launch from the committed rocprofv3 --pmc passes
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gate_conv_pmc.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tf / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                            "traffic_source": "profiles/r01_gate_conv_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                                              "FETCH_SIZE x2 per the gfx950 correction; tools/gate_conv_pmc.py)",
-                            "kernel": "gt_conv_gemm_kernel<64|128,128,true> (WN in_layer k=5 conv + gate, 48 launches/step; 64-row tiles when "
-                                      "128-row tiles would give <= 256 workgroups, as on this workload)",
-                            "algorithmic_flops_per_launch": flops_launch, "launch_ms": avg_ms,
-                            "how": "20 launches on the step's shapes and weights captured in one HIP graph, HIP events around 20 replays",
-                            "rows_per_launch": rows_launched,
-                            "launch_ms_eager_in_step": (kt["ms"] / kt["count"]) if kt["count"] else None}
+        # ---- roofline: the fused WaveNet-layer forward kernel, timed INSIDE the replayed graphs by its own device stamps
+        roof = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        if tr.stamps is not None:
+            d = tr.stamps.durations_ticks()[steps0:steps0 + args.steps].double()          # [K, launches per step] in 10-ns ticks
+            nl = model.decoder.n_layers
+            res_mask = torch.tensor([(k % nl) != nl - 1 for k in range(d.shape[1])])      # the layers that carry the residual 1x1
+            us = d[:, res_mask].mean().item() / 100.0                                     # wall_clock64: 100 MHz
+            rows_valid = (valid_total / args.steps) / 2.0                                 # squeezed frames
+            flops_launch = 2.0 * rows_valid * (384 * 192 * 5 + 192 * 192)
+            tf = flops_launch / (us * 1e-6) / 1e12
+            roof.update({"achieved": tf, "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+                         "kernel": "gt_wn_layer_fwd_kernel<true> (WaveNet layer: k=5 conv 192->384 + gate + residual 1x1, one launch; "
+                                   f"{int(res_mask.sum())} launches per step)",
+                         "algorithmic_flops_per_launch": flops_launch, "launch_us": us,
+                         "launch_us_last_layer_variant": d[:, ~res_mask].mean().item() / 100.0,
+                         "how": "device-side begin / end stamps (wall_clock64, 100 MHz) written by every launch of the kernel inside the "
+                                "replayed HIP graphs of the timed steps: max(end) - min(start) per launch, mean over "
+                                f"{int(res_mask.sum()) * args.steps} launches; FLOPs count the VALID squeezed frames only",
+                         "profile": "profiles/r02_trainstep_*_summary.txt (rocprofv3 --kernel-trace --stats of the same command)"})
+            pmc = os.path.join(ROOT, "profiles", "r02_wn_layer_pmc.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    pj = json.load(f)
+                roof["traffic"] = pj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = pj.get("source")
+        roof["step"] = {"algorithmic_flops_per_step": flops_step, "achieved": flops_step / (wall / args.steps) / 1e12,
+                        "frac": flops_step / (wall / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                        "how": "SURVEY §8d: 3 x forward FLOPs over the valid frames / tokens of the rotated batches, / wall time per step"}
+        line["roofline"] = roof
         m = mas_leg(dev, wl, rank)
         line["mas"] = {"metric": "mas_alignments_per_sec", "value": world * m["alignments_per_sec"], "unit": "alignments/s",
-                       "ms_per_batch": m["ms_per_batch"],
+                       "ms_per_batch": m["ms_per_batch"], "cpu_baseline": m.get("cpu"),
                        "roofline": {"bound": "hbm", "achieved": m["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": m["hbm_frac"], "traffic": None, "kernel": "gt_mas_dp_kernel + gt_mas_expand_kernel",
                                     "algorithmic_bytes_per_launch": m["algorithmic_bytes"]}}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ids, t_x, y, t_y, model, g=spk, n_layers_enc=wl.get("n_layers_enc", 6),
-                                                pitch=cond.get("pitch"), energy=cond.get("energy"), lang=cond.get("l"))
+            line["cpu_baseline"] = cpu_baseline(batches[0], model, wl)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -75,10 +75,10 @@ PROTOTYPES = {
     "gt_mle_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gt_wn_layer_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p]),
+                                c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gt_wn_layer_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32,
-                                c_void_p, c_void_p, c_int, c_void_p]),
+                                c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_dds_sep_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_dds_out_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),

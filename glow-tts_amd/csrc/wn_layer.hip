@@ -63,16 +63,16 @@ struct WnArgs {
   int R;
   uint32_t drop_thresh, drop_seed; float drop_scale; const uint32_t* seed_dev;
   // live timing of the dominant kernel inside a captured graph (bench.py): stamps[2*slot] = min start, [2*slot+1] = max end
-  unsigned long long* stamps; int stamp_slot;
+  unsigned long long* stamps; int stamp_slot; const int32_t* stamp_base;     // slot = stamp_slot + *stamp_base (a per-step device counter)
 };
 
 __device__ __forceinline__ void stamp_begin(const WnArgs& a)
 {
-  if (a.stamps && threadIdx.x == 0) atomicMin(a.stamps + 2 * a.stamp_slot, (unsigned long long)wall_clock64());
+  if (a.stamps && threadIdx.x == 0) atomicMin(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)), (unsigned long long)wall_clock64());
 }
 __device__ __forceinline__ void stamp_end(const WnArgs& a)
 {
-  if (a.stamps && threadIdx.x == 0) atomicMax(a.stamps + 2 * a.stamp_slot + 1, (unsigned long long)wall_clock64());
+  if (a.stamps && threadIdx.x == 0) atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
 }
 
 __device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
@@ -440,7 +440,7 @@ extern "C" int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, co
                                void* acts, int ldacts, void* gate_t, void* gate_s, int ldts,
                                const void* w_res_frag, const float* bias_res, void* x_next, int ldxn,
                                int R, int Hc, int taps, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
-                               unsigned long long* stamps, int stamp_slot, void* stream)
+                               unsigned long long* stamps, int stamp_slot, const int32_t* stamp_base, void* stream)
 {
   if (R < 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
@@ -456,7 +456,7 @@ extern "C" int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, co
   a.bias1 = bias_in; a.bias2 = bias_res; a.cond = cond; a.ldc = ldc; a.B = B; a.row0 = row0; a.Tp = Tp > 0 ? Tp : 1; a.rowmask = rowmask;
   a.acts = static_cast<bf16_t*>(acts); a.ldacts = ldacts; a.Tt = static_cast<bf16_t*>(gate_t); a.Ss = static_cast<bf16_t*>(gate_s); a.ldts = ldts;
   a.Xnext = static_cast<bf16_t*>(x_next); a.ldxn = ldxn; a.resid = a.X; a.ldres = ldx;
-  a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot;
+  a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot; a.stamp_base = stamp_base;
   const int rc = fill_drop(a, drop_p, drop_seed, seed_dev);
   if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -470,7 +470,7 @@ extern "C" int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in
                                const float* rowmask, void* dx, int lddx, const void* w_res_dgrad_frag,
                                const void* via_skip, int ldvs, const void* gate_t, const void* gate_s, int ldts,
                                void* dpre, void* dpre_c, int lddp, int R, int Hc, int taps, float drop_p, uint32_t drop_seed,
-                               const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, void* stream)
+                               const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, const int32_t* stamp_base, void* stream)
 {
   if (R < 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
@@ -486,7 +486,7 @@ extern "C" int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in
   a.rowmask = rowmask; a.Xnext = static_cast<bf16_t*>(dx); a.ldxn = lddx; a.resid = static_cast<const bf16_t*>(resid); a.ldres = ldres;
   a.viaskip = static_cast<const bf16_t*>(via_skip); a.ldvs = ldvs;
   a.Tt = const_cast<bf16_t*>(static_cast<const bf16_t*>(gate_t)); a.Ss = const_cast<bf16_t*>(static_cast<const bf16_t*>(gate_s)); a.ldts = ldts;
-  a.dpre = static_cast<bf16_t*>(dpre); a.dpre_c = static_cast<bf16_t*>(dpre_c); a.lddp = lddp; a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot;
+  a.dpre = static_cast<bf16_t*>(dpre); a.dpre_c = static_cast<bf16_t*>(dpre_c); a.lddp = lddp; a.R = R; a.stamps = stamps; a.stamp_slot = stamp_slot; a.stamp_base = stamp_base;
   const int rc = fill_drop(a, drop_p, drop_seed, seed_dev);
   if (rc) return rc;
   static bool attr = false;                    // > 64 KB of LDS: opt in once (per process; the attribute is per device function)

@@ -138,7 +138,7 @@ def _fused_ok(wn):
     return True
 
 
-def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
+def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
     it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
     Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
@@ -155,6 +155,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
     acts_all = torch.empty(R, n * H, dtype=torch.bfloat16, device=dev)
     x = h0
     fused = _fused_ok(wn)
+    stamps = getattr(rc, "stamps", None)              # bench.py: live in-graph timing of the dominant kernel (ops.KernelStamps)
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts = acts_all[:, i * H:(i + 1) * H]
@@ -174,7 +175,8 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, stamps=None):
                                       None if last else _lib.ptr(rs.pc_res.fwd),
                                       None if last else rs.bias.data_ptr(), _lib.ptr(xn), H,
                                       R, H, wn.kernel_size, float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None,
-                                      _lib.ptr(stamps[0]) if stamps else None, (stamps[1] + i) if stamps else 0, _st(dev))
+                                      _lib.ptr(stamps.buf) if stamps else None, stamps.take() if stamps else 0,
+                                      _lib.ptr(stamps.base) if stamps else None, _st(dev))
             KERNEL_TIMER.stop(_ev)
             _lib.check(rcode, "gt_wn_layer_fwd")
             ts.append(t); ss.append(s)
@@ -247,7 +249,7 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
         _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(nxt.pc.dgrad), _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
                                      _lib.ptr(dXn), H, _lib.ptr(rs.pc_res.dgrad), _lib.ptr(via), via.stride(0),
                                      _lib.ptr(ts[i]), _lib.ptr(ss[i]), H, _lib.ptr(dpre_i), _lib.ptr(dpre_ci), 2 * H, R, H, wn.kernel_size,
-                                     float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None, None, 0, _st(dev)),
+                                     float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None, None, 0, None, _st(dev)),
                    "gt_wn_layer_bwd")
         acts = acts_all[:, i * H:(i + 1) * H]
         grads.update(conv_param_grads(rs, acts, None, R, parts=[(dXn, 0, H), (dskip, H, H)]))
@@ -258,7 +260,7 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
     # d x_0 = dgrad(in_layer_0) + (residual path), through the mask of x_0's producer: the same kernel without its second stage
     dh0 = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
     _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(wn.in_layers[0].pc.dgrad), _lib.ptr(dX), H, _lib.ptr(rc.rowmask),
-                                 _lib.ptr(dh0), H, None, None, 0, None, None, 0, None, None, 0, R, H, wn.kernel_size, 0.0, 0, None, None, 0,
+                                 _lib.ptr(dh0), H, None, None, 0, None, None, 0, None, None, 0, R, H, wn.kernel_size, 0.0, 0, None, None, 0, None,
                                  _st(dev)), "gt_wn_layer_bwd")
     return dh0, grads, dcond
 

@@ -50,6 +50,41 @@ class _KernelTimer:
 
 KERNEL_TIMER = _KernelTimer()
 
+
+class KernelStamps:
+    """Device-side begin / end stamps of the fused WaveNet-layer forward launches (wall_clock64 ticks): the kernel's duration
+    INSIDE a replayed HIP graph, where there is no room for event pairs between kernel nodes.  A RowsCtx carries it
+    (`rc.stamps`); the step bumps `base` by `per_step` (one tiny launch), so every replay fills its own slots."""
+
+    def __init__(self, device, per_step, max_steps=512):
+        self.per_step, self.max_steps = per_step, max_steps
+        n = per_step * max_steps
+        init = torch.empty(2 * n, dtype=torch.int64)
+        init[0::2] = -1                                  # ~0 as uint64: atomicMin target
+        init[1::2] = 0
+        self.buf = init.to(device)
+        self.base = torch.zeros(1, dtype=torch.int32, device=device)
+        self._next = 0
+
+    def begin_step(self):
+        """inside the step (captured with it): the slots of this execution start at the counter's current value"""
+        self._next = 0
+
+    def end_step(self):
+        self.base.add_(self.per_step)
+
+    def take(self):
+        k = self._next
+        self._next += 1
+        assert k < self.per_step
+        return k
+
+    def durations_ticks(self):
+        """[steps executed, per_step] int64 tensor of (max end - min start), on the host"""
+        n = int(self.base.item()) // self.per_step
+        b = self.buf[: 2 * n * self.per_step].cpu().view(n, self.per_step, 2)
+        return (b[:, :, 1] - b[:, :, 0])
+
 _SEED = {}
 
 
@@ -118,6 +153,7 @@ class RowsConfig:
         self.row_round = row_round  # ragged R is rounded up to this (row tiles of the GEMMs; 512 under HIP graphs)
         self.host_lengths = {}      # "x" / "y" -> list of ints for the batch in flight (set by FlowGenerator.forward)
         self.prebuilt = {}          # "x" / "y" -> ragged RowsCtx the next forward must use (train.Trainer, around capture / replay)
+        self.stamps = None          # KernelStamps for the decoder's fused WaveNet kernels (bench.py), attached to the "y" context
 
 
 DEFAULT_ROWS = RowsConfig()
@@ -177,6 +213,8 @@ class RowsCtx:
     rounded up to `round_to` (the last utterance owns the extra, masked rows) so that a captured HIP graph can be
     replayed for every batch of the same rounded size; Tp = the largest row count of one utterance (grid sizing).
     The host needs the lengths (the data loader has them; no device sync)."""
+
+    stamps = None           # ops.KernelStamps or None (set by make_ctx for the decoder's context)
 
     def __init__(self, lengths, T, lengths_host=None, round_to=None):
         _lib.require_cuda(lengths)
@@ -291,11 +329,13 @@ def make_ctx(lengths, T, which, div=1, cfg=None):
     pre = cfg.prebuilt.get(which)
     if pre is not None:                                     # the captured-graph path: context built (and refreshed) outside
         assert pre.T == int(T) and pre.B == int(lengths.shape[0]), "prebuilt rows context does not fit this batch"
-        return pre
-    lh = cfg.host_lengths.get(which) if cfg.ragged else None
-    if lh is None:
-        return RowsCtx(lengths, T)
-    return RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh], round_to=cfg.row_round)
+        rc = pre
+    else:
+        lh = cfg.host_lengths.get(which) if cfg.ragged else None
+        rc = RowsCtx(lengths, T) if lh is None else RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh], round_to=cfg.row_round)
+    if which == "y":
+        rc.stamps = cfg.stamps
+    return rc
 
 
 class PackSlice:

@@ -258,7 +258,7 @@ class Trainer:
     WARMUPS = 2
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
-                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32):
+                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph forces the phased, several-graph form (default: world > 1)."""
         from collections import OrderedDict
@@ -296,6 +296,13 @@ class Trainer:
         self.cfg = model.rows_cfg                 # this model's rows-layout state (ops.RowsConfig): nothing process-global
         self.cfg.ragged = (os.environ.get("GT_RAGGED", "1") != "0") if ragged is None else bool(ragged)
         self.cfg.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
+        # bench.py: device-side begin / end stamps of every fused WaveNet-layer forward launch, valid inside replayed graphs
+        self.stamps = None
+        if kernel_stamps:
+            from . import ops
+            dec = model.decoder
+            per_step = dec.n_blocks * dec.n_layers * (3 if hasattr(dec.flows[2], "wn_pitch") else 1)
+            self.stamps = self.cfg.stamps = ops.KernelStamps(next(model.parameters()).device, per_step)
 
     @property
     def adam_steps(self):
@@ -316,6 +323,8 @@ class Trainer:
 
     def _begin(self, device):
         from . import ops
+        if self.stamps is not None:
+            self.stamps.begin_step()
         ops.bump_seed(device)
         ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
         self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
@@ -334,6 +343,8 @@ class Trainer:
         # reference commons.clip_grad_value_(params, None): total grad norm, no clipping — the sum of squares
         # falls out of the optimizer's own pass over the gradients (no ~1.8k .item() syncs)
         self.grad_norm = torch.sqrt(self.opt.step())
+        if self.stamps is not None:
+            self.stamps.end_step()
         ops.arena_end(device)
 
     def _phase1(self, ids, t_x, y, t_y, lengths_host=None, cond=None):

@@ -360,18 +360,19 @@ int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const 
  *                   dropout replayed, [R, 2H] = [d tanh-half | d sigmoid-half];  dpre_c (optional): the same before the dropout
  *                   mask (the gradient of the conditioning term, which is added after the dropout).  NULL: dx only (bottom layer).
  * stamps (optional, bench.py): device uint64 pairs [2*slot] = min start / [2*slot+1] = max end of the launch in
- * wall_clock64() ticks (100 MHz) — the kernel's duration inside a replayed HIP graph; init to ~0 / 0. */
+ * wall_clock64() ticks (100 MHz) — the kernel's duration inside a replayed HIP graph; init to ~0 / 0;
+ * slot = stamp_slot + *stamp_base (stamp_base: optional device int32 the step bumps, so every replay fills fresh slots). */
 int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, const float* bias_in,
                     const float* cond, int ldc, const int32_t* row0, int B, int Tp, const float* rowmask,
                     void* acts, int ldacts, void* gate_t, void* gate_s, int ldts,
                     const void* w_res_frag, const float* bias_res, void* x_next, int ldxn,
                     int R, int H, int taps, float drop_p, uint32_t drop_seed, const uint32_t* seed_dev,
-                    unsigned long long* stamps, int stamp_slot, void* stream);
+                    unsigned long long* stamps, int stamp_slot, const int32_t* stamp_base, void* stream);
 int gt_wn_layer_bwd(const void* dpre_next, int lddn, const void* w_in_dgrad_frag, const void* resid, int ldres,
                     const float* rowmask, void* dx, int lddx, const void* w_res_dgrad_frag,
                     const void* via_skip, int ldvs, const void* gate_t, const void* gate_s, int ldts,
                     void* dpre, void* dpre_c, int lddp, int R, int H, int taps, float drop_p, uint32_t drop_seed,
-                    const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, void* stream);
+                    const uint32_t* seed_dev, unsigned long long* stamps, int stamp_slot, const int32_t* stamp_base, void* stream);
 
 /* ---- Stochastic duration / pitch / energy predictors (models.py:217-481, modules.py:683-819,
  * transforms.py:12-202) on the rows layout.  C = 192 (filter_channels = in_channels, models.py:223).  `utt` is the

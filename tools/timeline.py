@@ -41,3 +41,18 @@ for t, d in ev:
         over += t - last_t
     n += d; last_t = t
 print(f"time with >= 2 kernels running: {over / 1e6:.3f} ms")
+
+# per-stream chains: time from the end of one kernel to the start of the next ON THE SAME STREAM (launch / dependency latency)
+by_stream = {}
+for r in sorted(step, key=lambda r: r[1]):
+    by_stream.setdefault(r[4], []).append(r)
+for sid, lst in sorted(by_stream.items(), key=lambda kv: -len(kv[1])):
+    kt = sum(r[2] - r[1] for r in lst)
+    gaps_s = [max(0, b[1] - a[2]) for a, b in zip(lst, lst[1:])]
+    print(f"stream {sid}: {len(lst)} kernels, kernel time {kt / 1e6:.3f} ms, span {(lst[-1][2] - lst[0][1]) / 1e6:.3f} ms, "
+          f"sum of gaps {sum(gaps_s) / 1e6:.3f} ms (median gap {sorted(gaps_s)[len(gaps_s) // 2] / 1e3 if gaps_s else 0:.2f} us)")
+    agg = {}
+    for r in lst:
+        a = agg.setdefault(r[0][:70], [0, 0]); a[0] += 1; a[1] += r[2] - r[1]
+    for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
+        print(f"      {tot / 1e6:7.3f} ms {cnt:4d} x {tot / cnt / 1e3:7.1f} us  {name}")

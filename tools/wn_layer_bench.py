@@ -28,14 +28,14 @@ def fwd(wn, i, res=True):
     il, rs = wn.in_layers[i], wn.res_skip_layers[i]
     _lib.check(L.gt_wn_layer_fwd(_lib.ptr(x), H, _lib.ptr(il.pc.fwd), _lib.ptr(il.bias), None, 0, None, 0, rc.Tp, _lib.ptr(rc.rowmask),
                                  _lib.ptr(acts), n * H, _lib.ptr(t), _lib.ptr(s), H, _lib.ptr(rs.pc_res.fwd) if res else None,
-                                 rs.bias.data_ptr() if res else None, _lib.ptr(xn), H, R, H, 5, 0.05, 7, None, None, 0, st()), "fwd")
+                                 rs.bias.data_ptr() if res else None, _lib.ptr(xn), H, R, H, 5, 0.05, 7, None, None, 0, None, st()), "fwd")
 
 
 def bwd(wn, i, s2=True):
     il, rs = wn.in_layers[i + 1], wn.res_skip_layers[i]
     _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(il.pc.dgrad), _lib.ptr(x), H, _lib.ptr(rc.rowmask), _lib.ptr(dx), H,
                                  _lib.ptr(rs.pc_res.dgrad) if s2 else None, _lib.ptr(xn), H, _lib.ptr(t), _lib.ptr(s), H, _lib.ptr(dpo), None, 2 * H,
-                                 R, H, 5, 0.05, 7, None, None, 0, st()), "bwd")
+                                 R, H, 5, 0.05, 7, None, None, 0, None, st()), "bwd")
 
 
 def timeit(name, fn, launches=48, replays=10):
@@ -59,6 +59,18 @@ def timeit(name, fn, launches=48, replays=10):
     print(f"{name:44s} {e0.elapsed_time(e1) / (replays * launches) * 1e3:7.1f} us / launch   (R = {R})", flush=True)
 
 
+for frac in (1, 2, 4, 8):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
+    Rs = R // frac // 64 * 64
+    def f(k, Rs=Rs):
+        il = wns[(k // 3) % 12].in_layers[k % 3]
+        _lib.check(L.gt_wn_layer_fwd(_lib.ptr(x), H, _lib.ptr(il.pc.fwd), _lib.ptr(il.bias), None, 0, None, 0, rc.Tp, _lib.ptr(rc.rowmask),
+                                     _lib.ptr(acts), n * H, _lib.ptr(t), _lib.ptr(s), H, None, None, None, H, Rs, H, 5, 0.0, 7, None, None, 0, None, st()), "fwd")
+    def b(k, Rs=Rs):
+        il = wns[(k // 3) % 12].in_layers[k % 3]
+        _lib.check(L.gt_wn_layer_bwd(_lib.ptr(dpre), 2 * H, _lib.ptr(il.pc.dgrad), None, 0, _lib.ptr(rc.rowmask), _lib.ptr(dx), H,
+                                     None, None, 0, None, None, 0, None, None, 0, Rs, H, 5, 0.0, 7, None, None, 0, None, st()), "bwd")
+    timeit(f"fwd stage 1 only, streaming, {Rs // 64} workgroups", f)
+    timeit(f"bwd stage 1 only, streaming, {Rs // 64} workgroups", b)
 timeit("fwd fused, L2-hot weights", lambda k: fwd(wns[0], 0))
 timeit("fwd fused, streaming weights (36 layers)", lambda k: fwd(wns[(k // 3) % 12], k % 3))
 timeit("fwd stage 1 only, hot", lambda k: fwd(wns[0], 0, False))
