@@ -165,6 +165,9 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
   // weight fragments of step `it` (slice, tap): 4 k-steps x this wave's 3 column blocks
   uint4 ring[RING][4][3];
   auto w_load = [&](int it, uint4 (&dst)[4][3]) {
+#ifdef WN_EXP_NOLOAD
+    if (it > RING) return;
+#endif
     const int slice = it / TAPS, tap = it - slice * TAPS;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -193,8 +196,12 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
         const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * LDP + ks * 16);
 #pragma unroll
         for (int bn = 0; bn < 3; ++bn) {
+#ifdef WN_EXP_NOMFMA
+          acc[bn][0][0] += __uint_as_float(ring[it % RING][ks][bn].x) + b0[0]; acc[bn][1][1] += __uint_as_float(ring[it % RING][ks][bn].w) + b1[1];
+#else
           acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
           acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
+#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
