@@ -36,6 +36,7 @@ PROTOTYPES = {
     "gt_squeeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_unsqueeze_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_flow_scalars": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gt_flow_scalars_multi": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "gt_actnorm_ddi": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gt_actnorm_invconv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -79,6 +80,8 @@ PROTOTYPES = {
     "gt_wn_layer_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32,
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gt_wn_boundary_fwd": (c_int, [c_void_p, c_void_p]),
+    "gt_wn_boundary_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_dds_sep_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_dds_out_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),
@@ -112,6 +115,36 @@ class PackDesc(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("Np_fwd", ctypes.c_int32),
                 ("Kp_fwd", ctypes.c_int32), ("Np_dgrad", ctypes.c_int32), ("Kp_dgrad", ctypes.c_int32), ("gate", ctypes.c_int32),
                 ("row_start", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class BoundaryFwdArgs(ctypes.Structure):
+    """struct gt_boundary_fwd_args (include/glowtts_hip.h); pointer fields take tensor.data_ptr() or None"""
+    _fields_ = [("acts", c_void_p), ("ldacts", c_int), ("w_skip", c_void_p), ("b_skip", c_void_p),
+                ("w_end", c_void_p), ("b_end", c_void_p), ("ks_end", c_int), ("y", c_void_p), ("wn_out", c_void_p),
+                ("logs_raw", c_void_p), ("z", c_void_p), ("logdet", c_void_p), ("rowutt", c_void_p), ("sigmoid_scale", c_int),
+                ("x_in", c_void_p), ("an_logs", c_void_p), ("an_bias", c_void_p), ("w_ic", c_void_p), ("scal", c_void_p),
+                ("len", c_void_p), ("B", c_int), ("y_next", c_void_p), ("y0_bf16", c_void_p), ("w_start", c_void_p),
+                ("b_start", c_void_p), ("ks_start", c_int), ("h_next", c_void_p), ("rowmask", c_void_p),
+                ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int)]
+
+
+class BoundaryBwdArgs(ctypes.Structure):
+    """struct gt_boundary_bwd_args (include/glowtts_hip.h)"""
+    _fields_ = [("dh", c_void_p), ("w_start_d", c_void_p), ("ks_start_d", c_int), ("dx_in", c_void_p), ("x", c_void_p),
+                ("an_logs", c_void_p), ("an_bias", c_void_p), ("w_ic", c_void_p), ("scal", c_void_p), ("len", c_void_p), ("B", c_int),
+                ("d_an_logs", c_void_p), ("d_an_bias", c_void_p), ("d_w_ic", c_void_p),
+                ("dz_in", c_void_p), ("logs_raw", c_void_p), ("y", c_void_p), ("dlogdet", c_void_p), ("rowutt", c_void_p),
+                ("sigmoid_scale", c_int), ("dx_out", c_void_p), ("dout", c_void_p), ("w_end_d", c_void_p), ("ks_end_d", c_int),
+                ("dwn_out", c_void_p), ("w_skip_d", c_void_p), ("ks_skip_d", c_int), ("via_skip", c_void_p), ("ldvs", c_int),
+                ("rowmask", c_void_p), ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int)]
+
+
+def fill_args(cls, **kw):
+    """ctypes struct from keyword arguments: tensors become device pointers, None stays NULL, ints stay ints."""
+    a = cls()
+    for k, v in kw.items():
+        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+    return a
 
 
 GT_TILE_AUTO, GT_TILE_64x64, GT_TILE_64x128, GT_TILE_128x64, GT_TILE_128x128, GT_TILE_256x64 = 0, 1, 2, 3, 4, 5

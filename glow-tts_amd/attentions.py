@@ -55,6 +55,15 @@ class CouplingBlock(nn.Module):
             self.wn_pitch = WNP(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout, 1, n_sqz)
             self.wn_energy = WNP(hidden_channels, kernel_size, dilation_rate, n_layers, p_dropout, 1, n_sqz)
 
+    def set_boundary_fused(self, on):
+        """Keep fragment-ordered twins of the start / end / skip-cat images for the fused between-WaveNets kernels
+        (csrc/wn_boundary.hip; the owning FlowSpecDecoder decides).  Returns whether the block's shape qualifies."""
+        ok = bool(on) and self.in_channels == 160 and self.hidden_channels == 192 and self.n_layers == 4 and \
+            getattr(self.wn, "fused", False) and not hasattr(self, "wn_pitch")
+        self.start.also_frag = self.end.also_frag = ok
+        self.wn.set_boundary_frag(ok)
+        return ok
+
     def store_inverse(self):
         """attentions.py:188-194 removes the weight norms of wn / wn_energy / wn_pitch so that synthesis stops
         recomputing g*v/|v|: here that product only exists inside the packed bf16 images, which FlowSpecDecoder.store_inverse

@@ -100,7 +100,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("hipcc failed")
     # gt_flow_scalars: ONE thread's 4x4 Gauss-Jordan with pivoting in fp64 — a dynamically indexed private array (144 B), no spills
-    bad = audit(reports, allow_scratch=("gt_flow_scalars_kernel",))
+    bad = audit(reports, allow_scratch=("gt_flow_scalars_kernel", "gt_flow_scalars_multi_kernel"))
     if bad:
         for src, name, scratch, vsp in bad:
             sys.stderr.write(f"[build] {src}: kernel {name} uses scratch ({scratch} B/lane, {vsp} spilled VGPRs)\n")

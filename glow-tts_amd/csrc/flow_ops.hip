@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void gt_unsqueeze_rows_kernel(const float* __r
 
 // ------------------------------------------------------------------ ActNorm + InvConvNear
 // scal[0] = sum(logs), scal[1] = log det W (4x4), scal[2..17] = W^{-T} (row major).
-__global__ void gt_flow_scalars_kernel(const float* __restrict__ logs, int C, const float* __restrict__ W, float* __restrict__ scal)
+__device__ __forceinline__ void flow_scalars_one(const float* __restrict__ logs, int C, const float* __restrict__ W, float* __restrict__ scal)
 {
   float s = 0.f;
   for (int i = threadIdx.x; i < C; i += 64) s += logs[i];
@@ -87,6 +87,16 @@ __global__ void gt_flow_scalars_kernel(const float* __restrict__ logs, int C, co
     scal[1] = (float)log(det);                                      // torch.logdet: nan if det < 0
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) scal[2 + i * 4 + j] = (float)inv[j][i];   // W^{-T}
   }
+}
+__global__ void gt_flow_scalars_kernel(const float* __restrict__ logs, int C, const float* __restrict__ W, float* __restrict__ scal)
+{
+  flow_scalars_one(logs, C, W, scal);
+}
+// all flow blocks of a decoder in one launch: block b reads logs_ptrs[b] / w_ptrs[b] (device pointer tables), writes scal[18 b ..]
+__global__ void gt_flow_scalars_multi_kernel(const float* const* __restrict__ logs_ptrs, const float* const* __restrict__ w_ptrs, int C,
+                                             float* __restrict__ scal)
+{
+  flow_scalars_one(logs_ptrs[blockIdx.x], C, w_ptrs[blockIdx.x], scal + 18 * blockIdx.x);
 }
 
 // thread = (row, group g): members {2g, 2g+1, C/2+2g, C/2+2g+1}.
@@ -422,6 +432,15 @@ extern "C" int gt_unsqueeze_rows_f32(const float* rows, float* y, const int32_t*
   hipLaunchKernelGGL(gt_unsqueeze_rows_kernel, dim3((Ty / 2 + 1 + 31) / 32, B), dim3(256), 0, GT_ST(stream), rows, y, len_sq, B, C, Ty, Tp, row0);
   GT_RET();
 }
+extern "C" int gt_flow_scalars_multi(const void* logs_ptrs, const void* w_ptrs, int C, float* scal, int n, void* stream)
+{
+  if (!logs_ptrs || !w_ptrs || !scal || C <= 0 || n < 0) return GT_E_INVAL;
+  if (n == 0) return GT_OK;
+  hipLaunchKernelGGL(gt_flow_scalars_multi_kernel, dim3(n), dim3(64), 0, GT_ST(stream), static_cast<const float* const*>(logs_ptrs),
+                     static_cast<const float* const*>(w_ptrs), C, scal);
+  GT_RET();
+}
+
 extern "C" int gt_flow_scalars(const float* logs, int C, const float* W, float* scal, void* stream)
 {
   if (!logs || !W || !scal || C <= 0) return GT_E_INVAL;

@@ -1,0 +1,582 @@
+// Everything BETWEEN two WaveNets of the flow decoder as one kernel, forward and backward, gfx950.
+//
+// reference, per flow block b (models.py:765-785 runs ActNorm, InvConvNear, CouplingBlock in turn):
+//     y      = InvConvNear(ActNorm(x))                                        modules.py:584-599, 635-665
+//     h      = start(y0) * mask                                               attentions.py:147
+//     out    = WN(h)           = (sum_i skip_i(acts_i)) * mask                modules.py:144-171
+//     m|logs = end(out)                                                       attentions.py:162-165
+//     z      = [y0 | (m + exp(logs) * y1) * mask],  logdet += sum logs * mask attentions.py:171-184
+// All of it except the WaveNet's k=5 layers is ROW-LOCAL (1x1 convs, elementwise maps, 4x4 channel mixing, per-utterance
+// sums).  Round 1 ran it as five launches per block forward (skip GEMM, end conv, coupling, ActNorm+InvConv, start conv)
+// and five backward, ~13 us each on the decoder's dependent chain for a few microseconds of work.  Here a workgroup owns
+// 64 rows and walks the whole chain on them, tile after tile in LDS:
+//
+//   forward  [tail of block b]    acts [64, 4H] -> skip GEMM (K = 768) -> wn_out -> end conv (K = 192) -> m | logs
+//                                 -> coupling -> z (HBM: the flow state, saved for the backward) + per-utterance log-det
+//            [head of block b+1]  ActNorm + InvConvNear on the z tile -> y (HBM), y0 (bf16) -> start conv (K = 80) -> h
+//   backward [head of block b+1]  d h -> start data gradient (K = 192, N = 80) + identity path -> ActNorm / InvConvNear
+//                                 backward (parameter gradients folded over the tile in LDS, then atomics)
+//            [tail of block b]    coupling backward -> d[m | logs] -> end data gradient (K = 160) -> d wn_out -> skip data
+//                                 gradient (N = 768) -> the skip-path gradient of every layer's gated activations
+// The first / last kernels of a pass have only a head or only a tail.  MFMA A = weights in fragment order straight from
+// L2 (every workgroup reads the same 0.4 MB: L2-resident), B = the bf16 LDS tile; accumulators e = 4g + j of lane (r, h)
+// are row r, column 32 * block + 8g + 4h + j.  What leaves for HBM is what the batched weight gradients and the next
+// pass read anyway (wn_out, y0, d out, d wn_out) plus the fp32 flow state.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int H = 192, C = 160, HALF = 80, NL = 4, G = C / 4;
+constexpr int BM = 64;
+constexpr int AP = H + 8;                     // bf16 tile pitch (halfs): 400 B = 16 mod 128 -> conflict-free ds_read_b128
+constexpr int XP = 136;                       // y0 tile pitch (halfs): K = 80 -> 5 k-steps; 272 B = 16 mod 128
+constexpr int ZP = C + 4;                     // fp32 tile pitch (floats)
+constexpr int RD = 8;                         // weight-fragment ring: k-steps in flight per wave
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // plain vector: staging arrays of it stay in registers
+
+__device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
+{
+  return *reinterpret_cast<const uint4*>(W + ((size_t)f * 64 + lane) * 8);
+}
+__device__ __forceinline__ bf16x8_t asfrag(const uint4& u) { return __builtin_bit_cast(bf16x8_t, u); }
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2bf(a, b), pack2bf(c, d)); }
+
+template <int NB>
+__device__ __forceinline__ void acc_zero(f32x16_t (&acc)[NB])
+{
+#pragma unroll
+  for (int bn = 0; bn < NB; ++bn)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[bn][e] = 0.0f;
+}
+
+// acc[bn] += W[block nb0 + bn][k-steps 0 .. KK) x Bt: W in fragment order with KS k-steps per block row; Brow points at
+// (this lane's row, 8h) of the bf16 LDS tile, k-step kk is 16 halfs further.
+template <int NB, int KK>
+__device__ __forceinline__ void gemm_lds(const bf16_t* __restrict__ W, int KS, int nb0, const bf16_t* Brow, int lane, f32x16_t (&acc)[NB])
+{
+  constexpr int D = KK < RD ? KK : RD;
+  uint4 ring[D][NB];
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int bn = 0; bn < NB; ++bn) ring[p][bn] = ldfrag(W, (nb0 + bn) * KS + p, lane);
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(Brow + kk * 16);
+#pragma unroll
+    for (int bn = 0; bn < NB; ++bn) {
+      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[kk % D][bn]), bfm, acc[bn], 0, 0, 0);
+      if (kk + D < KK) ring[kk % D][bn] = ldfrag(W, (nb0 + bn) * KS + kk + D, lane);
+    }
+  }
+}
+
+// per-utterance sum of 64 per-row values (one wave; rows of an utterance are consecutive): segmented scan, then ONE
+// atomic per utterance run of the tile (per-row atomics onto B addresses would serialise at L2)
+__device__ __forceinline__ void utt_atomic_add(float* __restrict__ dst, float s, int utt, int lane)
+{
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float v = __shfl_up(s, off);
+    const int u = __shfl_up(utt, off);
+    if (lane >= off && u == utt) s += v;
+  }
+  const int un = __shfl_down(utt, 1);
+  if ((lane == 63 || un != utt) && s != 0.0f) atomicAdd(dst + utt, s);
+}
+
+// layer slice L of the skip GEMM (K = 4H in four LDS tiles): registers -> LDS, barrier, 12 k-steps; the weight ring runs
+// across the slices (L is a template parameter so that every ring / staging index is a compile-time constant)
+template <int L>
+__device__ __forceinline__ void skip_slice(const u32x4_t (&xr)[6], bf16_t* As, const bf16_t* __restrict__ Wskip, int wm, int wn, int r, int h,
+                                           int lane, uint4 (&ring)[RD][3], f32x16_t (&acc)[3])
+{
+  constexpr int KK = NL * H / 16, kbase = L * (H / 16);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int chunk = threadIdx.x + 256 * i, row = chunk / 24, c8 = chunk - row * 24;
+    *reinterpret_cast<u32x4_t*>(As + (L * BM + row) * AP + c8 * 8) = xr[i];
+  }
+  __syncthreads();
+  const bf16_t* brow = As + (L * BM + 32 * wm + r) * AP + 8 * h;
+#pragma unroll
+  for (int k2 = 0; k2 < H / 16; ++k2) {
+    const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn) {
+      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[(kbase + k2) % RD][bn]), bfm, acc[bn], 0, 0, 0);
+      if (kbase + k2 + RD < KK) ring[(kbase + k2) % RD][bn] = ldfrag(Wskip, (3 * wn + bn) * KK + kbase + k2 + RD, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+constexpr int F_AS = 0;                                    // acts slices [4][64][AP] bf16; later At [64][AP] (slice 0) / y0 tile
+constexpr int F_O = BM * AP * 2;                           // m | logs tile [64][ZP] fp32 (over slices 1, 2 once they are dead)
+constexpr int F_Z = F_O + BM * ZP * 4;                     // z tile [64][ZP] fp32
+constexpr int F_RS = (F_Z + BM * ZP * 4 > NL * BM * AP * 2 ? F_Z + BM * ZP * 4 : NL * BM * AP * 2);   // row sums [64] fp32
+constexpr int FWD_LDS = F_RS + BM * 4;
+static_assert(F_O + BM * ZP * 4 <= 3 * BM * AP * 2, "the m | logs tile must stay clear of acts slice 3");
+
+template <bool TAIL, bool HEAD>
+__global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, R = a.R;
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem + F_AS);
+  float* Ot = reinterpret_cast<float*>(smem + F_O);
+  float* Zt = reinterpret_cast<float*>(smem + F_Z);
+  float* rowsum = reinterpret_cast<float*>(smem + F_RS);
+  const int mrow = m0 + 32 * wm + r;                        // this lane's row in the MFMA epilogues
+  const float rm_l = mrow < R ? a.rowmask[mrow] : 0.0f;
+
+  if (TAIL) {
+    const bf16_t* acts = static_cast<const bf16_t*>(a.acts);
+    const bf16_t* Wskip = static_cast<const bf16_t*>(a.w_skip);
+    // the tile's gated activations, all four layers: 6 x 16 B per thread per layer slice, in flight together
+    u32x4_t xr[NL][6];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int chunk = threadIdx.x + 256 * i, row = chunk / 24, c8 = chunk - row * 24;
+        const int gm = m0 + row < R ? m0 + row : R - 1;
+        xr[l][i] = *reinterpret_cast<const u32x4_t*>(acts + (size_t)gm * a.ldacts + l * H + c8 * 8);
+      }
+    if (threadIdx.x < BM) rowsum[threadIdx.x] = 0.0f;
+    // skip GEMM: wn_out = (acts @ Wskip^T + b) * mask;  wave (wm, wn): rows 32 wm .., column blocks 3 wn ..
+    f32x16_t acc[3];
+    acc_zero<3>(acc);
+    constexpr int KK = NL * H / 16;                         // 48 k-steps
+    uint4 ring[RD][3];
+#pragma unroll
+    for (int p = 0; p < RD; ++p)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) ring[p][bn] = ldfrag(Wskip, (3 * wn + bn) * KK + p, lane);
+    skip_slice<0>(xr[0], As, Wskip, wm, wn, r, h, lane, ring, acc);
+    skip_slice<1>(xr[1], As, Wskip, wm, wn, r, h, lane, ring, acc);
+    skip_slice<2>(xr[2], As, Wskip, wm, wn, r, h, lane, ring, acc);
+    skip_slice<3>(xr[3], As, Wskip, wm, wn, r, h, lane, ring, acc);
+    // every wave is past slices 0..2 (the barrier before slice 3): At = slice 0's region
+    bf16_t* wn_out = static_cast<bf16_t*>(a.wn_out);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        const float4 b4 = *reinterpret_cast<const float4*>(a.b_skip + n);
+        const uint2 v = pack4((acc[bn][4 * g] + b4.x) * rm_l, (acc[bn][4 * g + 1] + b4.y) * rm_l,
+                              (acc[bn][4 * g + 2] + b4.z) * rm_l, (acc[bn][4 * g + 3] + b4.w) * rm_l);
+        if (mrow < R) *reinterpret_cast<uint2*>(wn_out + (size_t)mrow * H + n) = v;
+        *reinterpret_cast<uint2*>(As + (32 * wm + r) * AP + n) = v;
+      }
+    __syncthreads();
+    // end conv: [m | logs] = wn_out @ Wend^T + b   (N = 160: blocks 0..4, block 5 is the image's zero padding)
+    f32x16_t acc2[3];
+    acc_zero<3>(acc2);
+    gemm_lds<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, As + (32 * wm + r) * AP + 8 * h, lane, acc2);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        if (n < C) {
+          const float4 b4 = *reinterpret_cast<const float4*>(a.b_end + n);
+          *reinterpret_cast<float4*>(Ot + (32 * wm + r) * ZP + n) =
+              make_float4(acc2[bn][4 * g] + b4.x, acc2[bn][4 * g + 1] + b4.y, acc2[bn][4 * g + 2] + b4.z, acc2[bn][4 * g + 3] + b4.w);
+        }
+      }
+    __syncthreads();
+    // affine coupling on (row, 4 channels): z = [y0 | (m + exp(logs) y1) mask]
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row;
+      float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), z1 = z0;
+      if (gm < R) {
+        const float rm = a.rowmask[gm];
+        const float4 mm = *reinterpret_cast<const float4*>(Ot + row * ZP + c);
+        const float4 lr = *reinterpret_cast<const float4*>(Ot + row * ZP + HALF + c);
+        z0 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + c);
+        const float4 y1 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
+        float lg[4] = {lr.x, lr.y, lr.z, lr.w};
+        if (a.sigmoid_scale) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lg[j] = __logf(1e-6f + sigmoidf_(lg[j] + 2.0f));
+        }
+        z1 = make_float4((mm.x + __expf(lg[0]) * y1.x) * rm, (mm.y + __expf(lg[1]) * y1.y) * rm,
+                         (mm.z + __expf(lg[2]) * y1.z) * rm, (mm.w + __expf(lg[3]) * y1.w) * rm);
+        *reinterpret_cast<float4*>(a.z + (size_t)gm * C + c) = z0;
+        *reinterpret_cast<float4*>(a.z + (size_t)gm * C + HALF + c) = z1;
+        *reinterpret_cast<float4*>(a.logs_raw + (size_t)gm * HALF + c) = lr;       // the backward needs logs only
+        const float s = (lg[0] + lg[1] + lg[2] + lg[3]) * rm;
+        if (s != 0.0f) atomicAdd(rowsum + row, s);
+      }
+      if (HEAD) {
+        *reinterpret_cast<float4*>(Zt + row * ZP + c) = z0;
+        *reinterpret_cast<float4*>(Zt + row * ZP + HALF + c) = z1;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int gm = m0 + lane < R ? m0 + lane : R - 1;
+      utt_atomic_add(a.logdet, rowsum[lane], a.rowutt[gm], lane);
+    }
+  } else {
+    // first block: the squeezed mel rows are the flow state
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / 40, c = 4 * (item - row * 40), gm = m0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < R) v = *reinterpret_cast<const float4*>(a.x_in + (size_t)gm * C + c);
+      *reinterpret_cast<float4*>(Zt + row * ZP + c) = v;
+    }
+    __syncthreads();
+  }
+  if (!HEAD) return;
+
+  // ActNorm + InvConvNear of the next block on (row, channel group g): members {2g, 2g+1, 80+2g, 80+2g+1}
+  if (blockIdx.x == 0) {                                     // its log-det: (sum logs + (C/4) logdet W) * len_b
+    const float per_frame = a.scal[0] + (float)G * a.scal[1];
+    for (int b = threadIdx.x; b < a.B; b += 256) atomicAdd(a.logdet + b, per_frame * (float)a.len[b]);
+  }
+  bf16_t* X0t = reinterpret_cast<bf16_t*>(smem + F_AS);      // At is dead: every wave is past the end conv
+  {
+    float Wm[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Wm[i] = a.w_ic[i];
+    bf16_t* y0b = static_cast<bf16_t*>(a.y0_bf16);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / G, g = item - row * G, gm = m0 + row;
+      const float rm = gm < R ? a.rowmask[gm] : 0.0f;
+      const float2 xa = *reinterpret_cast<const float2*>(Zt + row * ZP + 2 * g);
+      const float2 xb = *reinterpret_cast<const float2*>(Zt + row * ZP + HALF + 2 * g);
+      const float a0 = a.an_bias[2 * g] + __expf(a.an_logs[2 * g]) * xa.x, a1 = a.an_bias[2 * g + 1] + __expf(a.an_logs[2 * g + 1]) * xa.y;
+      const float a2 = a.an_bias[HALF + 2 * g] + __expf(a.an_logs[HALF + 2 * g]) * xb.x;
+      const float a3 = a.an_bias[HALF + 2 * g + 1] + __expf(a.an_logs[HALF + 2 * g + 1]) * xb.y;
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (Wm[q * 4] * a0 + Wm[q * 4 + 1] * a1 + Wm[q * 4 + 2] * a2 + Wm[q * 4 + 3] * a3) * rm;
+      const uint32_t p01 = pack2bf(o[0], o[1]);
+      if (gm < R) {
+        *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + 2 * g) = make_float2(o[0], o[1]);
+        *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + HALF + 2 * g) = make_float2(o[2], o[3]);
+        *reinterpret_cast<uint32_t*>(y0b + (size_t)gm * HALF + 2 * g) = p01;
+      }
+      *reinterpret_cast<uint32_t*>(X0t + row * XP + 2 * g) = p01;
+    }
+  }
+  __syncthreads();
+  // start conv: h = (y0 @ Wstart^T + b) * mask   (K = 80: 5 k-steps)
+  {
+    f32x16_t acc3[3];
+    acc_zero<3>(acc3);
+    gemm_lds<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, X0t + (32 * wm + r) * XP + 8 * h, lane, acc3);
+    bf16_t* h0 = static_cast<bf16_t*>(a.h_next);
+    if (mrow < R) {
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+          const float4 b4 = *reinterpret_cast<const float4*>(a.b_start + n);
+          *reinterpret_cast<uint2*>(h0 + (size_t)mrow * H + n) =
+              pack4((acc3[bn][4 * g] + b4.x) * rm_l, (acc3[bn][4 * g + 1] + b4.y) * rm_l,
+                    (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+constexpr int B_DH = 0;                                    // d h tile [64][AP] bf16; later d wn_out tile
+constexpr int B_D = BM * AP * 2;                           // fp32 gradient tile [64][ZP]
+constexpr int B_DO = B_D + BM * ZP * 4;                    // d[m | logs] tile [64][AP] bf16
+constexpr int B_RED = B_DO + BM * AP * 2;                  // parameter-gradient fold: sL, sB [4][64][4], sW [4][16], sred[4]
+constexpr int BWD_LDS = B_RED + 2 * 4 * 64 * 4 * 4 + 4 * 16 * 4 + 16;
+
+template <bool HEADB, bool TAILB>
+__global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, R = a.R;
+  bf16_t* Dh = reinterpret_cast<bf16_t*>(smem + B_DH);
+  float* Dt = reinterpret_cast<float*>(smem + B_D);
+  bf16_t* Dout = reinterpret_cast<bf16_t*>(smem + B_DO);
+  const int mrow = m0 + 32 * wm + r;
+  const float rm_l = mrow < R ? a.rowmask[mrow] : 0.0f;
+
+  if (HEADB) {
+    // d y0 (start conv part) = d h @ Wstart: N = 80 (blocks 0..2 of the padded image; wave wn takes 2 wn, 2 wn + 1)
+    const bf16_t* dh = static_cast<const bf16_t*>(a.dh);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int chunk = threadIdx.x + 256 * i, row = chunk / 24, c8 = chunk - row * 24;
+      const int gm = m0 + row < R ? m0 + row : R - 1;
+      *reinterpret_cast<uint4*>(Dh + row * AP + c8 * 8) = *reinterpret_cast<const uint4*>(dh + (size_t)gm * H + c8 * 8);
+    }
+    __syncthreads();
+    f32x16_t acc[2];
+    acc_zero<2>(acc);
+    gemm_lds<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, Dh + (32 * wm + r) * AP + 8 * h, lane, acc);
+#pragma unroll
+    for (int bn = 0; bn < 2; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (2 * wn + bn) + 8 * g + 4 * h;
+        if (n < HALF)
+          *reinterpret_cast<float4*>(Dt + (32 * wm + r) * ZP + n) = make_float4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
+      }
+    __syncthreads();
+    // ActNorm + InvConvNear backward: wave = row phase (rows ph, ph + 4, ..), lane = channel group
+    float* sL = reinterpret_cast<float*>(smem + B_RED);
+    float* sB = sL + 4 * 64 * 4;
+    float* sW = sB + 4 * 64 * 4;
+    float* sred = sW + 4 * 16;
+    if (blockIdx.x == 0) {                                   // backward of the log-det bookkeeping (see flow_ops.hip)
+      float sv = 0.f;
+      for (int b = threadIdx.x; b < a.B; b += 256) sv += a.dlogdet[b] * (float)a.len[b];
+      sv = wave_sum(sv);
+      if (lane == 0) sred[wave] = sv;
+      __syncthreads();
+      sv = sred[0] + sred[1] + sred[2] + sred[3];
+      for (int c = threadIdx.x; c < C; c += 256) atomicAdd(a.d_an_logs + c, sv);
+      if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, (float)G * sv * a.scal[2 + threadIdx.x]);
+    }
+    const int g = lane, ph = wave;
+    float accW[16], accL[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[i] = 0.f;
+    if (g < G) {
+      const int ch[4] = {2 * g, 2 * g + 1, HALF + 2 * g, HALF + 2 * g + 1};
+      float el[4], bs[4], Wm[16];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { el[k] = __expf(a.an_logs[ch[k]]); bs[k] = a.an_bias[ch[k]]; }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Wm[i] = a.w_ic[i];
+      for (int row = ph; row < BM; row += 4) {
+        const int gm = m0 + row;
+        float dxv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gm < R) {
+          const float rm = a.rowmask[gm];
+          const float2 xa = *reinterpret_cast<const float2*>(a.x + (size_t)gm * C + 2 * g);
+          const float2 xb = *reinterpret_cast<const float2*>(a.x + (size_t)gm * C + HALF + 2 * g);
+          const float2 da = *reinterpret_cast<const float2*>(a.dx_in + (size_t)gm * C + 2 * g);       // identity path of d y0
+          const float2 db = *reinterpret_cast<const float2*>(a.dx_in + (size_t)gm * C + HALF + 2 * g);
+          const float2 ds = *reinterpret_cast<const float2*>(Dt + row * ZP + 2 * g);
+          const float xv[4] = {xa.x, xa.y, xb.x, xb.y};
+          const float dym[4] = {(da.x + ds.x) * rm, (da.y + ds.y) * rm, db.x * rm, db.y * rm};
+          float av[4], d_a[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) av[k] = bs[k] + el[k] * xv[k];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) d_a[i] = Wm[i] * dym[0] + Wm[4 + i] * dym[1] + Wm[8 + i] * dym[2] + Wm[12 + i] * dym[3];
+#pragma unroll
+          for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accW[o * 4 + i] += dym[o] * av[i];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { accB[k] += d_a[k]; accL[k] += d_a[k] * xv[k] * el[k]; dxv[k] = d_a[k] * el[k]; }
+          if (!TAILB) {
+            *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + 2 * g) = make_float2(dxv[0], dxv[1]);
+            *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
+          }
+        }
+        if (TAILB) {
+          *reinterpret_cast<float2*>(Dt + row * ZP + 2 * g) = make_float2(dxv[0], dxv[1]);
+          *reinterpret_cast<float2*>(Dt + row * ZP + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
+        }
+      }
+    }
+    // one atomic per channel per workgroup (same-address float atomics serialise at L2): fold the row phases in LDS
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sL[(ph * 64 + g) * 4 + k] = accL[k]; sB[(ph * 64 + g) * 4 + k] = accB[k]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accW[i] = wave_sum(accW[i]);
+    if (g == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sW[ph * 16 + i] = accW[i];
+    }
+    __syncthreads();
+    if (ph == 0 && g < G) {
+      const int ch[4] = {2 * g, 2 * g + 1, HALF + 2 * g, HALF + 2 * g + 1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(a.d_an_logs + ch[k], sL[g * 4 + k] + sL[(64 + g) * 4 + k] + sL[(128 + g) * 4 + k] + sL[(192 + g) * 4 + k]);
+        atomicAdd(a.d_an_bias + ch[k], sB[g * 4 + k] + sB[(64 + g) * 4 + k] + sB[(128 + g) * 4 + k] + sB[(192 + g) * 4 + k]);
+      }
+    }
+    if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, sW[threadIdx.x] + sW[16 + threadIdx.x] + sW[32 + threadIdx.x] + sW[48 + threadIdx.x]);
+    if (!TAILB) return;
+  } else {
+    // last block: the squeezed gradient of the decoder's output is d z
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / 40, c = 4 * (item - row * 40), gm = m0 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gm < R) v = *reinterpret_cast<const float4*>(a.dz_in + (size_t)gm * C + c);
+      *reinterpret_cast<float4*>(Dt + row * ZP + c) = v;
+    }
+    __syncthreads();
+  }
+
+  // coupling backward on (row, 4 channels): d x = [d z0 | d z1 exp(logs)], d m = d z1, d logs = d z1 exp(logs) y1 + d logdet
+  bf16_t* dout = static_cast<bf16_t*>(a.dout);
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row;
+    uint2 pm = make_uint2(0, 0), pl = make_uint2(0, 0);
+    if (gm < R) {
+      const float rm = a.rowmask[gm];
+      const float4 dz0 = *reinterpret_cast<const float4*>(Dt + row * ZP + c);
+      const float4 dz1r = *reinterpret_cast<const float4*>(Dt + row * ZP + HALF + c);
+      const float4 lr = *reinterpret_cast<const float4*>(a.logs_raw + (size_t)gm * HALF + c);
+      const float4 y1 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
+      const float dld = a.dlogdet[a.rowutt[gm]] * rm;
+      const float dz1[4] = {dz1r.x * rm, dz1r.y * rm, dz1r.z * rm, dz1r.w * rm};
+      const float lraw[4] = {lr.x, lr.y, lr.z, lr.w}, y1v[4] = {y1.x, y1.y, y1.z, y1.w};
+      float dx1[4], dlg[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float lg = lraw[j], dl_draw = 1.0f;
+        if (a.sigmoid_scale) { const float sg = sigmoidf_(lraw[j] + 2.0f); lg = __logf(1e-6f + sg); dl_draw = sg * (1.0f - sg) / (1e-6f + sg); }
+        const float e = __expf(lg);
+        dx1[j] = dz1[j] * e;
+        dlg[j] = (dz1[j] * e * y1v[j] + dld) * dl_draw;
+      }
+      *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + c) = dz0;
+      *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + HALF + c) = make_float4(dx1[0], dx1[1], dx1[2], dx1[3]);
+      pm = pack4(dz1[0], dz1[1], dz1[2], dz1[3]);
+      pl = pack4(dlg[0], dlg[1], dlg[2], dlg[3]);
+      *reinterpret_cast<uint2*>(dout + (size_t)gm * C + c) = pm;
+      *reinterpret_cast<uint2*>(dout + (size_t)gm * C + HALF + c) = pl;
+    }
+    *reinterpret_cast<uint2*>(Dout + row * AP + c) = pm;
+    *reinterpret_cast<uint2*>(Dout + row * AP + HALF + c) = pl;
+  }
+  __syncthreads();
+  // end conv data gradient: d wn_out = (d out @ Wend) * mask   (K = 160: 10 k-steps)
+  bf16_t* At = Dh;                                           // the d h tile is dead
+  {
+    f32x16_t acc[3];
+    acc_zero<3>(acc);
+    gemm_lds<3, C / 16>(static_cast<const bf16_t*>(a.w_end_d), a.ks_end_d, 3 * wn, Dout + (32 * wm + r) * AP + 8 * h, lane, acc);
+    bf16_t* dwn = static_cast<bf16_t*>(a.dwn_out);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        const uint2 v = pack4(acc[bn][4 * g] * rm_l, acc[bn][4 * g + 1] * rm_l, acc[bn][4 * g + 2] * rm_l, acc[bn][4 * g + 3] * rm_l);
+        if (mrow < R) *reinterpret_cast<uint2*>(dwn + (size_t)mrow * H + n) = v;
+        *reinterpret_cast<uint2*>(At + (32 * wm + r) * AP + n) = v;
+      }
+  }
+  __syncthreads();
+  // skip data gradient: d acts_l (skip path) = d wn_out @ Wskip_l, one layer window per pass
+  bf16_t* via = static_cast<bf16_t*>(a.via_skip);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    f32x16_t acc[3];
+    acc_zero<3>(acc);
+    gemm_lds<3, H / 16>(static_cast<const bf16_t*>(a.w_skip_d), a.ks_skip_d, 6 * l + 3 * wn, At + (32 * wm + r) * AP + 8 * h, lane, acc);
+    if (mrow < R) {
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = l * H + 32 * (3 * wn + bn) + 8 * g + 4 * h;
+          *reinterpret_cast<uint2*>(via + (size_t)mrow * a.ldvs + n) = pack4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
+        }
+    }
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename K>
+int opt_in_lds(K kernel, int bytes)
+{
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream)
+{
+  if (!args) return GT_E_INVAL;
+  const gt_boundary_fwd_args& a = *args;
+  if (a.R < 0) return GT_E_INVAL;
+  if (a.R == 0) return GT_OK;
+  if (a.H != H || a.C != C || a.n_layers != NL) return GT_E_UNSUPPORTED;
+  const bool tail = a.acts != nullptr, head = a.y_next != nullptr;
+  if (!tail && !head) return GT_E_INVAL;
+  if (!a.rowmask) return GT_E_INVAL;
+  if (tail) {
+    if (!a.w_skip || !a.b_skip || !a.w_end || !a.b_end || !a.y || !a.wn_out || !a.logs_raw || !a.z || !a.logdet || !a.rowutt) return GT_E_INVAL;
+    if (a.ldacts < NL * H || (a.ldacts & 7) || a.ks_end < H / 16) return GT_E_INVAL;
+    if (!al16(a.acts) || !al16(a.w_skip) || !al16(a.w_end) || !al16(a.b_skip) || !al16(a.b_end) || !al16(a.y) || !al16(a.wn_out) ||
+        !al16(a.logs_raw) || !al16(a.z)) return GT_E_ALIGN;
+  } else if (!a.x_in || !al16(a.x_in)) return GT_E_INVAL;
+  if (head) {
+    if (!a.an_logs || !a.an_bias || !a.w_ic || !a.scal || !a.len || a.B <= 0 || !a.logdet || !a.y0_bf16 || !a.w_start || !a.b_start || !a.h_next)
+      return GT_E_INVAL;
+    if (a.ks_start < HALF / 16) return GT_E_INVAL;
+    if (!al16(a.y_next) || !al16(a.y0_bf16) || !al16(a.w_start) || !al16(a.b_start) || !al16(a.h_next)) return GT_E_ALIGN;
+  }
+  static bool attr = false;                    // > 64 KB of LDS: opt in once per process
+  if (!attr) {
+    if (opt_in_lds(&gt_wn_boundary_fwd_kernel<true, true>, FWD_LDS) || opt_in_lds(&gt_wn_boundary_fwd_kernel<true, false>, FWD_LDS) ||
+        opt_in_lds(&gt_wn_boundary_fwd_kernel<false, true>, FWD_LDS)) return GT_E_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((a.R + BM - 1) / BM), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tail && head) hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, true>), grid, block, FWD_LDS, st, a);
+  else if (tail)    hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, false>), grid, block, FWD_LDS, st, a);
+  else              hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<false, true>), grid, block, FWD_LDS, st, a);
+  return gt_launch_status(__func__);
+}
+
+extern "C" int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream)
+{
+  if (!args) return GT_E_INVAL;
+  const gt_boundary_bwd_args& a = *args;
+  if (a.R < 0) return GT_E_INVAL;
+  if (a.R == 0) return GT_OK;
+  if (a.H != H || a.C != C || a.n_layers != NL) return GT_E_UNSUPPORTED;
+  const bool headb = a.dh != nullptr, tailb = a.dout != nullptr;
+  if (!headb && !tailb) return GT_E_INVAL;
+  if (!a.rowmask || !a.dx_out || !al16(a.dx_out)) return GT_E_INVAL;
+  if (headb) {
+    if (!a.w_start_d || !a.dx_in || !a.x || !a.an_logs || !a.an_bias || !a.w_ic || !a.scal || !a.len || !a.dlogdet || a.B <= 0 ||
+        !a.d_an_logs || !a.d_an_bias || !a.d_w_ic) return GT_E_INVAL;
+    if (a.ks_start_d < H / 16) return GT_E_INVAL;
+    if (!al16(a.dh) || !al16(a.w_start_d) || !al16(a.dx_in) || !al16(a.x)) return GT_E_ALIGN;
+  } else if (!a.dz_in || !al16(a.dz_in)) return GT_E_INVAL;
+  if (tailb) {
+    if (!a.logs_raw || !a.y || !a.dlogdet || !a.rowutt || !a.w_end_d || !a.dwn_out || !a.w_skip_d || !a.via_skip) return GT_E_INVAL;
+    if (a.ks_end_d < C / 16 || a.ks_skip_d < H / 16 || a.ldvs < NL * H || (a.ldvs & 3)) return GT_E_INVAL;
+    if (!al16(a.logs_raw) || !al16(a.y) || !al16(a.dout) || !al16(a.w_end_d) || !al16(a.dwn_out) || !al16(a.w_skip_d) || !al16(a.via_skip))
+      return GT_E_ALIGN;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (opt_in_lds(&gt_wn_boundary_bwd_kernel<true, true>, BWD_LDS) || opt_in_lds(&gt_wn_boundary_bwd_kernel<true, false>, BWD_LDS) ||
+        opt_in_lds(&gt_wn_boundary_bwd_kernel<false, true>, BWD_LDS)) return GT_E_LAUNCH;
+    attr = true;
+  }
+  const dim3 grid((a.R + BM - 1) / BM), block(256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (headb && tailb) hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<true, true>), grid, block, BWD_LDS, st, a);
+  else if (headb)     hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<true, false>), grid, block, BWD_LDS, st, a);
+  else                hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<false, true>), grid, block, BWD_LDS, st, a);
+  return gt_launch_status(__func__);
+}

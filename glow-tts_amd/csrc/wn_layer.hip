@@ -243,7 +243,11 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
               vs = drop_keep(a.drop_seed, m, H + c + j, a.drop_thresh) ? vs * a.drop_scale : 0.0f;
             }
             vt += ctv[j]; vs += csv[j];
+#ifdef WN_EXP_NOEPI
+            tt[j] = vt; ss[j] = vs; aa[j] = vt + vs;
+#else
             tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
+#endif
           }
           *reinterpret_cast<uint2*>(a.Tt + (size_t)m * a.ldts + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
           *reinterpret_cast<uint2*>(a.Ss + (size_t)m * a.ldts + c) = pack4(ss[0], ss[1], ss[2], ss[3]);

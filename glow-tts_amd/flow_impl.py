@@ -138,7 +138,7 @@ def _fused_ok(wn):
     return True
 
 
-def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
+def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
     it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
     Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
@@ -192,16 +192,21 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False):
             # rows [0,H) of the weight -> residual, rows [H,2H) -> skip (modules.py:166-168)
             x = conv_rows(acts, rs.pc_res, rc, bias=rs.bias[:H], addend=x, mask=True)
             xs.append(x)
+    saved = (xs, ts, ss, acts_all, p, seed)
+    if layers_only:                                   # the fused boundary kernel runs the skip GEMM (csrc/wn_boundary.hip)
+        return None, saved
     out = conv_rows(acts_all, wn.pc_skipcat, rc, bias=wn.skip_bias, mask=True)
-    return out, (xs, ts, ss, acts_all, p, seed)
+    return out, saved
 
 
-def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False):
+def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False, dacts_skip=None):
     """dskip: [R,H] bf16, the MASKED gradient of the wn output (= d skip of every layer, since out = skip*mask).
+    dacts_skip (fused layers only): dskip @ [W_skip_0 | ..] [R, n*H] when the caller already has it (boundary kernel).
     Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond); dcond is [B, 2*H*n] (per-utterance sums) or, with
     cond_per_row, the per-frame gradient [R, 2*H*n] fp32."""
     if _fused_ok(wn):
-        return _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row)
+        return _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip)
+    assert dacts_skip is None
     return _wn_bwd_unfused(rc, wn, saved, dskip, want_dcond, cond_per_row)
 
 
@@ -212,7 +217,7 @@ def _dcond_store(rc, dcond, i, H, src, cond_per_row):
         rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
 
 
-def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
+def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=None):
     """One kernel per layer boundary (gt_wn_layer_bwd): the k=5 data gradient of layer i+1's in_layer gives dX_{i+1} (the
     gradient at x_{i+1}); on that tile the residual 1x1's data gradient + the skip-path gradient + the gate backward of
     layer i follow, and d pre_i leaves for the next launch and for the weight gradients."""
@@ -225,7 +230,8 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row):
     dcond = None if not want_dcond else torch.empty(R if cond_per_row else rc.B, 2 * H * n, dtype=torch.float32, device=dev)
     need_c = want_dcond and p > 0                     # cond is added after the dropout: its gradient is d pre BEFORE the mask
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
-    dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
+    if dacts_skip is None:
+        dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
     # top layer: no residual output, d acts = skip path only
     i = n - 1
     dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)
@@ -397,6 +403,150 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
         return dx, grads, dcond, [dpros.get(id(getattr(cb, "wn_energy", None))) if econd else None,
                                   dpros.get(id(getattr(cb, "wn_pitch", None))) if pcond else None]
     return dx, grads, dcond
+
+
+# ----------------------------------------------------------------------------- fused between-WaveNets kernels
+class _BlockState:
+    """what one flow block keeps for the backward on the fused path"""
+    __slots__ = ("x_in", "y", "x0", "h0", "wn_saved", "wn_out", "logs_raw", "z", "scal", "w_ic")
+
+
+def _ptr_table(dec):
+    """device arrays of the blocks' ActNorm.logs / InvConvNear.weight pointers (gt_flow_scalars_multi); rebuilt when a
+    parameter's storage moves"""
+    ans = [dec.flows[3 * b] for b in range(dec.n_blocks)]
+    ics = [dec.flows[3 * b + 1] for b in range(dec.n_blocks)]
+    key = tuple(a.logs.data_ptr() for a in ans) + tuple(i.weight.data_ptr() for i in ics)
+    tab = getattr(dec, "_scal_table", None)
+    if tab is None or tab[0] != key:
+        assert not torch.cuda.is_current_stream_capturing(), "flow-scalar pointer table is built outside graph capture"
+        dev = ans[0].logs.device
+        tab = (key, torch.tensor([a.logs.data_ptr() for a in ans], dtype=torch.int64).to(dev),
+               torch.tensor([i.weight.data_ptr() for i in ics], dtype=torch.int64).to(dev))
+        object.__setattr__(dec, "_scal_table", tab)
+    return tab[1], tab[2]
+
+
+def flow_scalars_all(dec):
+    """scal [n_blocks, 18] = {sum logs, logdet W, W^-T} of every block in ONE launch, and the blocks' (contiguous) 4x4
+    weights.  A weight that is a strided view (a hand-filled test module; trained parameters are slices of the flat
+    buffer) is copied and takes the one-pair-per-launch route."""
+    nb = dec.n_blocks
+    Ws = [dec.flows[3 * b + 1].weight.detach() for b in range(nb)]
+    lgs = [dec.flows[3 * b].logs.detach() for b in range(nb)]
+    if all(w.is_contiguous() for w in Ws) and all(l.is_contiguous() for l in lgs):
+        lp, wp = _ptr_table(dec)
+        C = dec.flows[0].channels
+        scal = torch.empty(nb, 18, dtype=torch.float32, device=lp.device)
+        _lib.check(_lib.lib().gt_flow_scalars_multi(_lib.ptr(lp), _lib.ptr(wp), C, _lib.ptr(scal), nb, _st(lp.device)),
+                   "gt_flow_scalars_multi")
+        return scal, Ws
+    Ws = [w.contiguous() for w in Ws]
+    return torch.stack([flow_scalars(l, w) for l, w in zip(lgs, Ws)]), Ws
+
+
+def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed):
+    """The decoder's flow chain with ONE kernel between consecutive WaveNets (gt_wn_boundary_fwd: tail of block b-1 + head
+    of block b) and one kernel per WaveNet layer: n_blocks * (n_layers + 1) + 1 launches.  rows [R, C] fp32 (squeezed mel),
+    conds[b]: [B, 2*H*n] or None.  Returns (z rows, per-block saved state)."""
+    L = _lib.lib()
+    dev = rows.device
+    R, C = rows.shape
+    H, nb, n = dec.hidden_channels, dec.n_blocks, dec.n_layers
+    scal, Ws = flow_scalars_all(dec)
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    blocks = []
+    for b in range(nb + 1):
+        kw = dict(rowmask=rc.rowmask, R=R, H=H, C=C, n_layers=n, logdet=logdet)
+        if b > 0:                                          # tail of block b-1
+            sv, cbp = blocks[b - 1], dec.flows[3 * (b - 1) + 2]
+            acts_all = sv.wn_saved[3]
+            sv.wn_out = torch.empty(R, H, **bf)
+            sv.logs_raw = torch.empty(R, C // 2, **f32)
+            sv.z = torch.empty(R, C, **f32)
+            kw.update(acts=acts_all, ldacts=acts_all.stride(0), w_skip=cbp.wn.pc_skipcat_frag.fwd, b_skip=cbp.wn.skip_bias,
+                      w_end=cbp.end.pc_frag.fwd, b_end=cbp.end.bias, ks_end=cbp.end.pc_frag.Kp_f // 16, y=sv.y, wn_out=sv.wn_out,
+                      logs_raw=sv.logs_raw, z=sv.z, rowutt=rc.rowutt, sigmoid_scale=int(cbp.sigmoid_scale))
+        if b < nb:                                         # head of block b
+            an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
+            st = _BlockState()
+            st.x_in = rows if b == 0 else blocks[b - 1].z
+            st.y = torch.empty(R, C, **f32)
+            st.x0 = torch.empty(R, C // 2, **bf)
+            st.h0 = torch.empty(R, H, **bf)
+            st.scal, st.w_ic = scal[b], Ws[b]
+            if b == 0:
+                kw.update(x_in=rows)
+            kw.update(an_logs=an.logs, an_bias=an.bias, w_ic=st.w_ic, scal=st.scal, len=rc.lengths, B=rc.B, y_next=st.y, y0_bf16=st.x0,
+                      w_start=cb.start.pc_frag.fwd, b_start=cb.start.bias, ks_start=cb.start.pc_frag.Kp_f // 16, h_next=st.h0)
+            blocks.append(st)
+        args = _lib.fill_args(_lib.BoundaryFwdArgs, **kw)
+        import ctypes
+        _ev = KERNEL_TIMER.start("wn_boundary_fwd")
+        rcode = L.gt_wn_boundary_fwd(ctypes.byref(args), _st(dev))
+        KERNEL_TIMER.stop(_ev)
+        _lib.check(rcode, "gt_wn_boundary_fwd")
+        if b < nb:
+            st = blocks[b]
+            _, st.wn_saved = wn_fwd(rc, dec.flows[3 * b + 2].wn, st.h0, conds[b], train, seed + 16 * b, layers_only=True)
+    return blocks[-1].z, blocks
+
+
+def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
+    """Backward of decoder_fwd_fused: gt_wn_boundary_bwd between the WaveNets' layer kernels.  drows [R, C] fp32 = gradient
+    of the decoder's output rows; returns (d input rows [R, C], {param: grad}, [dcond per block])."""
+    import ctypes
+    L = _lib.lib()
+    dev = drows.device
+    R, C = drows.shape
+    H, nb, n = dec.hidden_channels, dec.n_blocks, dec.n_layers
+    f32 = dict(dtype=torch.float32, device=dev)
+    bf = dict(dtype=torch.bfloat16, device=dev)
+    grads, dconds = {}, [None] * nb
+    dx_prev = None                                         # [d z0 | d y1] of the block whose WaveNet backward runs next
+    dh0 = None
+    tail = None                                            # (dout, dwn_out, via_skip) of that block
+    for b in range(nb, -1, -1):
+        kw = dict(rowmask=rc.rowmask, R=R, H=H, C=C, n_layers=n)
+        dx_out = torch.empty(R, C, **f32)
+        if b < nb:                                         # head of block b: its WaveNet backward has just produced dh0
+            an, ic, cb, sv = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2], blocks[b]
+            dlogs = grad_accumulator(an.logs, (C,))
+            dbias = grad_accumulator(an.bias, (C,))
+            dW = grad_accumulator(ic.weight, (16,))
+            kw.update(dh=dh0, w_start_d=cb.start.pc_frag.dgrad, ks_start_d=cb.start.pc_frag.Kp_d // 16, dx_in=dx_prev, x=sv.x_in,
+                      an_logs=an.logs, an_bias=an.bias, w_ic=sv.w_ic, scal=sv.scal, len=rc.lengths, B=rc.B,
+                      d_an_logs=dlogs, d_an_bias=dbias, d_w_ic=dW, dlogdet=dlogdet)
+            grads.update({an.logs: dlogs.view_as(an.logs), an.bias: dbias.view_as(an.bias), ic.weight: dW.view_as(ic.weight)})
+        else:
+            kw.update(dz_in=drows)
+        new_tail = None
+        if b > 0:                                          # tail of block b-1
+            cbp, svp = dec.flows[3 * (b - 1) + 2], blocks[b - 1]
+            dout = torch.empty(R, C, **bf)
+            dwn = torch.empty(R, H, **bf)
+            via = torch.empty(R, n * H, **bf)
+            kw.update(logs_raw=svp.logs_raw, y=svp.y, dlogdet=dlogdet, rowutt=rc.rowutt, sigmoid_scale=int(cbp.sigmoid_scale),
+                      dout=dout, w_end_d=cbp.end.pc_frag.dgrad, ks_end_d=cbp.end.pc_frag.Kp_d // 16, dwn_out=dwn,
+                      w_skip_d=cbp.wn.pc_skipcat_frag.dgrad, ks_skip_d=cbp.wn.pc_skipcat_frag.Kp_d // 16, via_skip=via, ldvs=via.stride(0))
+            new_tail = (dout, dwn, via)
+        kw.update(dx_out=dx_out)
+        args = _lib.fill_args(_lib.BoundaryBwdArgs, **kw)
+        _ev = KERNEL_TIMER.start("wn_boundary_bwd")
+        rcode = L.gt_wn_boundary_bwd(ctypes.byref(args), _st(dev))
+        KERNEL_TIMER.stop(_ev)
+        _lib.check(rcode, "gt_wn_boundary_bwd")
+        if b == 0:
+            return dx_out, grads, dconds
+        # block b-1: end conv's parameter gradients, the WaveNet's backward, then the start conv's
+        cbp, svp = dec.flows[3 * (b - 1) + 2], blocks[b - 1]
+        dout, dwn, via = new_tail
+        grads.update(conv_param_grads(cbp.end, svp.wn_out, dout, R))
+        dh0, g2, dconds[b - 1] = wn_bwd(rc, cbp.wn, svp.wn_saved, dwn, has_cond, dacts_skip=via)
+        grads.update(g2)
+        grads.update(conv_param_grads(cbp.start, svp.x0, dh0, R))
+        dx_prev = dx_out
 
 
 # ----------------------------------------------------------------------------- reverse flow (inference)

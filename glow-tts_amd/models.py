@@ -33,6 +33,19 @@ class FlowSpecDecoder(nn.Module):
                                             sigmoid_scale=sigmoid_scale, n_sqz=n_sqz, with_prosody_wn=with_prosody_wn))
         self._step = 0
         self._inv_cache = None
+        self.fused_boundary = False
+        self.set_fused_boundary(True)
+
+    def set_fused_boundary(self, on):
+        """One kernel for everything between two WaveNets (skip GEMM, end conv, coupling, ActNorm, InvConvNear, start conv;
+        csrc/wn_boundary.hip) when every block has the shape the kernel is built for; off = round 1's launch sequence
+        (the reference path of the tests).  Takes effect with the next prepare_all()."""
+        oks = [self.flows[3 * b + 2].set_boundary_fused(on) for b in range(self.n_blocks)]
+        self.fused_boundary = bool(on) and all(oks)
+        if not self.fused_boundary:
+            for b in range(self.n_blocks):
+                self.flows[3 * b + 2].set_boundary_fused(False)
+        return self.fused_boundary
 
     def store_inverse(self):
         """models.py:787-789 -> modules.py:667-668 / attentions.py:188-194: freeze the decoder for synthesis.  The
@@ -130,7 +143,13 @@ class _DecoderRunner:
         esig, psig = self._contour_rows(rc, self.energy, B, T2 * 2), self._contour_rows(rc, self.pitch, B, T2 * 2)
         saved = []
         cur = rows
-        for b in range(nb):
+        # one kernel between consecutive WaveNets (csrc/wn_boundary.hip) unless a block still waits for its data-dependent
+        # init (that forward runs round 1's launch sequence once) or per-frame prosody conditioning is on
+        fused = dec.fused_boundary and esig is None and psig is None and all(dec.flows[3 * b].initialized for b in range(nb))
+        if fused:
+            cur, blocks = flow_impl.decoder_fwd_fused(rc, dec, rows, conds, logdet, self.train, self.seed)
+            saved = ("fused", blocks)
+        for b in range(0 if not fused else nb, nb):
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
             if not an.initialized:                                    # data-dependent init, once (modules.py:588-590)
                 assert not torch.cuda.is_current_stream_capturing(), "run the DDI batch before capturing the step"
@@ -191,9 +210,12 @@ class _DecoderRunner:
         deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None
         dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None
         cur = drows
+        fused = isinstance(saved, tuple) and len(saved) == 2 and saved[0] == "fused"
         # data-gradient chain now; ALL weight gradients of the decoder go out as one batch when the block ends
         with wgrad.WgradQueue(dev, site=dec):
-            for b in reversed(range(nb)):
+            if fused:
+                cur, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], drows, dlogdet, self.has_cond)
+            for b in (() if fused else reversed(range(nb))):
                 an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
                 s1, s2 = saved[b]
                 if esig is None and psig is None:

@@ -34,6 +34,10 @@ class ConvP(nn.Module):
         self.bias = nn.Parameter(b)
         self._pc = None
         self.cat_slice = None                      # set by an owner that runs this conv as a window of a concatenated GEMM
+        # a SECOND pair of images in MFMA-fragment order, for the fused between-WaveNets kernels (csrc/wn_boundary.hip);
+        # the row-major pair stays (synthesis, the stand-alone module API and the reference path of the tests use it)
+        self.also_frag = False
+        self.pc_frag = None
 
     @property
     def pc(self):
@@ -45,14 +49,21 @@ class ConvP(nn.Module):
         return PackedConv(Cout or self.out_channels, self.in_channels, self.kernel_size, self.gate, device=self.weight.device,
                           norm_only=self.cat_slice is not None, split3=self.split3)
 
+    def _ensure_frag(self, dev):
+        if self.also_frag and (self.pc_frag is None or self.pc_frag.inv_norm.device != dev):
+            self.pc_frag = PackedConv(self.out_channels, self.in_channels, self.kernel_size, False, device=dev, frag=True)
+        if not self.also_frag:
+            self.pc_frag = None
+
     def _ensure_pcs(self):
         if self._pc is None or self._pc.inv_norm.device != self.weight.device:
             self._pc = self._new_pc()
+        self._ensure_frag(self.weight.device)
 
     def _pack_entries(self):
         if self.cat_slice is not None:             # the images live in the owner's concatenated GEMM
             return [(self.weight, None, self.cat_slice())]
-        return [(self.weight, None, self._pc)]
+        return [(self.weight, None, self._pc)] + ([(self.weight, None, self.pc_frag)] if self.pc_frag is not None else [])
 
     def prepare(self):
         """(Re)pack the current weights for the MFMA kernels — once per optimizer step."""
@@ -74,6 +85,7 @@ class WNConvP(ConvP):
         self.weight_v = nn.Parameter(v.clone())
         self.split_res_skip = split_res_skip       # res_skip layer of a WN: rows [0,h) residual, [h,2h) skip
         self.skip_slice = None                     # set by the owning WN: where the skip rows are packed
+        self.skip_slice_frag = None                # ... and where in the fragment-ordered twin of that image (boundary kernels)
         self.pc_res = None
         self.frag = False                          # set by the owning WN (fused layer kernels): fragment-ordered images
 
@@ -85,6 +97,7 @@ class WNConvP(ConvP):
                                   frag=self.frag and not in_wn, gate16=self.frag and self.gate)
             if self.split_res_skip:
                 self.pc_res = PackedConv(self.out_channels // 2, self.in_channels, self.kernel_size, False, device=dev, frag=self.frag)
+        self._ensure_frag(dev)
 
     def _pack_entries(self):
         out = [(self.weight_v, self.weight_g, self._pc)]                 # inv_norm (+ images unless norm_only)
@@ -93,6 +106,10 @@ class WNConvP(ConvP):
             out.append((self.weight_v[:h], self.weight_g[:h], self.pc_res))
         if self.skip_slice is not None:
             out.append((self.weight_v[h:], self.weight_g[h:], self.skip_slice()))
+            if self.skip_slice_frag is not None:
+                out.append((self.weight_v[h:], self.weight_g[h:], self.skip_slice_frag()))
+        elif self.pc_frag is not None:
+            out.append((self.weight_v, self.weight_g, self.pc_frag))
         return out
 
     def prepare(self):
@@ -308,6 +325,7 @@ class WN(nn.Module):
         # output = sum_i skip_i(acts_i) (modules.py:168-170) is ONE GEMM over the K-concatenated gated activations:
         # every layer's skip rows are packed into a window of pc_skipcat ([H, n_layers*H])
         self._pc_skipcat = None
+        self._pc_skipcat_frag = None               # its fragment-ordered twin (set_boundary_frag: csrc/wn_boundary.hip reads it)
         self.skip_bias = None
         # one kernel per layer (csrc/wn_layer.hip) for the shape every reference config has; set_fused(False) gives round 1's
         # two-kernels-per-layer launch sequence (kept as the reference the fused kernels are tested against)
@@ -327,6 +345,21 @@ class WN(nn.Module):
             il.frag, il._pc = on, None
         for rs in self.res_skip_layers:
             rs.frag, rs._pc, rs.pc_res = on, None, None
+
+    def set_boundary_frag(self, on):
+        """Also keep the skip-cat GEMM's images in MFMA-fragment order (the fused between-WaveNets kernels)."""
+        H = self.hidden_channels
+        for i, rs in enumerate(self.res_skip_layers):
+            rs.skip_slice_frag = (lambda i=i: PackSlice(self.pc_skipcat_frag, i * H, H, H)) if on else None
+        if not on:
+            self._pc_skipcat_frag = None
+
+    @property
+    def pc_skipcat_frag(self):
+        dev = self.in_layers[0].weight_v.device
+        if self._pc_skipcat_frag is None or self._pc_skipcat_frag.fwd.device != dev:
+            self._pc_skipcat_frag = PackedConv(self.hidden_channels, self.n_layers * self.hidden_channels, 1, False, device=dev, frag=True)
+        return self._pc_skipcat_frag
 
     @property
     def pc_skipcat(self):

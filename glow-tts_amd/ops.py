@@ -348,10 +348,15 @@ class PackSlice:
         self.Np_f, self.Kp_f, self.Np_d, self.Kp_d = parent.Np_f, parent.Kp_f, parent.Np_d, parent.Kp_d
         # forward image Pf[co][k0 + ci] / data-gradient image Pd[k0 + ci][co]
         assert k0 % 32 == 0
-        self.fwd = parent.fwd[k0:]
-        self.dgrad = parent.dgrad[k0 * parent.Kp_d:]
+        if getattr(parent, "frag", False):          # fragment order: [n / 32][k / 16] 1-KB (512-element) fragments
+            self.fwd = parent.fwd[(k0 >> 4) * 512:]
+            self.dgrad = parent.dgrad[(k0 >> 5) * (parent.Kp_d >> 4) * 512:]
+            self.flags = 6
+        else:
+            self.fwd = parent.fwd[k0:]
+            self.dgrad = parent.dgrad[k0 * parent.Kp_d:]
+            self.flags = 0
         self.inv_norm = None
-        self.flags = 0
 
 
 class PackSliceN:

@@ -226,6 +226,9 @@ int gt_actnorm_ddi(const float* x, const int32_t* len, int B, int R, int C, doub
  * gt_flow_scalars precomputes scal[18] = {sum logs, logdet W, W^-T}.  y0_bf16 (optional) receives
  * a bf16 copy of the first C/2 channels (the coupling's start-conv input). */
 int gt_flow_scalars(const float* logs, int C, const float* W, float* scal, void* stream);
+/* the same for n (ActNorm, InvConvNear) pairs in one launch: logs_ptrs / w_ptrs are DEVICE arrays of n device pointers,
+ * scal is [n][18] */
+int gt_flow_scalars_multi(const void* logs_ptrs, const void* w_ptrs, int C, float* scal, int n, void* stream);
 int gt_actnorm_invconv_fwd(const float* x, float* y, void* y0_bf16, int ld0, const float* logs, const float* bias,
                            const float* W, const float* scal, const float* rowmask, const int32_t* len,
                            float* logdet, int B, int R, int C, void* stream);
@@ -344,6 +347,65 @@ int gt_coupling_rev(const float* out, const float* z, float* x, const float* row
  * it) += sum g^2. */
 int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                   float* gnorm_sq, void* stream);
+
+/* ---- Everything between two WaveNets of the flow decoder as ONE kernel (csrc/wn_boundary.hip): all of it is row-local.
+ * Shapes: C = 160 flow channels (n_sqz * 80 mels), H = 192, n_layers = 4 (every reference config); 64 rows per workgroup.
+ * Weight images: gt_pack_conv_weights(_multi) in MFMA-fragment order (flags 2 | 4), ks_* = padded K / 16 of each image.
+ *
+ * gt_wn_boundary_fwd — [tail of block b] when acts != NULL:
+ *     wn_out = (acts @ Wskipcat^T + b_skip) * mask       modules.py:168-171 (K-concatenated skip GEMM, bf16 out, kept for wgrad)
+ *     [m | logs] = wn_out @ Wend^T + b_end               attentions.py:162-165
+ *     z = [y0 | (m + exp(logs) * y1) * mask], logdet[utt] += sum logs * mask      attentions.py:171-184; logs_raw [R, C/2] kept
+ *   [head of block b+1] when y_next != NULL (input: the z tile, or x_in [R, C] when there is no tail):
+ *     y_next = InvConvNear(ActNorm(z)) * mask, logdet[b] += (sum an_logs + C/4 * logdet W) * len[b]    modules.py:584-599, 635-665
+ *     y0_bf16 = bf16(y_next[:, :C/2]);  h_next = (y0 @ Wstart^T + b_start) * mask                      attentions.py:147
+ * gt_wn_boundary_bwd — [head of block b+1] when dh != NULL:
+ *     d y = [dx_in[:, :C/2] + dh @ Wstart | dx_in[:, C/2:]];  ActNorm / InvConvNear backward against x (their input):
+ *     d_an_logs, d_an_bias, d_w_ic accumulated with atomics (+ the log-det terms), d x -> the tile (or dx_out without a tail)
+ *   [tail of block b] when dout != NULL (input: that tile, or dz_in [R, C] when there is no head):
+ *     dx_out = [d z0 | d z1 * exp(logs) * mask];  dout = bf16 [d m | d logs] (kept for wgrad)
+ *     dwn_out = (dout @ Wend) * mask (bf16, kept for wgrad);  via_skip [R, n_layers * H] = dwn_out @ Wskipcat
+ * A NULL pointer selects the variant; everything is fp32 rows [R, C] unless said otherwise; rowutt int32 [R]. */
+typedef struct gt_boundary_fwd_args {
+  /* tail */
+  const void* acts; int ldacts;                 /* bf16 [R, >= n_layers*H] gated activations of the block's WN */
+  const void* w_skip; const float* b_skip;      /* forward image of the skip-cat GEMM [H, n_layers*H]; bias = sum of skip biases */
+  const void* w_end; const float* b_end; int ks_end;
+  const float* y;                               /* [R, C]: this block's ActNorm+InvConv output (y0 | y1) */
+  void* wn_out;                                 /* out: bf16 [R, H] */
+  float* logs_raw;                              /* out: [R, C/2] fp32 (before sigmoid_scale) */
+  float* z;                                     /* out: [R, C] */
+  float* logdet; const int32_t* rowutt; int sigmoid_scale;
+  /* head */
+  const float* x_in;                            /* head-only variant: the flow state [R, C] */
+  const float* an_logs; const float* an_bias; const float* w_ic; const float* scal; const int32_t* len; int B;
+  float* y_next; void* y0_bf16;                 /* out: [R, C] fp32, bf16 [R, C/2] */
+  const void* w_start; const float* b_start; int ks_start;
+  void* h_next;                                 /* out: bf16 [R, H] */
+  const float* rowmask; int R, H, C, n_layers;
+} gt_boundary_fwd_args;
+typedef struct gt_boundary_bwd_args {
+  /* head */
+  const void* dh;                               /* bf16 [R, H]: masked gradient at the WN's input */
+  const void* w_start_d; int ks_start_d;
+  const float* dx_in;                           /* [R, C]: [d z0 | d y1] of this block (dx_out of the previous launch) */
+  const float* x;                               /* [R, C]: input of this block's ActNorm */
+  const float* an_logs; const float* an_bias; const float* w_ic; const float* scal; const int32_t* len; int B;
+  float* d_an_logs; float* d_an_bias; float* d_w_ic;   /* accumulators [C], [C], [16] */
+  /* tail */
+  const float* dz_in;                           /* tail-only variant: gradient of the decoder's output rows [R, C] */
+  const float* logs_raw; const float* y;        /* saved by the forward: [R, C/2], [R, C] */
+  const float* dlogdet; const int32_t* rowutt; int sigmoid_scale;
+  float* dx_out;                                /* out: [R, C] */
+  void* dout;                                   /* out: bf16 [R, C] */
+  const void* w_end_d; int ks_end_d;
+  void* dwn_out;                                /* out: bf16 [R, H] */
+  const void* w_skip_d; int ks_skip_d;
+  void* via_skip; int ldvs;                     /* out: bf16 [R, >= n_layers*H] */
+  const float* rowmask; int R, H, C, n_layers;
+} gt_boundary_bwd_args;
+int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream);
+int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream);
 
 /* ---- One WaveNet layer as ONE kernel (modules.WN.forward, one loop iteration, modules.py:151-170; csrc/wn_layer.hip).
  * H = 192 hidden channels, k = 5, dilation 1; a workgroup owns 64 rows and all channels, so the 1x1 residual conv runs on the

@@ -469,3 +469,51 @@ def test_fused_wn_layer_kernels_match_the_two_kernel_path(built, mode):
     assert g1.keys() == g2.keys()
     for k in g1:
         assert relerr(g1[k], g2[k]) < 2e-2, relerr(g1[k], g2[k])
+
+
+@pytest.mark.parametrize("speaker,sigmoid_scale", [(False, False), (True, False), (False, True)])
+def test_fused_boundary_kernels_match_the_five_kernel_path(built, speaker, sigmoid_scale):
+    """csrc/wn_boundary.hip (skip GEMM + end conv + coupling + ActNorm + InvConvNear + start conv as ONE kernel between two
+    WaveNets, and the mirror kernel in the backward) against round 1's launch sequence on the same module, inputs and
+    dropout seeds (train mode): z, log-det, input gradient, speaker-vector gradient and every parameter gradient; three
+    blocks (head-only, head+tail, tail-only variants all run), ragged lengths incl. a 2-frame utterance, row count not a
+    multiple of 64."""
+    from glow_tts_amd import models
+    gin = 256 if speaker else 0
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 3, 4, p_dropout=0.05, sigmoid_scale=sigmoid_scale, gin_channels=gin),
+                      "decoder.").to(dev()).train()
+    assert dec.fused_boundary
+    lens = [140, 66, 2, 128, 90]
+    B, T = len(lens), 140
+    m = lens_mask(lens, T).to(dev())
+    gen = torch.Generator().manual_seed(21)
+    y0 = (torch.randn(B, 80, T, generator=gen)).to(dev()) * m
+    g0 = torch.randn(B, gin, 1, generator=gen).to(dev()) if speaker else None
+    rz = (torch.randn(B, 80, T, generator=gen)).to(dev()) * m
+    rl = (torch.randn(B, generator=gen) * 0.1).to(dev())
+    res = []
+    for fused in (True, False):
+        assert dec.set_fused_boundary(fused) == fused
+        dec._step = 5                                             # same dropout seeds in both runs
+        for p in dec.parameters():
+            p.grad = None
+        y = y0.clone().requires_grad_(True)
+        g = g0.clone().requires_grad_(True) if speaker else None
+        z, ld = dec(y, m, g=g)
+        ((z * rz).sum() + (ld * rl).sum()).backward()
+        torch.cuda.synchronize()
+        res.append((z.detach().clone(), ld.detach().clone(), y.grad.clone(), None if g is None else g.grad.clone(),
+                    {n: p.grad.clone() for n, p in dec.named_parameters()}))
+    (z1, l1, d1, c1, g1), (z2, l2, d2, c2, g2) = res
+    assert relerr(z1, z2) < 1e-2, relerr(z1, z2)
+    assert (l1 - l2).abs().max().item() < 1e-3 * max(1.0, l2.abs().max().item()), (l1, l2)
+    assert relerr(d1, d2) < 2e-2, relerr(d1, d2)
+    if speaker:
+        assert relerr(c1, c2) < 2e-2, relerr(c1, c2)
+    worst = ("", 0.0)
+    for n in g1:
+        e = relerr(g1[n], g2[n])
+        if e > worst[1]:
+            worst = (n, e)
+        assert e < 2e-2, (n, e)
+    print("fused boundary vs five kernels: worst parameter gradient", worst)

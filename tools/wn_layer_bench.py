@@ -59,7 +59,8 @@ def timeit(name, fn, launches=48, replays=10):
     print(f"{name:44s} {e0.elapsed_time(e1) / (replays * launches) * 1e3:7.1f} us / launch   (R = {R})", flush=True)
 
 
-for frac in (1, 2, 4, 8):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
+QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
+for frac in ((1,) if QUICK else (1, 2, 4, 8)):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
     Rs = R // frac // 64 * 64
     def f(k, Rs=Rs):
         il = wns[(k // 3) % 12].in_layers[k % 3]
@@ -71,6 +72,9 @@ for frac in (1, 2, 4, 8):          # fewer workgroups, same weights per workgrou
                                      None, None, 0, None, None, 0, None, None, 0, Rs, H, 5, 0.0, 7, None, None, 0, None, st()), "bwd")
     timeit(f"fwd stage 1 only, streaming, {Rs // 64} workgroups", f)
     timeit(f"bwd stage 1 only, streaming, {Rs // 64} workgroups", b)
+if QUICK:
+    timeit("fwd fused, streaming weights (36 layers)", lambda k: fwd(wns[(k // 3) % 12], k % 3))
+    sys.exit(0)
 timeit("fwd fused, L2-hot weights", lambda k: fwd(wns[0], 0))
 timeit("fwd fused, streaming weights (36 layers)", lambda k: fwd(wns[(k // 3) % 12], k % 3))
 timeit("fwd stage 1 only, hot", lambda k: fwd(wns[0], 0, False))
