@@ -53,23 +53,33 @@ __device__ __forceinline__ void acc_zero(f32x16_t (&acc)[NB])
 }
 
 // acc[bn] += W[block nb0 + bn][k-steps 0 .. KK) x Bt: W in fragment order with KS k-steps per block row; Brow points at
-// (this lane's row, 8h) of the bf16 LDS tile, k-step kk is 16 halfs further.
+// (this lane's row, 8h) of the bf16 LDS tile, k-step kk is 16 halfs further.  The first ring of fragments is fetched by
+// gemm_prefetch, which callers issue BEFORE the phase that produces the tile (weights do not depend on it), so the L2
+// latency of a stage hides under the previous stage's epilogue.
 template <int NB, int KK>
-__device__ __forceinline__ void gemm_lds(const bf16_t* __restrict__ W, int KS, int nb0, const bf16_t* Brow, int lane, f32x16_t (&acc)[NB])
+struct WRing { uint4 v[(KK < RD ? KK : RD)][NB]; };
+
+template <int NB, int KK>
+__device__ __forceinline__ void gemm_prefetch(const bf16_t* __restrict__ W, int KS, int nb0, int lane, WRing<NB, KK>& ring)
 {
   constexpr int D = KK < RD ? KK : RD;
-  uint4 ring[D][NB];
 #pragma unroll
   for (int p = 0; p < D; ++p)
 #pragma unroll
-    for (int bn = 0; bn < NB; ++bn) ring[p][bn] = ldfrag(W, (nb0 + bn) * KS + p, lane);
+    for (int bn = 0; bn < NB; ++bn) ring.v[p][bn] = ldfrag(W, (nb0 + bn) * KS + p, lane);
+}
+template <int NB, int KK>
+__device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ W, int KS, int nb0, const bf16_t* Brow, int lane, WRing<NB, KK>& ring,
+                                         f32x16_t (&acc)[NB])
+{
+  constexpr int D = KK < RD ? KK : RD;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
     const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(Brow + kk * 16);
 #pragma unroll
     for (int bn = 0; bn < NB; ++bn) {
-      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[kk % D][bn]), bfm, acc[bn], 0, 0, 0);
-      if (kk + D < KK) ring[kk % D][bn] = ldfrag(W, (nb0 + bn) * KS + kk + D, lane);
+      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring.v[kk % D][bn]), bfm, acc[bn], 0, 0, 0);
+      if (kk + D < KK) ring.v[kk % D][bn] = ldfrag(W, (nb0 + bn) * KS + kk + D, lane);
     }
   }
 }
@@ -162,6 +172,9 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     skip_slice<1>(xr[1], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<2>(xr[2], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<3>(xr[3], As, Wskip, wm, wn, r, h, lane, ring, acc);
+    // the end conv's first weight fragments fly under this epilogue
+    WRing<3, H / 16> ring2;
+    gemm_prefetch<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, lane, ring2);
     // every wave is past slices 0..2 (the barrier before slice 3): At = slice 0's region
     bf16_t* wn_out = static_cast<bf16_t*>(a.wn_out);
 #pragma unroll
@@ -177,9 +190,19 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       }
     __syncthreads();
     // end conv: [m | logs] = wn_out @ Wend^T + b   (N = 160: blocks 0..4, block 5 is the image's zero padding)
+    // the coupling's inputs (this block's y, written by the previous launch) fly under the end conv
+    float4 cy0[5], cy1[5];
+    float crm[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row < R ? m0 + row : R - 1;
+      cy0[k] = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + c);
+      cy1[k] = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
+      crm[k] = a.rowmask[gm];
+    }
     f32x16_t acc2[3];
     acc_zero<3>(acc2);
-    gemm_lds<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, As + (32 * wm + r) * AP + 8 * h, lane, acc2);
+    gemm_run<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, As + (32 * wm + r) * AP + 8 * h, lane, ring2, acc2);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -198,11 +221,11 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row;
       float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), z1 = z0;
       if (gm < R) {
-        const float rm = a.rowmask[gm];
+        const float rm = crm[k];
         const float4 mm = *reinterpret_cast<const float4*>(Ot + row * ZP + c);
         const float4 lr = *reinterpret_cast<const float4*>(Ot + row * ZP + HALF + c);
-        z0 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + c);
-        const float4 y1 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
+        z0 = cy0[k];
+        const float4 y1 = cy1[k];
         float lg[4] = {lr.x, lr.y, lr.z, lr.w};
         if (a.sigmoid_scale) {
 #pragma unroll
@@ -245,6 +268,8 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     for (int b = threadIdx.x; b < a.B; b += 256) atomicAdd(a.logdet + b, per_frame * (float)a.len[b]);
   }
   bf16_t* X0t = reinterpret_cast<bf16_t*>(smem + F_AS);      // At is dead: every wave is past the end conv
+  WRing<3, HALF / 16> ring3;                                 // the start conv's weights fly under the ActNorm / InvConvNear phase
+  gemm_prefetch<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, lane, ring3);
   {
     float Wm[16];
 #pragma unroll
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
   {
     f32x16_t acc3[3];
     acc_zero<3>(acc3);
-    gemm_lds<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, X0t + (32 * wm + r) * XP + 8 * h, lane, acc3);
+    gemm_run<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, X0t + (32 * wm + r) * XP + 8 * h, lane, ring3, acc3);
     bf16_t* h0 = static_cast<bf16_t*>(a.h_next);
     if (mrow < R) {
 #pragma unroll
@@ -322,10 +347,12 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       const int gm = m0 + row < R ? m0 + row : R - 1;
       *reinterpret_cast<uint4*>(Dh + row * AP + c8 * 8) = *reinterpret_cast<const uint4*>(dh + (size_t)gm * H + c8 * 8);
     }
+    WRing<2, H / 16> ring1;
+    gemm_prefetch<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, lane, ring1);
     __syncthreads();
     f32x16_t acc[2];
     acc_zero<2>(acc);
-    gemm_lds<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, Dh + (32 * wm + r) * AP + 8 * h, lane, acc);
+    gemm_run<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, Dh + (32 * wm + r) * AP + 8 * h, lane, ring1, acc);
 #pragma unroll
     for (int bn = 0; bn < 2; ++bn)
 #pragma unroll
@@ -361,19 +388,29 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       for (int k = 0; k < 4; ++k) { el[k] = __expf(a.an_logs[ch[k]]); bs[k] = a.an_bias[ch[k]]; }
 #pragma unroll
       for (int i = 0; i < 16; ++i) Wm[i] = a.w_ic[i];
-      for (int row = ph; row < BM; row += 4) {
-        const int gm = m0 + row;
-        float dxv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gm < R) {
-          const float rm = a.rowmask[gm];
-          const float2 xa = *reinterpret_cast<const float2*>(a.x + (size_t)gm * C + 2 * g);
-          const float2 xb = *reinterpret_cast<const float2*>(a.x + (size_t)gm * C + HALF + 2 * g);
-          const float2 da = *reinterpret_cast<const float2*>(a.dx_in + (size_t)gm * C + 2 * g);       // identity path of d y0
-          const float2 db = *reinterpret_cast<const float2*>(a.dx_in + (size_t)gm * C + HALF + 2 * g);
+      const float* __restrict__ xp = a.x;
+      const float* __restrict__ dip = a.dx_in;
+#pragma unroll
+      for (int rb = 0; rb < BM / 4; rb += 8) {               // this wave's 16 rows in two batches: the batch's loads fly together
+        float2 xa[8], xb[8], da[8], db[8];
+        float rmv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = ph + 4 * (rb + u), gm = m0 + row < R ? m0 + row : R - 1;
+          xa[u] = *reinterpret_cast<const float2*>(xp + (size_t)gm * C + 2 * g);
+          xb[u] = *reinterpret_cast<const float2*>(xp + (size_t)gm * C + HALF + 2 * g);
+          da[u] = *reinterpret_cast<const float2*>(dip + (size_t)gm * C + 2 * g);          // identity path of d y0
+          db[u] = *reinterpret_cast<const float2*>(dip + (size_t)gm * C + HALF + 2 * g);
+          rmv[u] = m0 + row < R ? a.rowmask[gm] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = ph + 4 * (rb + u), gm = m0 + row;
+          const float rm = rmv[u];
           const float2 ds = *reinterpret_cast<const float2*>(Dt + row * ZP + 2 * g);
-          const float xv[4] = {xa.x, xa.y, xb.x, xb.y};
-          const float dym[4] = {(da.x + ds.x) * rm, (da.y + ds.y) * rm, db.x * rm, db.y * rm};
-          float av[4], d_a[4];
+          const float xv[4] = {xa[u].x, xa[u].y, xb[u].x, xb[u].y};
+          const float dym[4] = {(da[u].x + ds.x) * rm, (da[u].y + ds.y) * rm, db[u].x * rm, db[u].y * rm};
+          float av[4], d_a[4], dxv[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) av[k] = bs[k] + el[k] * xv[k];
 #pragma unroll
@@ -384,14 +421,13 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
             for (int i = 0; i < 4; ++i) accW[o * 4 + i] += dym[o] * av[i];
 #pragma unroll
           for (int k = 0; k < 4; ++k) { accB[k] += d_a[k]; accL[k] += d_a[k] * xv[k] * el[k]; dxv[k] = d_a[k] * el[k]; }
-          if (!TAILB) {
+          if (TAILB) {
+            *reinterpret_cast<float2*>(Dt + row * ZP + 2 * g) = make_float2(dxv[0], dxv[1]);
+            *reinterpret_cast<float2*>(Dt + row * ZP + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
+          } else if (gm < R) {
             *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + 2 * g) = make_float2(dxv[0], dxv[1]);
             *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
           }
-        }
-        if (TAILB) {
-          *reinterpret_cast<float2*>(Dt + row * ZP + 2 * g) = make_float2(dxv[0], dxv[1]);
-          *reinterpret_cast<float2*>(Dt + row * ZP + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
         }
       }
     }
@@ -429,45 +465,64 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
 
   // coupling backward on (row, 4 channels): d x = [d z0 | d z1 exp(logs)], d m = d z1, d logs = d z1 exp(logs) y1 + d logdet
   bf16_t* dout = static_cast<bf16_t*>(a.dout);
+  WRing<3, C / 16> ring2;                                    // the end conv's data-gradient weights fly under this phase
+  gemm_prefetch<3, C / 16>(static_cast<const bf16_t*>(a.w_end_d), a.ks_end_d, 3 * wn, lane, ring2);
+  {
+    float4 lr4[5], y14[5];
+    float rmv[5], dldv[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row;
-    uint2 pm = make_uint2(0, 0), pl = make_uint2(0, 0);
-    if (gm < R) {
-      const float rm = a.rowmask[gm];
-      const float4 dz0 = *reinterpret_cast<const float4*>(Dt + row * ZP + c);
-      const float4 dz1r = *reinterpret_cast<const float4*>(Dt + row * ZP + HALF + c);
-      const float4 lr = *reinterpret_cast<const float4*>(a.logs_raw + (size_t)gm * HALF + c);
-      const float4 y1 = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
-      const float dld = a.dlogdet[a.rowutt[gm]] * rm;
-      const float dz1[4] = {dz1r.x * rm, dz1r.y * rm, dz1r.z * rm, dz1r.w * rm};
-      const float lraw[4] = {lr.x, lr.y, lr.z, lr.w}, y1v[4] = {y1.x, y1.y, y1.z, y1.w};
-      float dx1[4], dlg[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lg = lraw[j], dl_draw = 1.0f;
-        if (a.sigmoid_scale) { const float sg = sigmoidf_(lraw[j] + 2.0f); lg = __logf(1e-6f + sg); dl_draw = sg * (1.0f - sg) / (1e-6f + sg); }
-        const float e = __expf(lg);
-        dx1[j] = dz1[j] * e;
-        dlg[j] = (dz1[j] * e * y1v[j] + dld) * dl_draw;
-      }
-      *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + c) = dz0;
-      *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + HALF + c) = make_float4(dx1[0], dx1[1], dx1[2], dx1[3]);
-      pm = pack4(dz1[0], dz1[1], dz1[2], dz1[3]);
-      pl = pack4(dlg[0], dlg[1], dlg[2], dlg[3]);
-      *reinterpret_cast<uint2*>(dout + (size_t)gm * C + c) = pm;
-      *reinterpret_cast<uint2*>(dout + (size_t)gm * C + HALF + c) = pl;
+    for (int k = 0; k < 5; ++k) {                            // all of the phase's HBM reads first
+      const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row < R ? m0 + row : R - 1;
+      lr4[k] = *reinterpret_cast<const float4*>(a.logs_raw + (size_t)gm * HALF + c);
+      y14[k] = *reinterpret_cast<const float4*>(a.y + (size_t)gm * C + HALF + c);
+      rmv[k] = a.rowmask[gm];
+      dldv[k] = a.dlogdet[a.rowutt[gm]];
     }
-    *reinterpret_cast<uint2*>(Dout + row * AP + c) = pm;
-    *reinterpret_cast<uint2*>(Dout + row * AP + HALF + c) = pl;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int item = threadIdx.x + 256 * k, row = item / 20, c = 4 * (item - row * 20), gm = m0 + row;
+      uint2 pm = make_uint2(0, 0), pl = make_uint2(0, 0);
+      if (gm < R) {
+        const float rm = rmv[k];
+        const float4 dz0 = *reinterpret_cast<const float4*>(Dt + row * ZP + c);
+        const float4 dz1r = *reinterpret_cast<const float4*>(Dt + row * ZP + HALF + c);
+        const float dld = dldv[k] * rm;
+        const float dz1[4] = {dz1r.x * rm, dz1r.y * rm, dz1r.z * rm, dz1r.w * rm};
+        const float lraw[4] = {lr4[k].x, lr4[k].y, lr4[k].z, lr4[k].w}, y1v[4] = {y14[k].x, y14[k].y, y14[k].z, y14[k].w};
+        float dx1[4], dlg[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lg = lraw[j], dl_draw = 1.0f;
+          if (a.sigmoid_scale) { const float sg = sigmoidf_(lraw[j] + 2.0f); lg = __logf(1e-6f + sg); dl_draw = sg * (1.0f - sg) / (1e-6f + sg); }
+          const float e = __expf(lg);
+          dx1[j] = dz1[j] * e;
+          dlg[j] = (dz1[j] * e * y1v[j] + dld) * dl_draw;
+        }
+        *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + c) = dz0;
+        *reinterpret_cast<float4*>(a.dx_out + (size_t)gm * C + HALF + c) = make_float4(dx1[0], dx1[1], dx1[2], dx1[3]);
+        pm = pack4(dz1[0], dz1[1], dz1[2], dz1[3]);
+        pl = pack4(dlg[0], dlg[1], dlg[2], dlg[3]);
+        *reinterpret_cast<uint2*>(dout + (size_t)gm * C + c) = pm;
+        *reinterpret_cast<uint2*>(dout + (size_t)gm * C + HALF + c) = pl;
+      }
+      *reinterpret_cast<uint2*>(Dout + row * AP + c) = pm;
+      *reinterpret_cast<uint2*>(Dout + row * AP + HALF + c) = pl;
+    }
   }
   __syncthreads();
   // end conv data gradient: d wn_out = (d out @ Wend) * mask   (K = 160: 10 k-steps)
   bf16_t* At = Dh;                                           // the d h tile is dead
+  const bf16_t* Wsd = static_cast<const bf16_t*>(a.w_skip_d);
+  constexpr int KS2 = H / 16, NS = NL * KS2;                 // skip data gradient: 4 layer windows x 12 k-steps, ONE weight stream
+  uint4 ring3[RD][3];
   {
     f32x16_t acc[3];
     acc_zero<3>(acc);
-    gemm_lds<3, C / 16>(static_cast<const bf16_t*>(a.w_end_d), a.ks_end_d, 3 * wn, Dout + (32 * wm + r) * AP + 8 * h, lane, acc);
+    gemm_run<3, C / 16>(static_cast<const bf16_t*>(a.w_end_d), a.ks_end_d, 3 * wn, Dout + (32 * wm + r) * AP + 8 * h, lane, ring2, acc);
+#pragma unroll
+    for (int p = 0; p < RD; ++p)                             // the skip stage's first fragments fly under this epilogue
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) ring3[p][bn] = ldfrag(Wsd, (6 * (p / KS2) + 3 * wn + bn) * a.ks_skip_d + p % KS2, lane);
     bf16_t* dwn = static_cast<bf16_t*>(a.dwn_out);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
@@ -482,11 +537,21 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
   __syncthreads();
   // skip data gradient: d acts_l (skip path) = d wn_out @ Wskip_l, one layer window per pass
   bf16_t* via = static_cast<bf16_t*>(a.via_skip);
+  const bf16_t* brow = At + (32 * wm + r) * AP + 8 * h;
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     f32x16_t acc[3];
     acc_zero<3>(acc);
-    gemm_lds<3, H / 16>(static_cast<const bf16_t*>(a.w_skip_d), a.ks_skip_d, 6 * l + 3 * wn, At + (32 * wm + r) * AP + 8 * h, lane, acc);
+#pragma unroll
+    for (int kk = 0; kk < KS2; ++kk) {
+      const int st = l * KS2 + kk, nx = st + RD;
+      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + kk * 16);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) {
+        acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring3[st % RD][bn]), bfm, acc[bn], 0, 0, 0);
+        if (nx < NS) ring3[st % RD][bn] = ldfrag(Wsd, (6 * (nx / KS2) + 3 * wn + bn) * a.ks_skip_d + nx % KS2, lane);
+      }
+    }
     if (mrow < R) {
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn)
