@@ -406,6 +406,9 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
 
 
 # ----------------------------------------------------------------------------- fused between-WaveNets kernels
+BOUNDARY_TRACE = None        # dev (tools/wn_boundary_bench.py): a list collects the (entry name, args struct, keep-alive) of every launch
+
+
 class _BlockState:
     """what one flow block keeps for the backward on the fused path"""
     __slots__ = ("x_in", "y", "x0", "h0", "wn_saved", "wn_out", "logs_raw", "z", "scal", "w_ic")
@@ -483,6 +486,8 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed):
             blocks.append(st)
         args = _lib.fill_args(_lib.BoundaryFwdArgs, **kw)
         import ctypes
+        if BOUNDARY_TRACE is not None:
+            BOUNDARY_TRACE.append(("gt_wn_boundary_fwd", args, kw))
         _ev = KERNEL_TIMER.start("wn_boundary_fwd")
         rcode = L.gt_wn_boundary_fwd(ctypes.byref(args), _st(dev))
         KERNEL_TIMER.stop(_ev)
@@ -533,6 +538,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
             new_tail = (dout, dwn, via)
         kw.update(dx_out=dx_out)
         args = _lib.fill_args(_lib.BoundaryBwdArgs, **kw)
+        if BOUNDARY_TRACE is not None:
+            BOUNDARY_TRACE.append(("gt_wn_boundary_bwd", args, kw))
         _ev = KERNEL_TIMER.start("wn_boundary_bwd")
         rcode = L.gt_wn_boundary_bwd(ctypes.byref(args), _st(dev))
         KERNEL_TIMER.stop(_ev)
