@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--one-batch", action="store_true", help="round 1's protocol: the same batch every step")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: gradient exchange in fp32 (the reference's DDP all-reduce; default) or bf16 on the wire with fp32 accumulation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -246,7 +248,7 @@ def main():
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
     use_graph = not args.no_graph
-    tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True)
+    tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True, grad_wire=args.grad_wire)
     nb = 1 if args.one_batch else N_BATCHES
     batches = [make_batch(wl, rank, dev, i) for i in range(nb)]
     call = lambda b: tr.step(b["ids"], b["t_x"], b["y"], b["t_y"], lengths_host=b["lh"], **b["cond"])      # noqa: E731
@@ -305,7 +307,7 @@ def main():
                        "rows_layout": "ragged" if tr.cfg.ragged else "uniform",
                        "row_buckets_(text, mel, frames)": [list(k) for k in rows_keys], "graphs_captured": tr.n_captures,
                        "capture_s_untimed": round(t_cap, 2),
-                       "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce)",
+                       "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce, {args.grad_wire} on the wire)",
                        "launch": (("one HIP graph per step (one per ragged-row bucket, captured up front)" if world == 1 else
                                    "three HIP graphs per step (forward + decoder-side backward | encoder backward | optimizer), the RCCL "
                                    "all-reduces of the flat gradient buffer launched between them") if tr.graph_mode else "eager launches"),

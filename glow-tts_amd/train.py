@@ -76,12 +76,18 @@ class GradBuckets:
     `gather()` (one multi-tensor copy); the optimizer and the collectives only ever see the flat buffer."""
     ALIGN = 64          # floats: every parameter starts on a 256-byte boundary
 
-    def __init__(self, params, world, bucket_mb=64, accum=()):
-        """accum: parameters whose gradients are ACCUMULATED by atomics (LayerNorm, ActNorm, InvConvNear, relative-
+    def __init__(self, params, world, bucket_mb=64, accum=(), wire="fp32"):
+        """wire: "fp32" — all-reduce (mean) of the fp32 buffer, what the reference's DDP does; "bf16" — half the bytes on
+        xGMI with fp32 accumulation: every rank sends bf16 copies of the other ranks' shards (all-to-all), sums the copies of
+        its own shard in fp32, and the reduced shards travel back as bf16 (all-gather); all ranks end up with bit-identical
+        gradients, rounded to bf16 twice (opt-in: `Trainer(grad_wire="bf16")`).
+        accum: parameters whose gradients are ACCUMULATED by atomics (LayerNorm, ActNorm, InvConvNear, relative-
         position and token embeddings): they are laid out first, contiguously, and `zero_accum()` clears that region
         with one fill per step, so that their backward kernels add straight into the flat buffer
         (ops.grad_accumulator) — every other gradient is overwritten whole by the batched wgrad kernels."""
         self.world = world
+        assert wire in ("fp32", "bf16")
+        self.wire, self._wire_bufs = wire, {}
         ids = {id(p) for p in accum}
         ps = [p for p in params if p.requires_grad]
         self.params = [p for p in ps if id(p) in ids] + [p for p in ps if id(p) not in ids]
@@ -164,6 +170,19 @@ class GradBuckets:
         if self.world == 1 or hi <= lo:
             return
         pieces = [(max(s, lo), min(e, hi)) for s, e in self.buckets if min(e, hi) > max(s, lo)]
+        if self.wire == "bf16":
+            if self.on_gpu:
+                cur = torch.cuda.current_stream()
+                self.comm.wait_stream(cur)
+                with torch.cuda.stream(self.comm):
+                    for s, e in pieces:
+                        self._allreduce_bf16(s, e)
+                if wait:
+                    cur.wait_stream(self.comm)
+            else:
+                for s, e in pieces:
+                    self._allreduce_bf16(s, e)
+            return
         if self.on_gpu:
             cur = torch.cuda.current_stream()
             self.comm.wait_stream(cur)
@@ -179,6 +198,33 @@ class GradBuckets:
             for s, e in pieces:
                 dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM)
                 self.flat[s:e].mul_(1.0 / self.world)
+
+    def _allreduce_bf16(self, lo, hi):
+        """mean of floats [lo, hi) over the ranks with bf16 on the wire and fp32 accumulation (see __init__)."""
+        w, rank, n = self.world, dist.get_rank(), hi - lo
+        shard = (-(-n // w) + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        bufs = self._wire_bufs.get((lo, hi))
+        if bufs is None:
+            dev = self.flat.device
+            bufs = self._wire_bufs[(lo, hi)] = tuple(torch.zeros(w * shard, dtype=torch.bfloat16, device=dev) for _ in range(3)) + \
+                (torch.empty(shard, dtype=torch.bfloat16, device=dev),)
+        send, recv, full, mine = bufs
+        send[:n].copy_(self.flat[lo:hi])                                        # fp32 -> bf16; the padding stays zero
+        if dist.get_backend() == "nccl":
+            dist.all_to_all_single(recv, send)                                  # recv[j] = rank j's copy of MY shard
+            copies = recv.view(w, shard)
+        else:                                                                   # gloo (tests) has no all-to-all
+            every = [torch.empty_like(send) for _ in range(w)]
+            dist.all_gather(every, send)
+            copies = torch.stack([t[rank * shard:(rank + 1) * shard] for t in every])
+        mine.copy_(copies.float().sum(0).mul_(1.0 / w))                         # fp32 accumulate, bf16 back onto the wire
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(full, mine)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(w)]
+            dist.all_gather(parts, mine)
+            full.copy_(torch.cat(parts))
+        self.flat[lo:hi].copy_(full[:n])
 
     def wait_comm(self):
         if self.comm is not None:
@@ -258,7 +304,7 @@ class Trainer:
     WARMUPS = 2
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
-                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False):
+                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32"):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph forces the phased, several-graph form (default: world > 1)."""
         from collections import OrderedDict
@@ -277,7 +323,7 @@ class Trainer:
         # of the model's sub-modules; checkpoint.py maps the flat layout back to model.parameters() order by identity)
         named = list(model.named_parameters())
         plist = [p for n, p in named if not n.startswith("decoder.")] + [p for n, p in named if n.startswith("decoder.")]
-        self.buckets = GradBuckets(plist, world, accum=accum)
+        self.buckets = GradBuckets(plist, world, accum=accum, wire=grad_wire)      # grad_wire="bf16": GradBuckets.__init__
         # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
         # first backward call and travel over xGMI while the text encoder's backward runs
         name_of = {id(p): n for n, p in model.named_parameters()}
