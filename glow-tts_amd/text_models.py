@@ -8,6 +8,7 @@
                       round-1 scope).
 """
 import math
+import contextlib
 import os
 
 import torch
@@ -332,6 +333,7 @@ def mle_loss(z, m, logs, logdet, mask):
 
 
 ENCODER_STREAM = os.environ.get("GT_ENC_STREAM", "1") != "0"
+PREDICTOR_BRANCH = os.environ.get("GT_PRED_BRANCH", "1") != "0"     # stochastic predictors on the encoder's stream (cfg 5)
 _ENC_STREAMS = {}
 
 
@@ -623,6 +625,29 @@ class FlowGenerator(nn.Module):
             attn = mas.path.unsqueeze(1)
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         rcx, xb = self.encoder._last_rows
+        # The stochastic predictors need the alignment, but nothing after them does except the loss: they go onto the
+        # encoder's stream, so that autograd replays their (long, row-wise) backward there too, beside the decoder's.
+        pfork = fork and PREDICTOR_BRANCH and (self.use_sdp or self.use_spp or self.use_sep)
+        if pfork:
+            enc_stream.wait_stream(main)
+            for t_ in (w, mas.frame2token, mas.durations, pitch_norm, energy_norm, z_mask, x_mask, y_lengths):
+                if t_ is not None:
+                    t_.record_stream(enc_stream)
+        with (torch.cuda.stream(enc_stream) if pfork else contextlib.nullcontext()):
+            l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, z_mask, g, l, logw, noise, mas, y_lengths,
+                                                                       y_max_length, pitch_norm, energy_norm)
+        if pfork:
+            main.wait_stream(enc_stream)
+            for t_ in (l_length, l_pitch, l_energy):
+                if t_ is not None:
+                    t_.record_stream(main)
+        z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
+        z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)
+        self.last_logp = logp
+        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, l_pitch, l_energy), (None, None, None, None), None
+
+    def _predictor_losses(self, rcx, xb, w, x_mask, z_mask, g, l, logw, noise, mas, y_lengths, y_max_length, pitch_norm, energy_norm):
+        """l_length, l_pitch, l_energy of models.py:1086-1115 (+ logw of the deterministic duration predictor)."""
         if self.use_sdp:                                                       # models.py:1086-1088
             pw = self.encoder.proj_w
             w_rows = rcx.to_rows(w.float())[:, 0].contiguous()
@@ -646,7 +671,4 @@ class FlowGenerator(nn.Module):
                 pe = self.proj_energy
                 nez = None if noise is None else rcf.to_rows(noise[2].float())[:, 0].contiguous()
                 l_energy = torch.sum(pe.nll_rows(rcf, xf, rcf.to_rows(energy_norm.float())[:, 0].contiguous(), pe.cond_vec(g), nez) / zsum)
-        z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
-        z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)
-        self.last_logp = logp
-        return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, l_pitch, l_energy), (None, None, None, None), None
+        return l_length, l_pitch, l_energy, logw
