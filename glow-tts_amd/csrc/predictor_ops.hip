@@ -20,7 +20,21 @@ namespace {
 
 constexpr int PC = 192;                       // channels of every predictor network (filter_channels = in_channels, models.py:223)
 constexpr int NC = PC / 64;                   // channels per lane
-constexpr int RPW = 8;                        // rows per wave per workgroup
+constexpr int RPW = 8;                        // rows per wave per workgroup (forward kernels)
+constexpr int RPB = 8;                        // ... of the backward kernels that also accumulate parameter gradients
+
+// parameter-gradient partial of this lane -> ONE atomic per address per workgroup: the four waves' values are folded in LDS
+// first (same-address float atomics serialise at L2, ~25-50 ns each; with one per wave they were most of these kernels)
+__device__ __forceinline__ void wg_fold_add(float* __restrict__ dst, float v, float* sm, int lane, int wave)
+{
+  sm[wave * 64 + lane] = v;
+  __syncthreads();
+  if (wave == 0) {
+    const float s = sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
+    if (s != 0.f) atomicAdd(dst, s);
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x)
@@ -161,8 +175,9 @@ __global__ __launch_bounds__(256) void gt_dds_out_bwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[NC], be[NC], ag[NC] = {}, ab[NC] = {};
   ld3(gamma, lane, g); ld3(beta, lane, be);
-  const int m0 = (blockIdx.x * 4 + wave) * RPW;
-  for (int i = 0; i < RPW; ++i) {
+  __shared__ float fold_sm[256];
+  const int m0 = (blockIdx.x * 4 + wave) * RPB;
+  for (int i = 0; i < RPB; ++i) {
     const int m = m0 + i;
     if (m >= R) break;
     float o[NC] = {};
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(256) void gt_dds_out_bwd_kernel(
     for (int j = 0; j < NC; ++j) split3_store(dh2 + (size_t)m * 3 * PC, lane + 64 * j, o[j]);
   }
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { atomicAdd(dgamma + lane + 64 * j, ag[j]); atomicAdd(dbeta + lane + 64 * j, ab[j]); }
+  for (int j = 0; j < NC; ++j) { wg_fold_add(dgamma + lane + 64 * j, ag[j], fold_sm, lane, wave); wg_fold_add(dbeta + lane + 64 * j, ab[j], fold_sm, lane, wave); }
 }
 
 // backward of the first half, row-local part: d a1 (fp32, from the 1x1 data-gradient GEMM) -> d h1 (gradient at the
@@ -204,8 +219,9 @@ __global__ __launch_bounds__(256) void gt_dds_sep_bwd_kernel(
     wk[0][j] = w[c * 3]; wk[1][j] = w[c * 3 + 1]; wk[2][j] = w[c * 3 + 2];
     bb[j] = b[c]; g[j] = gamma[c]; be[j] = beta[c];
   }
-  const int m0 = (blockIdx.x * 4 + wave) * RPW;
-  for (int i = 0; i < RPW; ++i) {
+  __shared__ float fold_sm[256];
+  const int m0 = (blockIdx.x * 4 + wave) * RPB;
+  for (int i = 0; i < RPB; ++i) {
     const int m = m0 + i;
     if (m >= R) break;
     float o[NC] = {};
@@ -226,7 +242,7 @@ __global__ __launch_bounds__(256) void gt_dds_sep_bwd_kernel(
     for (int j = 0; j < NC; ++j) dh1[(size_t)m * PC + lane + 64 * j] = o[j];
   }
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { atomicAdd(dgamma + lane + 64 * j, ag[j]); atomicAdd(dbeta + lane + 64 * j, ab[j]); }
+  for (int j = 0; j < NC; ++j) { wg_fold_add(dgamma + lane + 64 * j, ag[j], fold_sm, lane, wave); wg_fold_add(dbeta + lane + 64 * j, ab[j], fold_sm, lane, wave); }
 }
 
 // backward of the depthwise conv + the residual: dx = (dy + sum_k w[k] * dh1[m - (k-1)d]) * mask;
@@ -240,8 +256,9 @@ __global__ __launch_bounds__(256) void gt_dds_dw_bwd_kernel(
   float wk[3][NC], aw[3][NC] = {}, ab[NC] = {};
 #pragma unroll
   for (int j = 0; j < NC; ++j) { const int c = lane + 64 * j; wk[0][j] = w[c * 3]; wk[1][j] = w[c * 3 + 1]; wk[2][j] = w[c * 3 + 2]; }
-  const int m0 = (blockIdx.x * 4 + wave) * RPW;
-  for (int i = 0; i < RPW; ++i) {
+  __shared__ float fold_sm[256];
+  const int m0 = (blockIdx.x * 4 + wave) * RPB;
+  for (int i = 0; i < RPB; ++i) {
     const int m = m0 + i;
     if (m >= R) break;
     float o[NC] = {};
@@ -274,8 +291,8 @@ __global__ __launch_bounds__(256) void gt_dds_dw_bwd_kernel(
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = lane + 64 * j;
-    atomicAdd(dw + c * 3, aw[0][j]); atomicAdd(dw + c * 3 + 1, aw[1][j]); atomicAdd(dw + c * 3 + 2, aw[2][j]);
-    atomicAdd(db + c, ab[j]);
+    wg_fold_add(dw + c * 3, aw[0][j], fold_sm, lane, wave); wg_fold_add(dw + c * 3 + 1, aw[1][j], fold_sm, lane, wave);
+    wg_fold_add(dw + c * 3 + 2, aw[2][j], fold_sm, lane, wave); wg_fold_add(db + c, ab[j], fold_sm, lane, wave);
   }
 }
 
@@ -312,8 +329,9 @@ __global__ __launch_bounds__(256) void gt_convflow_pre_bwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float w[NC], aw[NC] = {}, ab[NC] = {};
   ld3(wp, lane, w);
-  const int m0 = (blockIdx.x * 4 + wave) * RPW;
-  for (int i = 0; i < RPW; ++i) {
+  __shared__ float fold_sm[256];
+  const int m0 = (blockIdx.x * 4 + wave) * RPB;
+  for (int i = 0; i < RPB; ++i) {
     const int m = m0 + i;
     if (m >= R) break;
     if (rowmask[m] == 0.f) continue;
@@ -329,7 +347,7 @@ __global__ __launch_bounds__(256) void gt_convflow_pre_bwd_kernel(
     if (lane == 0 && dz) dz[(size_t)m * lddz] += s;
   }
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { atomicAdd(dwp + lane + 64 * j, aw[j]); atomicAdd(dbp + lane + 64 * j, ab[j]); }
+  for (int j = 0; j < NC; ++j) { wg_fold_add(dwp + lane + 64 * j, aw[j], fold_sm, lane, wave); wg_fold_add(dbp + lane + 64 * j, ab[j], fold_sm, lane, wave); }
 }
 
 // ------------------------------------------------------------------------------------------------ spline
@@ -672,7 +690,13 @@ __global__ __launch_bounds__(256) void gt_ea_bwd_kernel(const float* __restrict_
     dx[2 * m] = g0; dx[2 * m + 1] = g1;
   }
   a0 = wave_sum(a0); a1 = wave_sum(a1); t0 = wave_sum(t0); t1 = wave_sum(t1);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(dls, a0); atomicAdd(dls + 1, a1); atomicAdd(dtr, t0); atomicAdd(dtr + 1, t1); }
+  __shared__ float sm[4][4];
+  if ((threadIdx.x & 63) == 0) { float* q = sm[threadIdx.x >> 6]; q[0] = a0; q[1] = a1; q[2] = t0; q[3] = t1; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (v != 0.f) atomicAdd((threadIdx.x < 2 ? dls : dtr) + (threadIdx.x & 1), v);
+  }
 }
 
 // StochasticDurationPredictor, between the posterior flows and the flows (models.py:299-311):
@@ -772,6 +796,7 @@ __global__ __launch_bounds__(256) void gt_rows_split3_kernel(const void* __restr
 #define GT_ST(s) static_cast<hipStream_t>(s)
 #define GT_RET() return gt_launch_status(__func__)
 inline int wg_rows(int R) { return (R + 4 * RPW - 1) / (4 * RPW); }
+inline int wg_rows_b(int R) { return (R + 4 * RPB - 1) / (4 * RPB); }
 inline void fill_drop(float p, uint32_t& th, float& sc) { th = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f; }
 
 }  // namespace
@@ -808,7 +833,7 @@ extern "C" int gt_dds_out_bwd(const float* h2, const float* dy, const float* gam
   if (!h2 || !dy || !gamma || !beta || !rowmask || !dh2_bf16 || !dgamma || !dbeta || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
   uint32_t th; float sc; fill_drop(drop_p, th, sc);
-  hipLaunchKernelGGL(gt_dds_out_bwd_kernel, dim3(wg_rows(R)), dim3(256), 0, GT_ST(stream), h2, dy, gamma, beta, rowmask,
+  hipLaunchKernelGGL(gt_dds_out_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), h2, dy, gamma, beta, rowmask,
                      static_cast<bf16_t*>(dh2_bf16), dgamma, dbeta, R, eps, th, seed, seed_dev, sc);
   GT_RET();
 }
@@ -818,7 +843,7 @@ extern "C" int gt_dds_sep_bwd(const float* x, int ldx, const float* w, const flo
 {
   if (!x || !w || !b || !gamma || !beta || !utt || !rowmask || !da1 || !dh1 || !dgamma || !dbeta || R <= 0 || dilation <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(gt_dds_sep_bwd_kernel, dim3(wg_rows(R)), dim3(256), 0, GT_ST(stream), x, ldx, w, b, gamma, beta, utt, rowmask, da1, dh1,
+  hipLaunchKernelGGL(gt_dds_sep_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), x, ldx, w, b, gamma, beta, utt, rowmask, da1, dh1,
                      dgamma, dbeta, R, dilation, eps);
   GT_RET();
 }
@@ -827,7 +852,7 @@ extern "C" int gt_dds_dw_bwd(const float* x, int ldx, const float* dh1, const fl
 {
   if (!x || !dh1 || !dy || !w || !utt || !rowmask || !dx || !dw || !db || R <= 0 || dilation <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(gt_dds_dw_bwd_kernel, dim3(wg_rows(R)), dim3(256), 0, GT_ST(stream), x, ldx, dh1, dy, w, utt, rowmask, dx, dw, db, R, dilation);
+  hipLaunchKernelGGL(gt_dds_dw_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), x, ldx, dh1, dy, w, utt, rowmask, dx, dw, db, R, dilation);
   GT_RET();
 }
 extern "C" int gt_convflow_pre_fwd(const float* z, int ldz, const float* w_pre, const float* b_pre, const float* g1, const float* g2,
@@ -843,7 +868,7 @@ extern "C" int gt_convflow_pre_bwd(const float* dx0, const float* z, int ldz, co
 {
   if (!dx0 || !z || !w_pre || !rowmask || !dw_pre || !db_pre || R <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(gt_convflow_pre_bwd_kernel, dim3(wg_rows(R)), dim3(256), 0, GT_ST(stream), dx0, z, ldz, w_pre, rowmask, dw_pre, db_pre,
+  hipLaunchKernelGGL(gt_convflow_pre_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), dx0, z, ldz, w_pre, rowmask, dw_pre, db_pre,
                      dz, lddz, dg, R);
   GT_RET();
 }
