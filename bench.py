@@ -321,21 +321,31 @@ def main():
         # ---- roofline: the fused WaveNet-layer forward kernel, timed INSIDE the replayed graphs by its own device stamps
         roof = {"bound": "mfma", "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
         if tr.stamps is not None:
-            d = tr.stamps.durations_ticks()[steps0:steps0 + args.steps].double()          # [K, launches per step] in 10-ns ticks
+            d = tr.stamps.durations_ticks()[steps0:steps0 + args.steps].double()          # [K, slots per step] in 10-ns ticks
             nl = model.decoder.n_layers
-            res_mask = torch.tensor([(k % nl) != nl - 1 for k in range(d.shape[1])])      # the layers that carry the residual 1x1
-            us = d[:, res_mask].mean().item() / 100.0                                     # wall_clock64: 100 MHz
             rows_valid = (valid_total / args.steps) / 2.0                                 # squeezed frames
-            flops_launch = 2.0 * rows_valid * (384 * 192 * 5 + 192 * 192)
+            from glow_tts_amd import flow_impl
+            if flow_impl.WN_STACK and model.decoder.flows[2].wn.fused:
+                # one launch per WaveNet (csrc/wn_stack.hip): the first n_blocks slots of a step are written, the rest stay empty
+                used = d[:, :model.decoder.n_blocks]
+                us = used.mean().item() / 100.0                                           # wall_clock64: 100 MHz
+                flops_launch = 2.0 * rows_valid * (nl * 384 * 192 * 5 + (nl - 1) * 192 * 192)
+                name = (f"gt_wn_stack_fwd_kernel (a whole WaveNet forward in one launch: {nl} x (k=5 conv 192->384 + gate) + {nl - 1} x "
+                        f"residual 1x1, halo recomputed per 52-row tile; {used.shape[1]} launches per step)")
+                extra, n_l = {}, used.numel()
+            else:
+                res_mask = torch.tensor([(k % nl) != nl - 1 for k in range(d.shape[1])])  # the layers that carry the residual 1x1
+                us = d[:, res_mask].mean().item() / 100.0
+                flops_launch = 2.0 * rows_valid * (384 * 192 * 5 + 192 * 192)
+                name = ("gt_wn_layer_fwd_kernel<true> (WaveNet layer: k=5 conv 192->384 + gate + residual 1x1, one launch; "
+                        f"{int(res_mask.sum())} launches per step)")
+                extra, n_l = {"launch_us_last_layer_variant": d[:, ~res_mask].mean().item() / 100.0}, int(res_mask.sum()) * args.steps
             tf = flops_launch / (us * 1e-6) / 1e12
-            roof.update({"achieved": tf, "frac": tf / MFMA_BF16_PEAK_TFLOPS,
-                         "kernel": "gt_wn_layer_fwd_kernel<true> (WaveNet layer: k=5 conv 192->384 + gate + residual 1x1, one launch; "
-                                   f"{int(res_mask.sum())} launches per step)",
-                         "algorithmic_flops_per_launch": flops_launch, "launch_us": us,
-                         "launch_us_last_layer_variant": d[:, ~res_mask].mean().item() / 100.0,
+            roof.update({"achieved": tf, "frac": tf / MFMA_BF16_PEAK_TFLOPS, "kernel": name,
+                         "algorithmic_flops_per_launch": flops_launch, "launch_us": us, **extra,
                          "how": "device-side begin / end stamps (wall_clock64, 100 MHz) written by every launch of the kernel inside the "
                                 "replayed HIP graphs of the timed steps: max(end) - min(start) per launch, mean over "
-                                f"{int(res_mask.sum()) * args.steps} launches; FLOPs count the VALID squeezed frames only",
+                                f"{n_l} launches; FLOPs count the VALID squeezed frames only (the recomputed halo rows are not counted)",
                          "profile": "profiles/r02_trainstep_*_summary.txt (rocprofv3 --kernel-trace --stats of the same command)"})
             pmc = os.path.join(ROOT, "profiles", "r02_wn_layer_pmc.json")
             if os.path.exists(pmc):

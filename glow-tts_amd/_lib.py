@@ -80,6 +80,8 @@ PROTOTYPES = {
     "gt_wn_layer_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u32,
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gt_wn_stack_fwd": (c_int, [c_void_p, c_void_p]),
+    "gt_wn_stack_rows_per_workgroup": (c_int, [c_int]),
     "gt_wn_boundary_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -117,6 +119,15 @@ class PackDesc(ctypes.Structure):
                 ("row_start", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
+class WnStackFwdArgs(ctypes.Structure):
+    """struct gt_wn_stack_fwd_args (include/glowtts_hip.h)"""
+    _fields_ = [("x0", c_void_p), ("w_in", c_void_p * 4), ("b_in", c_void_p * 4), ("w_res", c_void_p * 4), ("b_res", c_void_p * 4),
+                ("cond", c_void_p), ("ldc", c_int), ("row0", c_void_p), ("B", c_int), ("Tp", c_int), ("rowmask", c_void_p),
+                ("acts", c_void_p), ("ldacts", c_int), ("gate_t", c_void_p * 4), ("gate_s", c_void_p * 4), ("x_out", c_void_p * 4),
+                ("R", c_int), ("H", c_int), ("taps", c_int), ("n_layers", c_int), ("drop_p", c_float), ("drop_seed", c_u32),
+                ("seed_dev", c_void_p), ("stamps", c_void_p), ("stamp_slot", c_int), ("stamp_base", c_void_p)]
+
+
 class BoundaryFwdArgs(ctypes.Structure):
     """struct gt_boundary_fwd_args (include/glowtts_hip.h); pointer fields take tensor.data_ptr() or None"""
     _fields_ = [("acts", c_void_p), ("ldacts", c_int), ("w_skip", c_void_p), ("b_skip", c_void_p),
@@ -143,7 +154,12 @@ def fill_args(cls, **kw):
     """ctypes struct from keyword arguments: tensors become device pointers, None stays NULL, ints stay ints."""
     a = cls()
     for k, v in kw.items():
-        setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
+        if isinstance(v, (list, tuple)):                  # pointer arrays: tensors / None per entry
+            arr = getattr(a, k)
+            for i, t in enumerate(v):
+                arr[i] = None if t is None else (t.data_ptr() if hasattr(t, "data_ptr") else t)
+        else:
+            setattr(a, k, v.data_ptr() if hasattr(v, "data_ptr") else v)
     return a
 
 

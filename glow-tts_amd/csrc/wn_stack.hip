@@ -1,0 +1,270 @@
+// A whole WaveNet (all n = 4 gated layers of modules.WN.forward, modules.py:144-171) as ONE kernel, gfx950.
+//
+// csrc/wn_layer.hip runs one kernel per layer: a workgroup owns 64 rows and all channels, and between two layers every row
+// tile needs 2 rows of its neighbours (k = 5), which is why the layers are separate launches (~2.5 us of launch gap, the first
+// tile's load latency and the store drain at the kernel boundary per layer, on the decoder's dependent chain).  Here a workgroup
+// RECOMPUTES that halo instead of exchanging it: it loads 68 rows of the WaveNet's input, computes layer 0 on 64 rows, layer 1
+// is then exact on the inner 60, layer 2 on 56, layer 3 on 52 — the workgroup OWNS those 52 rows and stores only them; tiles
+// advance by 52 rows (9 216..9 728 rows of cfg 2 -> 178..188 workgroups instead of 144..152: the extra 23 % of arithmetic runs on
+// CUs that were idle).  The layer's input never leaves LDS ([68][192] bf16, ping-pong), the k=5 conv needs no K-slice staging
+// and no barrier in its loop, and x_{i+1} is stored (for the weight gradients / the backward) without anyone waiting for it.
+// A halo row is computed by two workgroups with the same arithmetic in the same order and the same dropout hash (seed, global
+// row, column): what they produce is bit-identical, so the result equals the per-layer kernels' bit for bit.
+//
+// Per layer (as wn_layer.hip): stage 1  x_in = conv_k5(x): N = 384, K = 960; 4 waves x (64 rows x 96 columns); weights as MFMA-A
+// fragments L2 -> registers (3-step ring), activations = MFMA-B from the LDS tile; gate epilogue in registers (bias, dropout,
+// cond, tanh * sigmoid; T, S, acts -> HBM for the owned rows, acts -> LDS); stage 2  x_next = (x + acts @ W_res^T + b) * mask.
+#include "common.h"
+#include "../../include/glowtts_hip.h"
+
+namespace {
+
+constexpr int H = 192, TAPS = 5, NLMAX = 4;
+constexpr int BM = 64;                        // rows computed per layer
+constexpr int AP = H + 8;                     // LDS pitch (halfs): 400 B = 16 mod 128 -> conflict-free ds_read_b128
+constexpr int XR = BM + TAPS - 1;             // 68 input rows
+#ifndef WNS_RING
+#define WNS_RING 3
+#endif
+constexpr int RING = WNS_RING;
+constexpr int KK2 = H / 16;
+constexpr int STACK_LDS = (2 * XR + BM) * AP * 2;                       // Xa, Xb [68][200] + At [64][200] = 80 000 B
+
+__device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
+{
+  return *reinterpret_cast<const uint4*>(W + ((size_t)f * 64 + lane) * 8);
+}
+__device__ __forceinline__ bf16x8_t asfrag(const uint4& u) { return __builtin_bit_cast(bf16x8_t, u); }
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2bf(a, b), pack2bf(c, d)); }
+__device__ __forceinline__ void unpack4(const uint2& u, float (&v)[4])
+{
+  v[0] = bf2f(u.x & 0xffff); v[1] = bf2f(u.x >> 16); v[2] = bf2f(u.y & 0xffff); v[3] = bf2f(u.y >> 16);
+}
+template <typename T>
+__device__ __forceinline__ T pick(T const (&arr)[NLMAX], int i)        // scalar selects: no dynamically indexed kernarg copy
+{
+  return i == 0 ? arr[0] : (i == 1 ? arr[1] : (i == 2 ? arr[2] : arr[3]));
+}
+
+__global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_args a, uint32_t drop_thresh, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.stamps && threadIdx.x == 0)
+    atomicMin(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)), (unsigned long long)wall_clock64());
+  const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n_layers = a.n_layers, R = a.R;
+  const int halo = 2 * (n_layers - 1);                               // rows lost per side: 6 for 4 layers
+  const int own = BM - 2 * halo;                                     // rows this workgroup owns: 52
+  const int s0 = blockIdx.x * own - halo;                            // global row of tile row 0
+  bf16_t* Xc = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Xn = Xc + XR * AP;
+  bf16_t* At = Xn + XR * AP;
+  constexpr int KS = H / 16, NBT = 2 * H / 32, NIT = 3 * TAPS;       // 12 k-steps per tap, 12 column blocks, 15 steps of 4 k-steps
+
+  // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero)
+  {
+    const bf16_t* x0 = static_cast<const bf16_t*>(a.x0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int chunk = threadIdx.x + 256 * i, u = chunk / 24, c8 = chunk - u * 24, gm = s0 - 2 + u;
+      if (u < XR) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gm >= 0 && gm < R) v = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
+        *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = v;
+      }
+    }
+    if (threadIdx.x < 4 * 24) {                                       // the next tile's rows 0, 1, 66, 67 are never produced
+      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
+      *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  for (int layer = 0; layer < n_layers; ++layer) {
+    const bool last = layer == n_layers - 1;
+    const bf16_t* W1 = static_cast<const bf16_t*>(pick(a.w_in, layer));
+    const bf16_t* W2 = static_cast<const bf16_t*>(pick(a.w_res, layer));
+    const float* bias1 = pick(a.b_in, layer);
+    const float* bias2 = pick(a.b_res, layer);
+    bf16_t* Tt = static_cast<bf16_t*>(pick(a.gate_t, layer));
+    bf16_t* Ss = static_cast<bf16_t*>(pick(a.gate_s, layer));
+    bf16_t* xo = static_cast<bf16_t*>(pick(a.x_out, layer));
+    const uint32_t seed = (a.drop_seed + (uint32_t)layer) ^ seed_x;
+
+    f32x16_t acc[3][2];
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
+
+    uint4 ring[RING][4][3];
+    auto w_load = [&](int it, uint4 (&dst)[4][3]) {
+      const int kg = it / TAPS, tap = it - kg * TAPS;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = ldfrag(W1, (tap * NBT + 3 * wave + bn) * KS + kg * 4 + ks, lane);
+    };
+#pragma unroll
+    for (int p = 0; p < RING - 1; ++p) w_load(p, ring[p]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int kg = it / TAPS, tap = it - kg * TAPS;
+      w_load(it + RING - 1 < NIT ? it + RING - 1 : NIT - 1, ring[(it + RING - 1) % RING]);
+      __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RING - 1 steps ahead
+      const bf16_t* xsb = Xc + (r + tap) * AP + 8 * h + kg * 64;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16);
+        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * AP + ks * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // second-stage weights start flying now, under the gate epilogue
+    const int wn2 = wave & 1, wm2 = wave >> 1;
+    uint4 ring2[KK2 / 2][3];
+    if (!last) {
+#pragma unroll
+      for (int kk = 0; kk < KK2 / 2; ++kk)
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk, lane);
+    }
+
+    // gate epilogue in registers (see wn_layer.hip): block 3*wave + bn holds [16 tanh | 16 sigmoid] of channels 16*(3*wave+bn)..+15
+    bf16_t* acts = static_cast<bf16_t*>(a.acts) + layer * H;
+    const float* cond = a.cond ? a.cond + (size_t)layer * 2 * H : nullptr;
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int c = 16 * (3 * wave + bn) + 8 * g + 4 * h;
+        const float4 bt = *reinterpret_cast<const float4*>(bias1 + c), bs = *reinterpret_cast<const float4*>(bias1 + H + c);
+        const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int bm = 0; bm < 2; ++bm) {
+          const int t = 32 * bm + r, m = s0 + t;
+          const int mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
+          float ctv[4] = {}, csv[4] = {};
+          if (cond) {
+            const float* cp = cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc) * a.ldc + c;
+            const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
+            ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
+          }
+          float tt[4], ss[4], aa[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
+            if (drop_thresh) {                                         // x_in = drop(conv(x)) (modules.py:153)
+              vt = drop_keep(seed, m, c + j, drop_thresh) ? vt * drop_scale : 0.0f;
+              vs = drop_keep(seed, m, H + c + j, drop_thresh) ? vs * drop_scale : 0.0f;
+            }
+            vt += ctv[j]; vs += csv[j];
+            tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
+          }
+          const uint2 pa = pack4(aa[0], aa[1], aa[2], aa[3]);
+          if (t >= halo && t < BM - halo && m < R) {                   // the rows this workgroup owns
+            *reinterpret_cast<uint2*>(Tt + (size_t)m * H + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
+            *reinterpret_cast<uint2*>(Ss + (size_t)m * H + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
+            *reinterpret_cast<uint2*>(acts + (size_t)m * a.ldacts + c) = pa;
+          }
+          if (!last) *reinterpret_cast<uint2*>(At + t * AP + c) = pa;
+        }
+      }
+    if (last) break;
+    __syncthreads();                                                   // At complete
+
+    // stage 2: x_next = (x + acts @ W_res^T + b_res) * mask -> the next layer's LDS tile (+ HBM for the owned rows)
+    f32x16_t acc2[3];
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
+    {
+      const bf16_t* ab = At + (32 * wm2 + r) * AP + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < KK2; ++kk) {
+        const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
+          if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk + KK2 / 2, lane);
+        }
+      }
+    }
+    {
+      const int t = 32 * wm2 + r, m = s0 + t;
+      const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+      const bool mine = t >= halo && t < BM - halo && m < R;
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * (3 * wn2 + bn) + 8 * g + 4 * h;
+          const float4 b2 = *reinterpret_cast<const float4*>(bias2 + n);
+          float xv[4];
+          unpack4(*reinterpret_cast<const uint2*>(Xc + (t + 2) * AP + n), xv);
+          const uint2 v = pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
+                                (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
+          *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
+          if (mine) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
+        }
+    }
+    __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
+    bf16_t* tmp = Xc; Xc = Xn; Xn = tmp;
+    if (threadIdx.x < 4 * 24) {                                        // rows 0, 1, 66, 67 of the tile after next
+      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
+      *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
+    }
+  }
+  if (a.stamps && threadIdx.x == 0)
+    atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
+}
+
+inline bool al16(const void* p) { return !((uintptr_t)p & 15); }
+
+}  // namespace
+
+extern "C" int gt_wn_stack_rows_per_workgroup(int n_layers) { return BM - 4 * (n_layers - 1); }
+
+extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
+{
+  if (!args) return GT_E_INVAL;
+  const gt_wn_stack_fwd_args& a = *args;
+  if (a.R < 0) return GT_E_INVAL;
+  if (a.R == 0) return GT_OK;
+  if (a.H != H || a.taps != TAPS || a.n_layers < 1 || a.n_layers > NLMAX) return GT_E_UNSUPPORTED;
+  if (!a.x0 || !a.rowmask || !a.acts || a.ldacts < a.n_layers * H || (a.ldacts & 3) || (a.cond && (a.ldc & 3))) return GT_E_INVAL;
+  if (!al16(a.x0) || !al16(a.acts) || !al16(a.cond)) return GT_E_ALIGN;
+  for (int i = 0; i < a.n_layers; ++i) {
+    if (!a.w_in[i] || !a.b_in[i] || !a.gate_t[i] || !a.gate_s[i]) return GT_E_INVAL;
+    if (i < a.n_layers - 1 && (!a.w_res[i] || !a.b_res[i] || !a.x_out[i])) return GT_E_INVAL;
+    if (!al16(a.w_in[i]) || !al16(a.b_in[i]) || !al16(a.gate_t[i]) || !al16(a.gate_s[i]) || !al16(a.w_res[i]) || !al16(a.b_res[i]) ||
+        !al16(a.x_out[i])) return GT_E_ALIGN;
+  }
+  if (a.cond && (a.Tp <= 0 || (a.row0 && a.B <= 0))) return GT_E_INVAL;
+  uint32_t thresh = 0; float scale = 1.0f;
+  if (a.drop_p > 0.0f) {
+    if (a.drop_p >= 1.0f) return GT_E_UNSUPPORTED;
+    thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
+  }
+  static bool attr = false;                    // > 64 KB of LDS: opt in once per process
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS) != hipSuccess)
+      return GT_E_LAUNCH;
+    attr = true;
+  }
+  const int own = BM - 4 * (a.n_layers - 1);
+  const dim3 grid((a.R + own - 1) / own), block(256);
+  hipLaunchKernelGGL(gt_wn_stack_fwd_kernel, grid, block, STACK_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  return gt_launch_status(__func__);
+}

@@ -156,6 +156,30 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
     x = h0
     fused = _fused_ok(wn)
     stamps = getattr(rc, "stamps", None)              # bench.py: live in-graph timing of the dominant kernel (ops.KernelStamps)
+    if fused and WN_STACK and n <= 4:
+        # all layers in ONE launch (csrc/wn_stack.hip: the 2-row halo between layers is recomputed, not exchanged)
+        import ctypes
+        ts = [torch.empty(R, H, dtype=torch.bfloat16, device=dev) for _ in range(n)]
+        ss = [torch.empty(R, H, dtype=torch.bfloat16, device=dev) for _ in range(n)]
+        xs = [h0] + [torch.empty(R, H, dtype=torch.bfloat16, device=dev) for _ in range(n - 1)]
+        pad = [None] * (4 - n)
+        args = _lib.fill_args(
+            _lib.WnStackFwdArgs, x0=h0, w_in=[il.pc.fwd for il in wn.in_layers] + pad, b_in=[il.bias for il in wn.in_layers] + pad,
+            w_res=[rs.pc_res.fwd for rs in wn.res_skip_layers[:n - 1]] + [None] + pad,
+            b_res=[rs.bias for rs in wn.res_skip_layers[:n - 1]] + [None] + pad,
+            cond=cond, ldc=0 if cond is None else cond.stride(0), row0=rc.row0 if (cond is not None and not cond_per_row) else None,
+            B=0 if (cond_per_row or cond is None) else rc.B, Tp=rc.Tp, rowmask=rc.rowmask, acts=acts_all, ldacts=acts_all.stride(0),
+            gate_t=ts + pad, gate_s=ss + pad, x_out=xs[1:] + [None] + pad, R=R, H=H, taps=wn.kernel_size, n_layers=n,
+            drop_p=float(p), drop_seed=int(seed), seed_dev=seed_word(dev) if p > 0 else None,
+            stamps=stamps.buf if stamps else None, stamp_slot=stamps.take() if stamps else 0, stamp_base=stamps.base if stamps else None)
+        _ev = KERNEL_TIMER.start("wn_stack_fwd")
+        rcode = L.gt_wn_stack_fwd(ctypes.byref(args), _st(dev))
+        KERNEL_TIMER.stop(_ev)
+        _lib.check(rcode, "gt_wn_stack_fwd")
+        saved = (xs, ts, ss, acts_all, p, seed)
+        if layers_only:
+            return None, saved
+        return conv_rows(acts_all, wn.pc_skipcat, rc, bias=wn.skip_bias, mask=True), saved
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts = acts_all[:, i * H:(i + 1) * H]
@@ -406,6 +430,7 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
 
 
 # ----------------------------------------------------------------------------- fused between-WaveNets kernels
+WN_STACK = True              # all layers of a WaveNet forward in one launch (False: one launch per layer, the path it is tested against)
 BOUNDARY_TRACE = None        # dev (tools/wn_boundary_bench.py): a list collects the (entry name, args struct, keep-alive) of every launch
 
 

@@ -348,6 +348,28 @@ int gt_coupling_rev(const float* out, const float* z, float* x, const float* row
 int gt_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                   float* gnorm_sq, void* stream);
 
+/* ---- A whole WaveNet (all gated layers of modules.WN.forward, modules.py:144-171, without the final skip sum) as ONE kernel
+ * (csrc/wn_stack.hip): a workgroup recomputes the 2-row halo every k = 5 layer needs instead of exchanging it — 64 rows computed
+ * per layer, gt_wn_stack_rows_per_workgroup(n_layers) = 64 - 4 (n_layers - 1) rows owned and stored.  Same arithmetic, dropout
+ * hash and outputs as n_layers calls of gt_wn_layer_fwd (bit-identical).  H = 192, taps = 5, n_layers <= 4; weight images as
+ * for gt_wn_layer_fwd; cond: [B, >= 2H n] per utterance (B > 0, row0 / Tp as elsewhere) or [R, >= 2H n] per row (B == 0),
+ * layer i reads columns [2H i, 2H (i+1)); dropout seed of layer i is drop_seed + i (^ *seed_dev). */
+typedef struct gt_wn_stack_fwd_args {
+  const void* x0;                               /* bf16 [R, H]: the WaveNet's input (masked) */
+  const void* w_in[4]; const float* b_in[4];    /* in_layer images (flags 2 | 4 | 16) and biases [2H] */
+  const void* w_res[4]; const float* b_res[4];  /* residual 1x1 images and biases [H] of layers 0 .. n_layers-2 */
+  const float* cond; int ldc; const int32_t* row0; int B; int Tp;
+  const float* rowmask;
+  void* acts; int ldacts;                       /* out: bf16 [R, >= n_layers * H], layer i in columns [H i, H (i+1)) */
+  void* gate_t[4]; void* gate_s[4];             /* out: bf16 [R, H] per layer (saved tanh / sigmoid halves) */
+  void* x_out[4];                               /* out: x_out[i] = input of layer i+1, bf16 [R, H], i < n_layers-1 */
+  int R, H, taps, n_layers;
+  float drop_p; uint32_t drop_seed; const uint32_t* seed_dev;
+  unsigned long long* stamps; int stamp_slot; const int32_t* stamp_base;   /* as gt_wn_layer_fwd */
+} gt_wn_stack_fwd_args;
+int gt_wn_stack_rows_per_workgroup(int n_layers);
+int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream);
+
 /* ---- Everything between two WaveNets of the flow decoder as ONE kernel (csrc/wn_boundary.hip): all of it is row-local.
  * Shapes: C = 160 flow channels (n_sqz * 80 mels), H = 192, n_layers = 4 (every reference config); 64 rows per workgroup.
  * Weight images: gt_pack_conv_weights(_multi) in MFMA-fragment order (flags 2 | 4), ks_* = padded K / 16 of each image.

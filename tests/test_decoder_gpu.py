@@ -517,3 +517,43 @@ def test_fused_boundary_kernels_match_the_five_kernel_path(built, speaker, sigmo
             worst = (n, e)
         assert e < 2e-2, (n, e)
     print("fused boundary vs five kernels: worst parameter gradient", worst)
+
+
+@pytest.mark.parametrize("mode", ["none", "speaker", "per_row"])
+def test_wn_stack_kernel_is_bit_identical_to_the_per_layer_kernels(built, mode):
+    """csrc/wn_stack.hip (all four layers of a WaveNet in one launch, the 2-row halo between layers recomputed per 52-row tile)
+    against four gt_wn_layer_fwd launches: same arithmetic in the same order and the same dropout hash, so T / S / acts / x_i
+    must be EQUAL on every valid row — ragged rows, utterances of 1 and 2 frames, a row count that is neither a multiple of
+    52 nor of 64, train mode (p = 0.05)."""
+    from glow_tts_amd import flow_impl, modules, ops
+    H, n = 192, 4
+    gin = 256 if mode == "speaker" else 0
+    wn = fill_module(modules.WN(160, H, 5, 1, n, gin, 0.05), "wn.").to(dev())
+    modules.prepare_all(wn)
+    lens = [131, 70, 2, 1, 64, 97]
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev())
+    rc = ops.RowsCtx(lt, 131, lengths_host=lens, round_to=8)
+    assert rc.R % 64 != 0 and rc.R % 52 != 0
+    g = torch.Generator().manual_seed(31)
+    h0 = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    cond = None
+    if mode == "speaker":
+        cond = (torch.randn(rc.B, 2 * H * n, generator=g) * 0.3).to(dev())
+    elif mode == "per_row":
+        cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
+    res = []
+    for stack in (True, False):
+        flow_impl.WN_STACK = stack
+        try:
+            out, (xs, ts, ss, acts_all, p, seed) = flow_impl.wn_fwd(rc, wn, h0, cond, True, 123, cond_per_row=mode == "per_row")
+        finally:
+            flow_impl.WN_STACK = True
+        torch.cuda.synchronize()
+        res.append((out, xs, ts, ss, acts_all))
+    valid = rc.rowmask.bool()
+    (o1, x1, t1, s1, a1), (o2, x2, t2, s2, a2) = res
+    # every row m < R is owned by exactly one tile: acts / T / S are written for masked rows too, as the per-layer kernels do
+    assert torch.equal(a1, a2)
+    for u, v in zip(t1 + s1 + x1, t2 + s2 + x2):
+        assert torch.equal(u, v)
+    assert torch.equal(o1[valid], o2[valid])

@@ -59,6 +59,20 @@ def timeit(name, fn, launches=48, replays=10):
     print(f"{name:44s} {e0.elapsed_time(e1) / (replays * launches) * 1e3:7.1f} us / launch   (R = {R})", flush=True)
 
 
+def stack(wn):
+    flow_impl.wn_fwd(rc, wn, x, None, True, 7, layers_only=True)
+
+
+def layers(wn):
+    flow_impl.WN_STACK = False
+    try:
+        flow_impl.wn_fwd(rc, wn, x, None, True, 7, layers_only=True)
+    finally:
+        flow_impl.WN_STACK = True
+
+
+timeit("WN forward, 4 layers: ONE stack launch", lambda k: stack(wns[k % 12]), launches=24)
+timeit("WN forward, 4 layers: four layer launches", lambda k: layers(wns[k % 12]), launches=24)
 QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 for frac in ((1,) if QUICK else (1, 2, 4, 8)):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
     Rs = R // frac // 64 * 64
