@@ -230,6 +230,240 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
 }
 
+// ------------------------------------------------------------------------------------------------ backward
+// The mirror: the gate backward of the top layer (row-local, from the skip-path gradient), then for j = n-1 .. 0 the k=5 data
+// gradient of in_layer_j on the d pre_j tile -> dX_j (+ the residual-path gradient dX_{j+1}, * mask), and below it the
+// residual 1x1's data gradient + skip-path gradient + gate backward -> d pre_{j-1}.  The first conv reads an exact 68-row
+// tile, each of the other n-1 loses 2 rows per side: the workgroup owns the same 64 - 4 (n-1) rows as the forward.
+//   stage 1: N = 192, K = 5 * 384: 2 (column halves) x 2 (K halves) waves x 64 rows, partial sums exchanged through LDS
+//   stage 2: N = 192, K = 192 on the dX tile: 2 x 2 waves x (32 rows x 96 columns)
+constexpr int DP = 2 * H + 8;                 // d pre tile pitch (halfs): 784 B = 16 mod 128
+constexpr int EX_BYTES = 4 * 3 * 16 * 64 * 4; // partial-sum exchange [4 waves][3 blocks][16][64 lanes] fp32: aliases the d pre tile
+constexpr int BWD_DT = XR * DP * 2;           // 53 312 B
+static_assert(EX_BYTES <= BWD_DT, "the exchange buffer lives in the d pre tile");
+constexpr int SBWD_LDS = BWD_DT + BM * AP * 2;
+
+__device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)[4], const float (&s)[4], uint32_t seed, int m, int n,
+                                          uint32_t thresh, float scale, uint2& pt, uint2& ps, uint2& ct, uint2& cs)
+{
+  float gt[4], gs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { gt[j] = dd[j] * s[j] * (1.0f - t[j] * t[j]); gs[j] = dd[j] * t[j] * s[j] * (1.0f - s[j]); }
+  ct = pack4(gt[0], gt[1], gt[2], gt[3]); cs = pack4(gs[0], gs[1], gs[2], gs[3]);      // before the dropout mask: d cond
+  if (thresh) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gt[j] = drop_keep(seed, m, n + j, thresh) ? gt[j] * scale : 0.0f;
+      gs[j] = drop_keep(seed, m, H + n + j, thresh) ? gs[j] * scale : 0.0f;
+    }
+  }
+  pt = pack4(gt[0], gt[1], gt[2], gt[3]); ps = pack4(gs[0], gs[1], gs[2], gs[3]);
+}
+
+// one step j of the chain (compile-time j: every pointer is a kernel argument, every fragment address is formed where it is used)
+template <int J>
+__device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t drop_thresh, float drop_scale, uint32_t seed_x,
+                                         bf16_t* Dt, float* Ex, bf16_t* At, int s0, int halo, int lane, int wave)
+{
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave & 1, wk = wave >> 1;     // stage 1: column half, K half;  afterwards wk doubles as the row half
+  const int n_layers = a.n_layers, R = a.R;
+  const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
+  constexpr int NS = 2 * H / 64, NIT = NS * TAPS, KS = 2 * H / 16, NBT = H / 32;  // 6 slices, 30 steps, 24 k-steps per tap, 6 blocks
+  const bf16_t* W1 = static_cast<const bf16_t*>(a.w_in_d[J]);
+  f32x16_t acc[3][2];
+#pragma unroll
+  for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+    for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
+  constexpr int RB = 2 * RING - 1;             // half the fragments per step: twice the depth for the same registers
+  uint4 ring[RB][2][3];
+  auto w_load = [&](int it, uint4 (&dst)[2][3]) {
+    const int slice = it / TAPS, tap = it - slice * TAPS;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) dst[k2][bn] = ldfrag(W1, (tap * NBT + 3 * wn + bn) * KS + slice * 4 + 2 * wk + k2, lane);
+  };
+#pragma unroll
+  for (int p = 0; p < RB - 1; ++p) w_load(p, ring[p]);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int slice = it / TAPS, tap = it - slice * TAPS;
+    w_load(it + RB - 1 < NIT ? it + RB - 1 : NIT - 1, ring[(it + RB - 1) % RB]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16_t* xsb = Dt + (r + tap) * DP + 8 * h + slice * 64 + 32 * wk;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + k2 * 16);
+      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * DP + k2 * 16);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) {
+        acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b0, acc[bn][0], 0, 0, 0);
+        acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b1, acc[bn][1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // second-stage weights (the layer below): this wave's 96 columns (wn), rows 32*wk
+  constexpr int JL = J > 0 ? J - 1 : 0;
+  const bf16_t* W2 = static_cast<const bf16_t*>(a.w_res_d[JL]);
+  uint4 ring2[KK2 / 2][3];
+  if (J > 0) {
+#pragma unroll
+    for (int kk = 0; kk < KK2 / 2; ++kk)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk, lane);
+  }
+  __syncthreads();                            // every wave is done with the d pre tile: the exchange buffer may overwrite it
+
+  // K halves meet: a wave keeps row block bm == wk and hands the other one to its partner (same columns, other K half)
+  {
+    float* mine = Ex + wave * (3 * 16 * 64);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mine[(bn * 16 + e) * 64 + lane] = wk ? acc[bn][0][e] : acc[bn][1][e];
+  }
+  __syncthreads();
+  f32x16_t sum[3];
+  {
+    const float* theirs = Ex + (wave ^ 2) * (3 * 16 * 64);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sum[bn][e] = (wk ? acc[bn][1][e] : acc[bn][0][e]) + theirs[(bn * 16 + e) * 64 + lane];
+  }
+  // dX_j = (conv^T(d pre_j) + dX_{j+1}) * mask -> HBM (owned rows) and the stage-2 tile (which still holds dX_{j+1})
+  const int t = 32 * wk + r, m = s0 + t;
+  const bool mine_row = t >= halo && t < BM - halo && m < R;
+  {
+    const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+    bf16_t* dx = static_cast<bf16_t*>(a.dx[J]);
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        float ad[4] = {};
+        if (J < n_layers - 1) unpack4(*reinterpret_cast<const uint2*>(At + t * AP + n), ad);
+        const uint2 v = pack4((sum[bn][4 * g] + ad[0]) * rm, (sum[bn][4 * g + 1] + ad[1]) * rm,
+                              (sum[bn][4 * g + 2] + ad[2]) * rm, (sum[bn][4 * g + 3] + ad[3]) * rm);
+        if (mine_row) *reinterpret_cast<uint2*>(dx + (size_t)m * H + n) = v;
+        *reinterpret_cast<uint2*>(At + t * AP + n) = v;
+      }
+  }
+  if (J == 0) return;                                               // bottom: dX_0 is the gradient at the WaveNet's input
+  __syncthreads();
+
+  // d acts_{j-1} = dX_j W_res + skip-path gradient -> gate backward -> d pre_{j-1}: the next tile (+ HBM for the owned rows)
+  f32x16_t acc2[3];
+#pragma unroll
+  for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
+  {
+    const bf16_t* ab = At + (32 * wk + r) * AP + 8 * h;
+#pragma unroll
+    for (int kk = 0; kk < KK2; ++kk) {
+      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) {
+        acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
+        if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk + KK2 / 2, lane);
+      }
+    }
+  }
+  {
+    const bf16_t* Tt = static_cast<const bf16_t*>(a.gate_t[JL]);
+    const bf16_t* Ss = static_cast<const bf16_t*>(a.gate_s[JL]);
+    bf16_t* dpre = static_cast<bf16_t*>(a.dpre[JL]);
+    bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
+    const uint32_t seed = (a.drop_seed + (uint32_t)JL) ^ seed_x;
+    const bool in = m >= 0 && m < R;
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        uint2 pt = make_uint2(0, 0), ps = pt, ct = pt, cs = pt;
+        if (in) {
+          float vs[4], tt[4], sg[4], dd[4];
+          unpack4(*reinterpret_cast<const uint2*>(via + (size_t)m * a.ldvs + JL * H + n), vs);
+          unpack4(*reinterpret_cast<const uint2*>(Tt + (size_t)m * H + n), tt);
+          unpack4(*reinterpret_cast<const uint2*>(Ss + (size_t)m * H + n), sg);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dd[q] = acc2[bn][4 * g + q] + vs[q];
+          gate_bwd4(dd, tt, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
+          if (mine_row) {
+            *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + n) = pt;
+            *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + H + n) = ps;
+            if (dpre_c) {
+              *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
+              *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
+            }
+          }
+        }
+        *reinterpret_cast<uint2*>(Dt + (t + 2) * DP + n) = pt;
+        *reinterpret_cast<uint2*>(Dt + (t + 2) * DP + H + n) = ps;
+      }
+  }
+  __syncthreads();                                                   // the next conv's input tile is complete
+}
+
+__global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_args a, uint32_t drop_thresh, float drop_scale)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_layers = a.n_layers, R = a.R;
+  const int halo = 2 * (n_layers - 1), own = BM - 2 * halo;
+  const int s0 = blockIdx.x * own - halo;
+  bf16_t* Dt = reinterpret_cast<bf16_t*>(smem);
+  float* Ex = reinterpret_cast<float*>(smem);
+  bf16_t* At = reinterpret_cast<bf16_t*>(smem + BWD_DT);
+  const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
+
+  // top layer: d acts = the skip-path gradient only -> d pre on all 68 rows of the tile (row-local)
+  {
+    const int L = n_layers - 1;
+    const bf16_t* Tt = static_cast<const bf16_t*>(pick(a.gate_t, L));
+    const bf16_t* Ss = static_cast<const bf16_t*>(pick(a.gate_s, L));
+    bf16_t* dpre = static_cast<bf16_t*>(pick(a.dpre, L));
+    bf16_t* dpre_c = static_cast<bf16_t*>(pick(a.dpre_c, L));
+    const uint32_t seed = (a.drop_seed + (uint32_t)L) ^ seed_x;
+    for (int item = threadIdx.x; item < XR * (H / 4); item += 256) {
+      const int u = item / (H / 4), n = 4 * (item - u * (H / 4)), m = s0 - 2 + u;
+      uint2 pt = make_uint2(0, 0), ps = pt, ct = pt, cs = pt;
+      if (m >= 0 && m < R) {
+        float dd[4], t[4], sg[4];
+        unpack4(*reinterpret_cast<const uint2*>(via + (size_t)m * a.ldvs + L * H + n), dd);
+        unpack4(*reinterpret_cast<const uint2*>(Tt + (size_t)m * H + n), t);
+        unpack4(*reinterpret_cast<const uint2*>(Ss + (size_t)m * H + n), sg);
+        gate_bwd4(dd, t, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
+        if (u - 2 >= halo && u - 2 < BM - halo) {
+          *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + n) = pt;
+          *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + H + n) = ps;
+          if (dpre_c) {
+            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
+            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
+          }
+        }
+      }
+      *reinterpret_cast<uint2*>(Dt + u * DP + n) = pt;
+      *reinterpret_cast<uint2*>(Dt + u * DP + H + n) = ps;
+    }
+  }
+  __syncthreads();
+  // the chain, top to bottom (workgroup-uniform branches; each step is its own straight-line code)
+  if (n_layers > 3) bwd_step<3>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
+  if (n_layers > 2) bwd_step<2>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
+  if (n_layers > 1) bwd_step<1>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
+  bwd_step<0>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
+}
+
 inline bool al16(const void* p) { return !((uintptr_t)p & 15); }
 
 }  // namespace
@@ -266,5 +500,37 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
   const int own = BM - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
   hipLaunchKernelGGL(gt_wn_stack_fwd_kernel, grid, block, STACK_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  return gt_launch_status(__func__);
+}
+
+extern "C" int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream)
+{
+  if (!args) return GT_E_INVAL;
+  const gt_wn_stack_bwd_args& a = *args;
+  if (a.R < 0) return GT_E_INVAL;
+  if (a.R == 0) return GT_OK;
+  if (a.H != H || a.taps != TAPS || a.n_layers < 1 || a.n_layers > NLMAX) return GT_E_UNSUPPORTED;
+  if (!a.via_skip || !a.rowmask || a.ldvs < a.n_layers * H || (a.ldvs & 3)) return GT_E_INVAL;
+  if (!al16(a.via_skip)) return GT_E_ALIGN;
+  for (int i = 0; i < a.n_layers; ++i) {
+    if (!a.w_in_d[i] || !a.gate_t[i] || !a.gate_s[i] || !a.dpre[i] || !a.dx[i]) return GT_E_INVAL;
+    if (i < a.n_layers - 1 && !a.w_res_d[i]) return GT_E_INVAL;
+    if (!al16(a.w_in_d[i]) || !al16(a.gate_t[i]) || !al16(a.gate_s[i]) || !al16(a.dpre[i]) || !al16(a.dpre_c[i]) || !al16(a.dx[i]) ||
+        !al16(a.w_res_d[i])) return GT_E_ALIGN;
+  }
+  uint32_t thresh = 0; float scale = 1.0f;
+  if (a.drop_p > 0.0f) {
+    if (a.drop_p >= 1.0f) return GT_E_UNSUPPORTED;
+    thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SBWD_LDS) != hipSuccess)
+      return GT_E_LAUNCH;
+    attr = true;
+  }
+  const int own = BM - 4 * (a.n_layers - 1);
+  const dim3 grid((a.R + own - 1) / own), block(256);
+  hipLaunchKernelGGL(gt_wn_stack_bwd_kernel, grid, block, SBWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }

@@ -369,6 +369,24 @@ typedef struct gt_wn_stack_fwd_args {
 } gt_wn_stack_fwd_args;
 int gt_wn_stack_rows_per_workgroup(int n_layers);
 int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream);
+/* gt_wn_stack_bwd: the data-gradient chain of the same WaveNet in one launch (what n_layers - 1 calls of gt_wn_layer_bwd, the
+ * bottom call without a second stage and gt_gate_bwd for the top layer compute; bit-identical):
+ *   d pre_{n-1} = gate backward of via_skip[:, H (n-1) ..] (the top layer has no residual output);
+ *   for j = n-1 .. 0:  dx[j] = (conv_k5^T(d pre_j; w_in_d[j]) + dx[j+1]) * rowmask;
+ *                      j > 0:  d acts_{j-1} = dx[j] @ W_res_{j-1} (w_res_d[j-1]) + via_skip[:, H (j-1) ..];  d pre_{j-1} = gate backward.
+ * dx[0] is the gradient at the WaveNet's input; dpre_c[i] (optional) = d pre_i before the dropout mask (gradient of the cond
+ * term).  via_skip: bf16 [R, >= n H]; dpre / dpre_c: bf16 [R, 2H]; dx: bf16 [R, H]. */
+typedef struct gt_wn_stack_bwd_args {
+  const void* via_skip; int ldvs;
+  const void* gate_t[4]; const void* gate_s[4];
+  const void* w_in_d[4];                        /* data-gradient images of the in_layers (flag 4) */
+  const void* w_res_d[4];                       /* data-gradient images of the residual 1x1s, layers 0 .. n_layers-2 */
+  const float* rowmask;
+  void* dpre[4]; void* dpre_c[4]; void* dx[4];
+  int R, H, taps, n_layers;
+  float drop_p; uint32_t drop_seed; const uint32_t* seed_dev;
+} gt_wn_stack_bwd_args;
+int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream);
 
 /* ---- Everything between two WaveNets of the flow decoder as ONE kernel (csrc/wn_boundary.hip): all of it is row-local.
  * Shapes: C = 160 flow channels (n_sqz * 80 mels), H = 192, n_layers = 4 (every reference config); 64 rows per workgroup.
