@@ -82,6 +82,7 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gt_wn_stack_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_stack_rows_per_workgroup": (c_int, [c_int]),
+    "gt_wn_stack_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -126,6 +127,14 @@ class WnStackFwdArgs(ctypes.Structure):
                 ("acts", c_void_p), ("ldacts", c_int), ("gate_t", c_void_p * 4), ("gate_s", c_void_p * 4), ("x_out", c_void_p * 4),
                 ("R", c_int), ("H", c_int), ("taps", c_int), ("n_layers", c_int), ("drop_p", c_float), ("drop_seed", c_u32),
                 ("seed_dev", c_void_p), ("stamps", c_void_p), ("stamp_slot", c_int), ("stamp_base", c_void_p)]
+
+
+class WnStackBwdArgs(ctypes.Structure):
+    """struct gt_wn_stack_bwd_args (include/glowtts_hip.h)"""
+    _fields_ = [("via_skip", c_void_p), ("ldvs", c_int), ("gate_t", c_void_p * 4), ("gate_s", c_void_p * 4), ("w_in_d", c_void_p * 4),
+                ("w_res_d", c_void_p * 4), ("rowmask", c_void_p), ("dpre", c_void_p * 4), ("dpre_c", c_void_p * 4), ("dx", c_void_p * 4),
+                ("R", c_int), ("H", c_int), ("taps", c_int), ("n_layers", c_int), ("drop_p", c_float), ("drop_seed", c_u32),
+                ("seed_dev", c_void_p)]
 
 
 class BoundaryFwdArgs(ctypes.Structure):

@@ -256,6 +256,33 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     if dacts_skip is None:
         dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
+    if WN_STACK and n <= 4:
+        # the whole data-gradient chain in ONE launch (csrc/wn_stack.hip), then the weight-gradient jobs on what it wrote
+        import ctypes
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        dpre = [torch.empty(R, 2 * H, **bf) for _ in range(n)]
+        dpre_c = [torch.empty(R, 2 * H, **bf) if need_c else None for _ in range(n)]
+        dxs = [torch.empty(R, H, **bf) for _ in range(n)]                  # dxs[0] = gradient at the WaveNet's input
+        pad = [None] * (4 - n)
+        args = _lib.fill_args(
+            _lib.WnStackBwdArgs, via_skip=dacts_skip, ldvs=dacts_skip.stride(0), gate_t=list(ts) + pad, gate_s=list(ss) + pad,
+            w_in_d=[il.pc.dgrad for il in wn.in_layers] + pad, w_res_d=[rs.pc_res.dgrad for rs in wn.res_skip_layers[:n - 1]] + [None] + pad,
+            rowmask=rc.rowmask, dpre=dpre + pad, dpre_c=dpre_c + pad, dx=dxs + pad, R=R, H=H, taps=wn.kernel_size, n_layers=n,
+            drop_p=float(p), drop_seed=int(seed), seed_dev=seed_word(dev) if p > 0 else None)
+        _ev = KERNEL_TIMER.start("wn_stack_bwd")
+        rcode = L.gt_wn_stack_bwd(ctypes.byref(args), _st(dev))
+        KERNEL_TIMER.stop(_ev)
+        _lib.check(rcode, "gt_wn_stack_bwd")
+        for i in reversed(range(n)):
+            acts = acts_all[:, i * H:(i + 1) * H]
+            if i == n - 1:
+                grads.update(conv_param_grads(wn.res_skip_layers[i], acts, dskip, R))
+            else:
+                grads.update(conv_param_grads(wn.res_skip_layers[i], acts, None, R, parts=[(dxs[i + 1], 0, H), (dskip, H, H)]))
+            grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre[i], R))
+            if want_dcond:
+                _dcond_store(rc, dcond, i, H, dpre_c[i] if need_c else dpre[i], cond_per_row)
+        return dxs[0], grads, dcond
     # top layer: no residual output, d acts = skip path only
     i = n - 1
     dpre = torch.empty(R, 2 * H, dtype=torch.bfloat16, device=dev)

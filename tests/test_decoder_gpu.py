@@ -557,3 +557,44 @@ def test_wn_stack_kernel_is_bit_identical_to_the_per_layer_kernels(built, mode):
     for u, v in zip(t1 + s1 + x1, t2 + s2 + x2):
         assert torch.equal(u, v)
     assert torch.equal(o1[valid], o2[valid])
+
+
+@pytest.mark.parametrize("mode", ["none", "speaker", "per_row"])
+def test_wn_stack_backward_is_bit_identical_to_the_per_layer_kernels(built, mode):
+    """gt_wn_stack_bwd (the WaveNet's whole data-gradient chain in one launch, halo recomputed) against gt_gate_bwd + three
+    gt_wn_layer_bwd + the bottom data gradient: d h0, the conditioning gradient and every parameter gradient EQUAL (the batched
+    weight-gradient kernels read the d pre / dX rows both paths wrote), dropout replayed, ragged rows."""
+    from glow_tts_amd import flow_impl, modules, ops, wgrad
+    H, n = 192, 4
+    gin = 256 if mode == "speaker" else 0
+    wn = fill_module(modules.WN(160, H, 5, 1, n, gin, 0.05), "wn.").to(dev())
+    modules.prepare_all(wn)
+    lens = [131, 70, 2, 1, 64, 97]
+    lt = torch.tensor(lens, dtype=torch.int32, device=dev())
+    rc = ops.RowsCtx(lt, 131, lengths_host=lens, round_to=8)
+    g = torch.Generator().manual_seed(32)
+    h0 = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    dskip = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    cond = None
+    if mode == "speaker":
+        cond = (torch.randn(rc.B, 2 * H * n, generator=g) * 0.3).to(dev())
+    elif mode == "per_row":
+        cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
+    res = []
+    for stack in (True, False):
+        flow_impl.WN_STACK = stack
+        try:
+            out, saved = flow_impl.wn_fwd(rc, wn, h0, cond, True, 55, cond_per_row=mode == "per_row")
+            with wgrad.WgradQueue(dev(), site=wn):
+                dh0, grads, dcond = flow_impl.wn_bwd(rc, wn, saved, dskip, want_dcond=cond is not None, cond_per_row=mode == "per_row")
+        finally:
+            flow_impl.WN_STACK = True
+        torch.cuda.synchronize()
+        res.append((dh0.clone(), None if dcond is None else dcond.clone(), {id(k): v.clone() for k, v in grads.items()}))
+    (d1, c1, g1), (d2, c2, g2) = res
+    assert torch.equal(d1, d2)
+    if c1 is not None:
+        assert torch.equal(c1, c2)
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        assert torch.equal(g1[k], g2[k])
