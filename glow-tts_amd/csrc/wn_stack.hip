@@ -23,6 +23,9 @@ constexpr int H = 192, TAPS = 5, NLMAX = 4;
 constexpr int BM = 64;                        // rows computed per layer
 constexpr int AP = H + 8;                     // LDS pitch (halfs): 400 B = 16 mod 128 -> conflict-free ds_read_b128
 constexpr int XR = BM + TAPS - 1;             // 68 input rows
+#ifndef WNS_PIN_STEP
+#define WNS_PIN_STEP 1
+#endif
 #ifndef WNS_RING
 #define WNS_RING 3
 #endif
@@ -30,9 +33,14 @@ constexpr int RING = WNS_RING;
 constexpr int KK2 = H / 16;
 constexpr int STACK_LDS = (2 * XR + BM) * AP * 2;                       // Xa, Xb [68][200] + At [64][200] = 80 000 B
 
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// through an explicit GLOBAL pointer: a pointer that went through `pinned` is generic to the compiler, and flat loads count on
+// lgkmcnt as well as vmcnt — every LDS wait would then drain the weight prefetch
 __device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
 {
-  return *reinterpret_cast<const uint4*>(W + ((size_t)f * 64 + lane) * 8);
+  typedef const u32x4_t __attribute__((address_space(1)))* gptr_t;
+  const u32x4_t v = *reinterpret_cast<gptr_t>(reinterpret_cast<uintptr_t>(W + ((size_t)f * 64 + lane) * 8));
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ bf16x8_t asfrag(const uint4& u) { return __builtin_bit_cast(bf16x8_t, u); }
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) { return make_uint2(pack2bf(a, b), pack2bf(c, d)); }
@@ -60,173 +68,27 @@ __device__ __forceinline__ T pick(T const (&arr)[NLMAX], int i)        // scalar
   return i == 0 ? arr[0] : (i == 1 ? arr[1] : (i == 2 ? arr[2] : arr[3]));
 }
 
-// one layer (compile-time L: pointers are kernel arguments, fragment addresses are formed where they are used)
-template <int L>
-__device__ __forceinline__ void fwd_layer(const gt_wn_stack_fwd_args& a, uint32_t drop_thresh, float drop_scale, uint32_t seed_x,
-                                          bf16_t* Xc, bf16_t* Xn, bf16_t* At, int s0, int halo, int lane)
-{
-  constexpr int KS = H / 16, NBT = 2 * H / 32, NIT = 3 * TAPS;       // 12 k-steps per tap, 12 column blocks, 15 steps of 4 k-steps
-  const int r = lane & 31, h = lane >> 5;
-  const int R = a.R;
-  const bool last = L == a.n_layers - 1;
-  const bf16_t* W1 = pinned(static_cast<const bf16_t*>(a.w_in[L]));
-  const bf16_t* W2 = pinned(static_cast<const bf16_t*>(a.w_res[L]));
-  const float* bias1 = a.b_in[L];
-  const float* bias2 = a.b_res[L];
-  bf16_t* Tt = static_cast<bf16_t*>(a.gate_t[L]);
-  bf16_t* Ss = static_cast<bf16_t*>(a.gate_s[L]);
-  bf16_t* xo = static_cast<bf16_t*>(a.x_out[L]);
-  const uint32_t seed = (a.drop_seed + (uint32_t)L) ^ seed_x;
-  const int wave = wave_scalar();
-
-  f32x16_t acc[3][2];
-#pragma unroll
-  for (int bn = 0; bn < 3; ++bn)
-#pragma unroll
-    for (int bm = 0; bm < 2; ++bm)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
-
-  uint4 ring[RING][4][3];
-  auto w_load = [&](int it, uint4 (&dst)[4][3]) {
-    const int kg = it / TAPS, tap = it - kg * TAPS;
-    // the step's base pointer is pinned too: its 12 scalar fragment addresses are then formed here, not all 180 at the layer's top
-    const bf16_t* Wt = pinned(W1 + (size_t)((tap * NBT + 3 * wave) * KS + kg * 4) * 512);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = ldfrag(Wt, bn * KS + ks, lane);
-  };
-#pragma unroll
-  for (int p = 0; p < RING - 1; ++p) w_load(p, ring[p]);
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int kg = it / TAPS, tap = it - kg * TAPS;
-    w_load(it + RING - 1 < NIT ? it + RING - 1 : NIT - 1, ring[(it + RING - 1) % RING]);
-    __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RING - 1 steps ahead
-    const bf16_t* xsb = Xc + (r + tap) * AP + 8 * h + kg * 64;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16);
-      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * AP + ks * 16);
-#pragma unroll
-      for (int bn = 0; bn < 3; ++bn) {
-        acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
-        acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  // second-stage weights start flying now, under the gate epilogue
-  const int wn2 = wave & 1, wm2 = wave >> 1;
-  uint4 ring2[KK2 / 2][3];
-  if (!last) {
-#pragma unroll
-    for (int kk = 0; kk < KK2 / 2; ++kk)
-#pragma unroll
-      for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk, lane);
-  }
-
-  // gate epilogue in registers (see wn_layer.hip): block 3*wave + bn holds [16 tanh | 16 sigmoid] of channels 16*(3*wave+bn)..+15
-  bf16_t* acts = static_cast<bf16_t*>(a.acts) + L * H;
-  const float* cond = a.cond ? a.cond + (size_t)L * 2 * H : nullptr;
-#pragma unroll
-  for (int bn = 0; bn < 3; ++bn)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const int c = 16 * (3 * wave + bn) + 8 * g + 4 * h;
-      const float4 bt = *reinterpret_cast<const float4*>(bias1 + c), bs = *reinterpret_cast<const float4*>(bias1 + H + c);
-      const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
-#pragma unroll
-      for (int bm = 0; bm < 2; ++bm) {
-        const int t = 32 * bm + r, m = s0 + t;
-        const int mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
-        float ctv[4] = {}, csv[4] = {};
-        if (cond) {
-          const float* cp = cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc) * a.ldc + c;
-          const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
-          ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
-        }
-        float tt[4], ss[4], aa[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
-          if (drop_thresh) {                                         // x_in = drop(conv(x)) (modules.py:153)
-            vt = drop_keep(seed, m, c + j, drop_thresh) ? vt * drop_scale : 0.0f;
-            vs = drop_keep(seed, m, H + c + j, drop_thresh) ? vs * drop_scale : 0.0f;
-          }
-          vt += ctv[j]; vs += csv[j];
-          tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
-        }
-        const uint2 pa = pack4(aa[0], aa[1], aa[2], aa[3]);
-        if (t >= halo && t < BM - halo && m < R) {                   // the rows this workgroup owns
-          *reinterpret_cast<uint2*>(Tt + (size_t)m * H + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
-          *reinterpret_cast<uint2*>(Ss + (size_t)m * H + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
-          *reinterpret_cast<uint2*>(acts + (size_t)m * a.ldacts + c) = pa;
-        }
-        if (!last) *reinterpret_cast<uint2*>(At + t * AP + c) = pa;
-      }
-    }
-  if (last) return;
-  __syncthreads();                                                   // At complete
-
-  // stage 2: x_next = (x + acts @ W_res^T + b_res) * mask -> the next layer's LDS tile (+ HBM for the owned rows)
-  f32x16_t acc2[3];
-#pragma unroll
-  for (int bn = 0; bn < 3; ++bn)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
-  {
-    const bf16_t* ab = At + (32 * wm2 + r) * AP + 8 * h;
-#pragma unroll
-    for (int kk = 0; kk < KK2; ++kk) {
-      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
-#pragma unroll
-      for (int bn = 0; bn < 3; ++bn) {
-        acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
-        if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk + KK2 / 2, lane);
-      }
-    }
-  }
-  {
-    const int t = 32 * wm2 + r, m = s0 + t;
-    const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
-    const bool mine = t >= halo && t < BM - halo && m < R;
-#pragma unroll
-    for (int bn = 0; bn < 3; ++bn)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = 32 * (3 * wn2 + bn) + 8 * g + 4 * h;
-        const float4 b2 = *reinterpret_cast<const float4*>(bias2 + n);
-        float xv[4];
-        unpack4(*reinterpret_cast<const uint2*>(Xc + (t + 2) * AP + n), xv);
-        const uint2 v = pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
-                              (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
-        *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
-        if (mine) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
-      }
-  }
-  __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
-}
-
+// The forward keeps a RUNTIME layer loop: the compiler then forms the layer's 180 fragment offsets once (hoisted out of the loop,
+// parked in the accumulation registers the MFMAs do not use) — measured 8 % faster than the straight-line, scalar-addressed form
+// the backward kernel needs (its register budget has no room for them).
 __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_args a, uint32_t drop_thresh, float drop_scale)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.stamps && threadIdx.x == 0)
     atomicMin(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)), (unsigned long long)wall_clock64());
   const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
   const int n_layers = a.n_layers, R = a.R;
   const int halo = 2 * (n_layers - 1);                               // rows lost per side: 6 for 4 layers
   const int own = BM - 2 * halo;                                     // rows this workgroup owns: 52
   const int s0 = blockIdx.x * own - halo;                            // global row of tile row 0
-  bf16_t* Xa = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* Xb = Xa + XR * AP;
-  bf16_t* At = Xb + XR * AP;
+  bf16_t* Xc = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* Xn = Xc + XR * AP;
+  bf16_t* At = Xn + XR * AP;
+  constexpr int KS = H / 16, NBT = 2 * H / 32, NIT = 3 * TAPS;       // 12 k-steps per tap, 12 column blocks, 15 steps of 4 k-steps
 
-  // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero); the other tile's rows 0, 1, 66, 67
-  // are never produced by a layer: zero both tiles' edge rows once (stage 2 writes rows 2 .. 65 only)
+  // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero)
   {
     const bf16_t* x0 = static_cast<const bf16_t*>(a.x0);
 #pragma unroll
@@ -235,21 +97,160 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       if (u < XR) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (gm >= 0 && gm < R) v = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
-        *reinterpret_cast<uint4*>(Xa + u * AP + c8 * 8) = v;
+        *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = v;
       }
     }
-    if (threadIdx.x < 4 * 24) {
+    if (threadIdx.x < 4 * 24) {                                       // the next tile's rows 0, 1, 66, 67 are never produced
       const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
-      *reinterpret_cast<uint4*>(Xb + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
     }
   }
   __syncthreads();
-  // layer after layer (workgroup-uniform branches; each layer is its own straight-line code); tiles ping-pong.  After layer 1
-  // tile A's edge rows hold layer 0's input rows: finite values that only feed rows outside the owned range.
-  fwd_layer<0>(a, drop_thresh, drop_scale, seed_x, Xa, Xb, At, s0, halo, lane);
-  if (n_layers > 1) fwd_layer<1>(a, drop_thresh, drop_scale, seed_x, Xb, Xa, At, s0, halo, lane);
-  if (n_layers > 2) fwd_layer<2>(a, drop_thresh, drop_scale, seed_x, Xa, Xb, At, s0, halo, lane);
-  if (n_layers > 3) fwd_layer<3>(a, drop_thresh, drop_scale, seed_x, Xb, Xa, At, s0, halo, lane);
+
+  for (int layer = 0; layer < n_layers; ++layer) {
+    const bool last = layer == n_layers - 1;
+    const bf16_t* W1 = static_cast<const bf16_t*>(pick(a.w_in, layer));
+    const bf16_t* W2 = static_cast<const bf16_t*>(pick(a.w_res, layer));
+    const float* bias1 = pick(a.b_in, layer);
+    const float* bias2 = pick(a.b_res, layer);
+    bf16_t* Tt = static_cast<bf16_t*>(pick(a.gate_t, layer));
+    bf16_t* Ss = static_cast<bf16_t*>(pick(a.gate_s, layer));
+    bf16_t* xo = static_cast<bf16_t*>(pick(a.x_out, layer));
+    const uint32_t seed = (a.drop_seed + (uint32_t)layer) ^ seed_x;
+
+    f32x16_t acc[3][2];
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int bm = 0; bm < 2; ++bm)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
+
+    uint4 ring[RING][4][3];
+    auto w_load = [&](int it, uint4 (&dst)[4][3]) {
+      const int kg = it / TAPS, tap = it - kg * TAPS;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = ldfrag(W1, (tap * NBT + 3 * wave + bn) * KS + kg * 4 + ks, lane);
+    };
+#pragma unroll
+    for (int p = 0; p < RING - 1; ++p) w_load(p, ring[p]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int kg = it / TAPS, tap = it - kg * TAPS;
+      w_load(it + RING - 1 < NIT ? it + RING - 1 : NIT - 1, ring[(it + RING - 1) % RING]);
+      __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RING - 1 steps ahead
+      const bf16_t* xsb = Xc + (r + tap) * AP + 8 * h + kg * 64;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16);
+        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * AP + ks * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
+          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // second-stage weights start flying now, under the gate epilogue
+    const int wn2 = wave & 1, wm2 = wave >> 1;
+    uint4 ring2[KK2 / 2][3];
+    if (!last) {
+#pragma unroll
+      for (int kk = 0; kk < KK2 / 2; ++kk)
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk, lane);
+    }
+
+    // gate epilogue in registers (see wn_layer.hip): block 3*wave + bn holds [16 tanh | 16 sigmoid] of channels 16*(3*wave+bn)..+15
+    bf16_t* acts = static_cast<bf16_t*>(a.acts) + layer * H;
+    const float* cond = a.cond ? a.cond + (size_t)layer * 2 * H : nullptr;
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int c = 16 * (3 * wave + bn) + 8 * g + 4 * h;
+        const float4 bt = *reinterpret_cast<const float4*>(bias1 + c), bs = *reinterpret_cast<const float4*>(bias1 + H + c);
+        const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int bm = 0; bm < 2; ++bm) {
+          const int t = 32 * bm + r, m = s0 + t;
+          const int mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
+          float ctv[4] = {}, csv[4] = {};
+          if (cond) {
+            const float* cp = cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc) * a.ldc + c;
+            const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
+            ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
+          }
+          float tt[4], ss[4], aa[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
+            if (drop_thresh) {                                         // x_in = drop(conv(x)) (modules.py:153)
+              vt = drop_keep(seed, m, c + j, drop_thresh) ? vt * drop_scale : 0.0f;
+              vs = drop_keep(seed, m, H + c + j, drop_thresh) ? vs * drop_scale : 0.0f;
+            }
+            vt += ctv[j]; vs += csv[j];
+            tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
+          }
+          const uint2 pa = pack4(aa[0], aa[1], aa[2], aa[3]);
+          if (t >= halo && t < BM - halo && m < R) {                   // the rows this workgroup owns
+            *reinterpret_cast<uint2*>(Tt + (size_t)m * H + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
+            *reinterpret_cast<uint2*>(Ss + (size_t)m * H + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
+            *reinterpret_cast<uint2*>(acts + (size_t)m * a.ldacts + c) = pa;
+          }
+          if (!last) *reinterpret_cast<uint2*>(At + t * AP + c) = pa;
+        }
+      }
+    if (last) break;
+    __syncthreads();                                                   // At complete
+
+    // stage 2: x_next = (x + acts @ W_res^T + b_res) * mask -> the next layer's LDS tile (+ HBM for the owned rows)
+    f32x16_t acc2[3];
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
+    {
+      const bf16_t* ab = At + (32 * wm2 + r) * AP + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < KK2; ++kk) {
+        const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) {
+          acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
+          if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk + KK2 / 2, lane);
+        }
+      }
+    }
+    {
+      const int t = 32 * wm2 + r, m = s0 + t;
+      const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+      const bool mine = t >= halo && t < BM - halo && m < R;
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = 32 * (3 * wn2 + bn) + 8 * g + 4 * h;
+          const float4 b2 = *reinterpret_cast<const float4*>(bias2 + n);
+          float xv[4];
+          unpack4(*reinterpret_cast<const uint2*>(Xc + (t + 2) * AP + n), xv);
+          const uint2 v = pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
+                                (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
+          *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
+          if (mine) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
+        }
+    }
+    __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
+    bf16_t* tmp = Xc; Xc = Xn; Xn = tmp;
+    if (threadIdx.x < 4 * 24) {                                        // rows 0, 1, 66, 67 of the tile after next
+      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
+      *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
+    }
+  }
   if (a.stamps && threadIdx.x == 0)
     atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
 }

@@ -256,7 +256,7 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     if dacts_skip is None:
         dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
-    if WN_STACK and n <= 4:
+    if WN_STACK and WN_STACK_BWD and n <= 4:
         # the whole data-gradient chain in ONE launch (csrc/wn_stack.hip), then the weight-gradient jobs on what it wrote
         import ctypes
         bf = dict(dtype=torch.bfloat16, device=dev)
@@ -457,7 +457,9 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
 
 
 # ----------------------------------------------------------------------------- fused between-WaveNets kernels
-WN_STACK = True              # all layers of a WaveNet forward in one launch (False: one launch per layer, the path it is tested against)
+import os as _os
+WN_STACK_BWD = _os.environ.get('GT_WN_STACK_BWD', '1') != '0'   # dev
+WN_STACK = _os.environ.get('GT_WN_STACK', '1') != '0'              # all layers of a WaveNet forward in one launch (False: one launch per layer, the path it is tested against)
 BOUNDARY_TRACE = None        # dev (tools/wn_boundary_bench.py): a list collects the (entry name, args struct, keep-alive) of every launch
 
 

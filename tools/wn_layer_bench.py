@@ -71,6 +71,29 @@ def layers(wn):
         flow_impl.WN_STACK = True
 
 
+from glow_tts_amd import wgrad
+_saved = {}
+dsk = (torch.randn(R, H, device=dev) * rc.rowmask[:, None] * 0.1).to(torch.bfloat16)
+via_all = (torch.randn(R, n * H, device=dev) * rc.rowmask[:, None] * 0.1).to(torch.bfloat16)
+
+
+def bwd_wn(wn, stack_on):
+    if id(wn) not in _saved:
+        _saved[id(wn)] = flow_impl.wn_fwd(rc, wn, x, None, True, 7, layers_only=True)[1]
+    flow_impl.WN_STACK = stack_on
+    try:
+        q = wgrad.WgradQueue(dev, site=wn)
+        q.__enter__()
+        flow_impl.wn_bwd(rc, wn, _saved[id(wn)], dsk, dacts_skip=via_all)
+        wgrad._ACTIVE.pop(); q.items = []                      # data-gradient chain only: drop the recorded weight-gradient jobs
+    finally:
+        flow_impl.WN_STACK = True
+
+
+for w in wns:
+    bwd_wn(w, True)
+timeit("WN backward chain: ONE stack launch", lambda k: bwd_wn(wns[k % 12], True), launches=24)
+timeit("WN backward chain: gate_bwd + 4 layer launches", lambda k: bwd_wn(wns[k % 12], False), launches=24)
 timeit("WN forward, 4 layers: ONE stack launch", lambda k: stack(wns[k % 12]), launches=24)
 timeit("WN forward, 4 layers: four layer launches", lambda k: layers(wns[k % 12]), launches=24)
 QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
