@@ -325,7 +325,7 @@ def main():
             nl = model.decoder.n_layers
             rows_valid = (valid_total / args.steps) / 2.0                                 # squeezed frames
             from glow_tts_amd import flow_impl
-            if flow_impl.WN_STACK and model.decoder.flows[2].wn.fused:
+            if flow_impl.WN_STACK and model.decoder.flows[2].wn.fused and bool((d[:, model.decoder.n_blocks:] <= 1).all()):
                 # one launch per WaveNet (csrc/wn_stack.hip): the first n_blocks slots of a step are written, the rest stay empty
                 used = d[:, :model.decoder.n_blocks]
                 us = used.mean().item() / 100.0                                           # wall_clock64: 100 MHz
@@ -333,6 +333,7 @@ def main():
                 name = (f"gt_wn_stack_fwd_kernel (a whole WaveNet forward in one launch: {nl} x (k=5 conv 192->384 + gate) + {nl - 1} x "
                         f"residual 1x1, halo recomputed per 52-row tile; {used.shape[1]} launches per step)")
                 extra, n_l = {}, used.numel()
+                pmc_name = "r02_wn_stack_pmc.json"
             else:
                 res_mask = torch.tensor([(k % nl) != nl - 1 for k in range(d.shape[1])])  # the layers that carry the residual 1x1
                 us = d[:, res_mask].mean().item() / 100.0
@@ -340,6 +341,7 @@ def main():
                 name = ("gt_wn_layer_fwd_kernel<true> (WaveNet layer: k=5 conv 192->384 + gate + residual 1x1, one launch; "
                         f"{int(res_mask.sum())} launches per step)")
                 extra, n_l = {"launch_us_last_layer_variant": d[:, ~res_mask].mean().item() / 100.0}, int(res_mask.sum()) * args.steps
+                pmc_name = "r02_wn_layer_pmc.json"
             tf = flops_launch / (us * 1e-6) / 1e12
             roof.update({"achieved": tf, "frac": tf / MFMA_BF16_PEAK_TFLOPS, "kernel": name,
                          "algorithmic_flops_per_launch": flops_launch, "launch_us": us, **extra,
@@ -347,7 +349,7 @@ def main():
                                 "replayed HIP graphs of the timed steps: max(end) - min(start) per launch, mean over "
                                 f"{n_l} launches; FLOPs count the VALID squeezed frames only (the recomputed halo rows are not counted)",
                          "profile": "profiles/r02_trainstep_*_summary.txt (rocprofv3 --kernel-trace --stats of the same command)"})
-            pmc = os.path.join(ROOT, "profiles", "r02_wn_layer_pmc.json")
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     pj = json.load(f)

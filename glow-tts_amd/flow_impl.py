@@ -138,6 +138,24 @@ def _fused_ok(wn):
     return True
 
 
+_CUS = {}
+
+
+def _stack_pays(R, n, dev):
+    """One launch per WaveNet (csrc/wn_stack.hip) owns 64 - 4 (n - 1) rows per workgroup where the per-layer kernels own 64: more
+    workgroups for the same rows.  That is free while they fit the CUs at once (cfg 2: 188 instead of 152 of 256) and loses when it
+    costs an extra round of workgroups (cfg 3's longest batches: 268 instead of 218)."""
+    if not WN_STACK:
+        return False
+    key = str(dev)
+    if key not in _CUS:
+        _CUS[key] = torch.cuda.get_device_properties(dev).multi_processor_count
+    cus = _CUS[key]
+    own = 64 - 4 * (n - 1)
+    rounds = lambda rows: -(-(-(-R // rows)) // cus)
+    return rounds(own) <= rounds(64)
+
+
 def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
     it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
@@ -156,7 +174,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
     x = h0
     fused = _fused_ok(wn)
     stamps = getattr(rc, "stamps", None)              # bench.py: live in-graph timing of the dominant kernel (ops.KernelStamps)
-    if fused and WN_STACK and n <= 4:
+    if fused and n <= 4 and _stack_pays(R, n, dev):
         # all layers in ONE launch (csrc/wn_stack.hip: the 2-row halo between layers is recomputed, not exchanged)
         import ctypes
         ts = [torch.empty(R, H, dtype=torch.bfloat16, device=dev) for _ in range(n)]
@@ -256,7 +274,7 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     if dacts_skip is None:
         dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
-    if WN_STACK and WN_STACK_BWD and n <= 4:
+    if WN_STACK_BWD and n <= 4 and _stack_pays(R, n, dev):
         # the whole data-gradient chain in ONE launch (csrc/wn_stack.hip), then the weight-gradient jobs on what it wrote
         import ctypes
         bf = dict(dtype=torch.bfloat16, device=dev)
