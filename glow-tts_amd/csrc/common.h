@@ -28,6 +28,16 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t row, uint32_t 
   return hash_u32(seed + row * 0x9E3779B1U + col * 0x85EBCA6BU) >= thresh;
 }
 
+// The WaveNet gate drops the tanh half and the sigmoid half of a channel independently (modules.py:153 drops all 2H conv
+// outputs).  ONE hash per (row, gate channel) decides both — low 16 bits for the tanh half, high 16 bits for the sigmoid half,
+// each against p * 2^16 (p = 0.05 -> 0.0500031): half the integer multiplies (v_mul_lo_u32 is a quarter-rate instruction, and
+// the two hashes per gate element were ~10 % of the fused WaveNet kernels) in every kernel that applies or replays that mask.
+__device__ __forceinline__ uint32_t drop_thresh16(uint32_t thresh) { return (thresh + 0x8000u) >> 16; }
+__device__ __forceinline__ void drop_keep_gate(uint32_t seed, uint32_t row, uint32_t chan, uint32_t thresh16, bool& keep_t, bool& keep_s) {
+  const uint32_t hsh = hash_u32(seed + row * 0x9E3779B1U + chan * 0x85EBCA6BU);
+  keep_t = (hsh & 0xffffu) >= thresh16; keep_s = (hsh >> 16) >= thresh16;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

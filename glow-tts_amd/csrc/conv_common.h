@@ -65,8 +65,10 @@ __device__ __forceinline__ void epilogue_gate(const ConvArgs& a, const float* es
     for (int i = 0; i < 8; ++i) {
       float pt = pt_[i], ps = ps_[i];
       if (a.drop_thresh) {                                         // x_in = drop(conv(x))
-        pt = drop_keep(a.drop_seed, m, cg + i, a.drop_thresh) ? pt * a.drop_scale : 0.0f;
-        ps = drop_keep(a.drop_seed, m, half + cg + i, a.drop_thresh) ? ps * a.drop_scale : 0.0f;
+        bool kt, ks;
+        drop_keep_gate(a.drop_seed, m, cg + i, drop_thresh16(a.drop_thresh), kt, ks);
+        pt = kt ? pt * a.drop_scale : 0.0f;
+        ps = ks ? ps * a.drop_scale : 0.0f;
       }
       pt += ct_[i]; ps += cs_[i];
       tt[i] = tanhf_(pt); ss[i] = sigmoidf_(ps); aa[i] = tt[i] * ss[i];
@@ -166,8 +168,10 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, const float* e
         const float t = bf2f((tw[i >> 1] >> (16 * (i & 1))) & 0xffff), sg = bf2f((sw[i >> 1] >> (16 * (i & 1))) & 0xffff);
         gt[i] = v[i] * sg * (1.0f - t * t); gs[i] = v[i] * t * sg * (1.0f - sg);
         if (a.gb_thresh) {
-          gt[i] = drop_keep(a.drop_seed, m, n + i, a.gb_thresh) ? gt[i] * a.drop_scale : 0.0f;
-          gs[i] = drop_keep(a.drop_seed, m, a.N + n + i, a.gb_thresh) ? gs[i] * a.drop_scale : 0.0f;
+          bool kt, ks;
+          drop_keep_gate(a.drop_seed, m, n + i, drop_thresh16(a.gb_thresh), kt, ks);
+          gt[i] = kt ? gt[i] * a.drop_scale : 0.0f;
+          gs[i] = ks ? gs[i] * a.drop_scale : 0.0f;
         }
       }
       bf16_t* yp = static_cast<bf16_t*>(a.Y) + (size_t)m * a.ldy + n;

@@ -356,8 +356,10 @@ __global__ __launch_bounds__(256) void gt_gate_bwd_kernel(const bf16_t* __restri
   if (drop_thresh) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      gt[i] = drop_keep(drop_seed, m, c + i, drop_thresh) ? gt[i] * drop_scale : 0.0f;
-      gs[i] = drop_keep(drop_seed, m, half + c + i, drop_thresh) ? gs[i] * drop_scale : 0.0f;
+      bool kt, ks;
+      drop_keep_gate(drop_seed, m, c + i, drop_thresh16(drop_thresh), kt, ks);
+      gt[i] = kt ? gt[i] * drop_scale : 0.0f;
+      gs[i] = ks ? gs[i] * drop_scale : 0.0f;
     }
   }
   *reinterpret_cast<uint2*>(dpre + (size_t)m * ldp + c) = make_uint2(pack2bf(gt[0], gt[1]), pack2bf(gt[2], gt[3]));

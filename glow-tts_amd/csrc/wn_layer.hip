@@ -239,8 +239,10 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
           for (int j = 0; j < 4; ++j) {
             float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
             if (a.drop_thresh) {                                       // x_in = drop(conv(x)) (modules.py:153)
-              vt = drop_keep(a.drop_seed, m, c + j, a.drop_thresh) ? vt * a.drop_scale : 0.0f;
-              vs = drop_keep(a.drop_seed, m, H + c + j, a.drop_thresh) ? vs * a.drop_scale : 0.0f;
+              bool kt, ks;
+              drop_keep_gate(a.drop_seed, m, c + j, drop_thresh16(a.drop_thresh), kt, ks);
+              vt = kt ? vt * a.drop_scale : 0.0f;
+              vs = ks ? vs * a.drop_scale : 0.0f;
             }
             vt += ctv[j]; vs += csv[j];
 #ifdef WN_EXP_NOEPI
@@ -421,8 +423,10 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
         if (a.drop_thresh) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            gt[j] = drop_keep(a.drop_seed, m, n + j, a.drop_thresh) ? gt[j] * a.drop_scale : 0.0f;
-            gs[j] = drop_keep(a.drop_seed, m, H + n + j, a.drop_thresh) ? gs[j] * a.drop_scale : 0.0f;
+            bool kt, ks;
+            drop_keep_gate(a.drop_seed, m, n + j, drop_thresh16(a.drop_thresh), kt, ks);
+            gt[j] = kt ? gt[j] * a.drop_scale : 0.0f;
+            gs[j] = ks ? gs[j] * a.drop_scale : 0.0f;
           }
         }
         bf16_t* yp = a.dpre + (size_t)m * a.lddp + n;

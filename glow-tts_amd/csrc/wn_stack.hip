@@ -26,6 +26,9 @@ constexpr int XR = BM + TAPS - 1;             // 68 input rows
 #ifndef WNS_PIN_STEP
 #define WNS_PIN_STEP 1
 #endif
+#ifndef WNS_EXP
+#define WNS_EXP 0                             // dev experiments (bit mask), 0 in every build that ships
+#endif
 #ifndef WNS_RING
 #define WNS_RING 3
 #endif
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 
     uint4 ring[RING][4][3];
     auto w_load = [&](int it, uint4 (&dst)[4][3]) {
+      if ((WNS_EXP & 2) && it > RING) return;
       const int kg = it / TAPS, tap = it - kg * TAPS;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -189,15 +193,17 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
-            if (drop_thresh) {                                         // x_in = drop(conv(x)) (modules.py:153)
-              vt = drop_keep(seed, m, c + j, drop_thresh) ? vt * drop_scale : 0.0f;
-              vs = drop_keep(seed, m, H + c + j, drop_thresh) ? vs * drop_scale : 0.0f;
+            if (drop_thresh && !(WNS_EXP & 4)) {                       // x_in = drop(conv(x)) (modules.py:153)
+              bool kt, ks;
+              drop_keep_gate(seed, m, c + j, drop_thresh16(drop_thresh), kt, ks);
+              vt = kt ? vt * drop_scale : 0.0f;
+              vs = ks ? vs * drop_scale : 0.0f;
             }
             vt += ctv[j]; vs += csv[j];
-            tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
+            if (WNS_EXP & 4) { tt[j] = vt; ss[j] = vs; aa[j] = vt + vs; } else { tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j]; }
           }
           const uint2 pa = pack4(aa[0], aa[1], aa[2], aa[3]);
-          if (t >= halo && t < BM - halo && m < R) {                   // the rows this workgroup owns
+          if (t >= halo && t < BM - halo && m < R && !(WNS_EXP & 1)) {    // the rows this workgroup owns
             *reinterpret_cast<uint2*>(Tt + (size_t)m * H + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
             *reinterpret_cast<uint2*>(Ss + (size_t)m * H + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
             *reinterpret_cast<uint2*>(acts + (size_t)m * a.ldacts + c) = pa;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
           const uint2 v = pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
                                 (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
           *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
-          if (mine) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
+          if (mine && !(WNS_EXP & 1)) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
         }
     }
     __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
@@ -278,8 +284,10 @@ __device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)
   if (thresh) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      gt[j] = drop_keep(seed, m, n + j, thresh) ? gt[j] * scale : 0.0f;
-      gs[j] = drop_keep(seed, m, H + n + j, thresh) ? gs[j] * scale : 0.0f;
+      bool kt, ks;
+      drop_keep_gate(seed, m, n + j, drop_thresh16(thresh), kt, ks);
+      gt[j] = kt ? gt[j] * scale : 0.0f;
+      gs[j] = ks ? gs[j] * scale : 0.0f;
     }
   }
   pt = pack4(gt[0], gt[1], gt[2], gt[3]); ps = pack4(gs[0], gs[1], gs[2], gs[3]);

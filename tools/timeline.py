@@ -7,7 +7,7 @@ db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
 packs = [i for i, r in enumerate(rows) if "gt_pack_conv_weights_multi" in r[0]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else len(packs) // 2
+k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else len(packs) // 2
 i0, i1 = packs[k], packs[k + 1]                     # default: a step in the middle of the run (the replayed ones)
 step = rows[i0:i1]
 t0, t1 = step[0][1], max(r[2] for r in step)
@@ -56,3 +56,8 @@ for sid, lst in sorted(by_stream.items(), key=lambda kv: -len(kv[1])):
         a = agg.setdefault(r[0][:70], [0, 0]); a[0] += 1; a[1] += r[2] - r[1]
     for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
         print(f"      {tot / 1e6:7.3f} ms {cnt:4d} x {tot / cnt / 1e3:7.1f} us  {name}")
+
+if "--list" in sys.argv:                               # chronological listing of the step: start (us from the step's start), duration, name
+    for r in sorted(step, key=lambda r: r[1]):
+        nm = r[0].replace("(anonymous namespace)::", "").replace("void ", "").replace("at::native::", "")
+        print(f"{(r[1] - t0) / 1e3:9.1f} {(r[2] - r[1]) / 1e3:7.1f}  q{r[3]}  {nm[:90]}")
