@@ -539,17 +539,35 @@ __global__ __launch_bounds__(256) void gt_prior_expand_kernel(const float* __res
   const int t = tok[(size_t)b * Ty + j];
   zm[idx] = t >= 0 ? xm[(size_t)bc * Tx + t] : 0.f;
 }
-// backward of the gather: dxm[b,c,i] = sum_{j in [start_i, start_{i+1})} dzm[b,c,j]  (segments, no atomics)
-__global__ __launch_bounds__(256) void gt_prior_expand_bwd_kernel(const float* __restrict__ dzm, const int32_t* __restrict__ starts,
-                                                                  float* __restrict__ dxm, int B, int C, int Tx, int Ty, int Txs)
+// backward of the gather: dxm[b,c,i] = sum of dzm[b,c,j] over the frames j aligned to token i.  One wave per (b, c) row walks
+// the frames 64 at a time (coalesced), sums each run of equal tokens with a segmented wave scan (the MAS path is monotone: runs
+// are contiguous) and the run's last lane adds it to the row's token accumulator in LDS — fixed order, no atomics.  (The first
+// form — a thread per (b, c, token) looping over its frames — took 74 us on the step's critical path: autograd runs it before the
+// decoder's backward.)
+__global__ __launch_bounds__(256) void gt_prior_expand_bwd_kernel(const float* __restrict__ dzm, const int32_t* __restrict__ f2t,
+                                                                  float* __restrict__ dxm, int B, int C, int Tx, int Ty)
 {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= B * C * Tx) return;
-  const int i = idx % Tx, bc = idx / Tx, b = bc / C;
-  const int s0 = starts[(size_t)b * (Txs + 1) + i], s1 = starts[(size_t)b * (Txs + 1) + i + 1];
-  float a = 0.f;
-  for (int j = s0; j < s1; ++j) a += dzm[(size_t)bc * Ty + j];
-  dxm[idx] = a;
+  __shared__ float acc[4][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bc = blockIdx.x * 4 + wave;
+  if (bc >= B * C) return;                                  // waves are independent: no workgroup barrier below
+  const int b = bc / C;
+  float* a = acc[wave];
+  for (int i = lane; i < Tx; i += 64) a[i] = 0.f;
+  for (int j0 = 0; j0 < Ty; j0 += 64) {
+    const int j = j0 + lane;
+    int t = -1; float v = 0.f;
+    if (j < Ty) { t = f2t[(size_t)b * Ty + j]; v = dzm[(size_t)bc * Ty + j]; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float vv = __shfl_up(v, off);
+      const int tt = __shfl_up(t, off);
+      if (lane >= off && tt == t) v += vv;
+    }
+    const int tn = __shfl_down(t, 1);
+    if (t >= 0 && t < Tx && (lane == 63 || tn != t)) a[t] += v;   // a run that crosses the chunk boundary continues in the next chunk
+  }
+  for (int i = lane; i < Tx; i += 64) dxm[(size_t)bc * Tx + i] = a[i];
 }
 // mle loss partial sums (commons.py:28-33): acc[0] += sum(logs*?) ... computed over [B,C,T] tensors:
 //   acc[0] += sum logs,  acc[1] += sum exp(-2 logs) (z-m)^2   (logs may be NULL = 0)
@@ -593,6 +611,62 @@ __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict
     if (dz) dz[i] = v;
     if (dm) dm[i] = -v;
     if (dlogs) dlogs[i] = g * (1.0f - e * d * d);
+  }
+}
+
+// mle_loss's scalar tail (commons.py:31-33) in one launch: out[0] = loss = (acc[0] + 0.5 acc[1] - sum logdet) / denom + 0.5 log 2pi,
+// out[1] = denom = C * sum(mask)  (= sum(ones_like(z) * mask))
+__global__ __launch_bounds__(256) void gt_mle_finish_kernel(const float* __restrict__ acc, const float* __restrict__ logdet,
+                                                            const float* __restrict__ mask, int n_mask, int B, int C, float* __restrict__ out)
+{
+  __shared__ float red[2][4];
+  float sl = 0.f, sn = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) sl += logdet[b];
+  for (int i = threadIdx.x; i < n_mask; i += 256) sn += mask[i];
+  sl = wave_sum(sl); sn = wave_sum(sn);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sn; }
+  __syncthreads();
+  sl = red[0][0] + red[0][1] + red[0][2] + red[0][3]; sn = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (threadIdx.x == 0) {
+    const float denom = sn * (float)C;
+    out[0] = (acc[0] + 0.5f * acc[1] - sl) / denom + 0.91893853320467274f;
+    out[1] = denom;
+  }
+}
+
+// duration loss of the deterministic predictor (models.py:1089-1092): l[b] = sum_t (logw[b,t] - log(w[b,t] + 1e-8) mask)^2 / sum(mask)
+// One wave per utterance; backward: d logw[b,t] = g[b] * 2 (logw - logw_) / sum(mask) on valid tokens (w comes from MAS: no gradient).
+__global__ void gt_duration_loss_fwd_kernel(const float* __restrict__ logw, const float* __restrict__ w, const int32_t* __restrict__ len,
+                                            int B, int Tx, float* __restrict__ out)
+{
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float tot = 0.f;
+  for (int i = lane; i < B; i += 64) tot += (float)len[i];
+  tot = wave_sum(tot);
+  float a = 0.f;
+  const int n = len[b];
+  for (int t = lane; t < Tx; t += 64) {
+    const float lw = logw[(size_t)b * Tx + t];
+    const float ref = t < n ? __logf(w[(size_t)b * Tx + t] + 1e-8f) : 0.f;
+    const float d = lw - ref;
+    a += d * d;
+  }
+  a = wave_sum(a);
+  if (lane == 0) out[b] = a / tot;
+}
+__global__ void gt_duration_loss_bwd_kernel(const float* __restrict__ logw, const float* __restrict__ w, const int32_t* __restrict__ len,
+                                            const float* __restrict__ g, int B, int Tx, float* __restrict__ dlogw)
+{
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float tot = 0.f;
+  for (int i = lane; i < B; i += 64) tot += (float)len[i];
+  tot = wave_sum(tot);
+  const int n = len[b];
+  const float gb = 2.0f * g[b] / tot;
+  for (int t = lane; t < Tx; t += 64) {
+    const float lw = logw[(size_t)b * Tx + t];
+    const float ref = t < n ? __logf(w[(size_t)b * Tx + t] + 1e-8f) : 0.f;
+    dlogw[(size_t)b * Tx + t] = gb * (lw - ref);
   }
 }
 
@@ -791,10 +865,11 @@ extern "C" int gt_prior_expand(const float* x_m, const int32_t* frame2token, flo
   hipLaunchKernelGGL(gt_prior_expand_kernel, dim3(((size_t)B * C * Ty + 255) / 256), dim3(256), 0, GT_ST(stream), x_m, frame2token, z_m, B, C, Tx, Ty);
   GT_RET();
 }
-extern "C" int gt_prior_expand_bwd(const float* dz_m, const int32_t* starts, float* dx_m, int B, int C, int Tx, int Ty, void* stream)
+extern "C" int gt_prior_expand_bwd(const float* dz_m, const int32_t* frame2token, float* dx_m, int B, int C, int Tx, int Ty, void* stream)
 {
-  if (!dz_m || !starts || !dx_m || B <= 0 || C <= 0 || Tx <= 0 || Ty <= 0) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_prior_expand_bwd_kernel, dim3(((size_t)B * C * Tx + 255) / 256), dim3(256), 0, GT_ST(stream), dz_m, starts, dx_m, B, C, Tx, Ty, Tx);
+  if (!dz_m || !frame2token || !dx_m || B <= 0 || C <= 0 || Tx <= 0 || Ty <= 0) return GT_E_INVAL;
+  if (Tx > 512) return GT_E_UNSUPPORTED;                      // the MAS kernel's own limit
+  hipLaunchKernelGGL(gt_prior_expand_bwd_kernel, dim3(((size_t)B * C + 3) / 4), dim3(256), 0, GT_ST(stream), dz_m, frame2token, dx_m, B, C, Tx, Ty);
   GT_RET();
 }
 extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream)
@@ -804,6 +879,25 @@ extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, fl
   if (((uintptr_t)z | (uintptr_t)m | (uintptr_t)logs) & 15) return GT_E_ALIGN;
   size_t blocks = (n / 4 + 255) / 256; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gt_mle_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, acc2, n);
+  GT_RET();
+}
+extern "C" int gt_mle_finish(const float* acc2, const float* logdet, const float* mask, int n_mask, int B, int C, float* out2, void* stream)
+{
+  if (!acc2 || !logdet || !mask || !out2 || B <= 0 || C <= 0 || n_mask <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_mle_finish_kernel, dim3(1), dim3(256), 0, GT_ST(stream), acc2, logdet, mask, n_mask, B, C, out2);
+  GT_RET();
+}
+extern "C" int gt_duration_loss_fwd(const float* logw, const float* w, const int32_t* x_lengths, int B, int Tx, float* l_length, void* stream)
+{
+  if (!logw || !w || !x_lengths || !l_length || B <= 0 || Tx <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_duration_loss_fwd_kernel, dim3(B), dim3(64), 0, GT_ST(stream), logw, w, x_lengths, B, Tx, l_length);
+  GT_RET();
+}
+extern "C" int gt_duration_loss_bwd(const float* logw, const float* w, const int32_t* x_lengths, const float* g, int B, int Tx,
+                                    float* dlogw, void* stream)
+{
+  if (!logw || !w || !x_lengths || !g || !dlogw || B <= 0 || Tx <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_duration_loss_bwd_kernel, dim3(B), dim3(64), 0, GT_ST(stream), logw, w, x_lengths, g, B, Tx, dlogw);
   GT_RET();
 }
 extern "C" int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,

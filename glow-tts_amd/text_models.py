@@ -282,7 +282,7 @@ class _PriorExpandFn(torch.autograd.Function):
         xm = x_m.detach().float().contiguous()
         z_m = torch.empty(B, C, Ty, dtype=torch.float32, device=x_m.device)
         _lib.check(L.gt_prior_expand(_lib.ptr(xm), _lib.ptr(f2t), _lib.ptr(z_m), B, C, Tx, Ty, _lib.current_stream(x_m.device)), "gt_prior_expand")
-        ctx.starts, ctx.shape = starts, (B, C, Tx, Ty)
+        ctx.f2t, ctx.shape = f2t, (B, C, Tx, Ty)
         return z_m
 
     @staticmethod
@@ -291,7 +291,7 @@ class _PriorExpandFn(torch.autograd.Function):
         B, C, Tx, Ty = ctx.shape
         d = dz_m.float().contiguous()
         dx_m = torch.empty(B, C, Tx, dtype=torch.float32, device=d.device)
-        _lib.check(L.gt_prior_expand_bwd(_lib.ptr(d), _lib.ptr(ctx.starts), _lib.ptr(dx_m), B, C, Tx, Ty, _lib.current_stream(d.device)),
+        _lib.check(L.gt_prior_expand_bwd(_lib.ptr(d), _lib.ptr(ctx.f2t), _lib.ptr(dx_m), B, C, Tx, Ty, _lib.current_stream(d.device)),
                    "gt_prior_expand_bwd")
         return dx_m, None, None
 
@@ -307,17 +307,21 @@ class _MleLossFn(torch.autograd.Function):
         lc = None if logs is None else logs.detach().float().contiguous()
         acc = ops.zeros_small(2, torch.float32, dev)
         _lib.check(L.gt_mle_sums(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(acc), zc.numel(), _lib.current_stream(dev)), "gt_mle_sums")
-        denom = (mask.sum() * z.shape[1]).to(torch.float32)                 # sum(ones_like(z) * mask)
-        loss = (acc[0] + 0.5 * acc[1] - logdet.sum()) / denom + 0.5 * math.log(2 * math.pi)
-        ctx.saved = (zc, mc, lc, denom, logdet.shape)
-        return loss
+        # the scalar tail in one launch: loss = (acc[0] + 0.5 acc[1] - sum logdet) / denom + 0.5 log 2pi, denom = C * sum(mask)
+        ld = logdet.detach().float().contiguous()
+        mk = mask.detach().float().contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        _lib.check(L.gt_mle_finish(_lib.ptr(acc), _lib.ptr(ld), _lib.ptr(mk), mk.numel(), ld.numel(), z.shape[1], _lib.ptr(out),
+                                   _lib.current_stream(dev)), "gt_mle_finish")
+        ctx.saved = (zc, mc, lc, out, logdet.shape)
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
         L = _lib.lib()
-        zc, mc, lc, denom, ld_shape = ctx.saved
+        zc, mc, lc, out, ld_shape = ctx.saved
         dev = zc.device
-        gs = (g.float() / denom).reshape(1).contiguous()
+        gs = (g.float() / out[1]).reshape(1).contiguous()
         dz = torch.empty_like(zc)
         dm = torch.empty_like(mc)
         dl = None if lc is None else torch.empty_like(lc)
@@ -325,6 +329,35 @@ class _MleLossFn(torch.autograd.Function):
                                 zc.numel(), _lib.current_stream(dev)), "gt_mle_bwd")
         dlogdet = (-gs).expand(ld_shape).contiguous()
         return dz, dm, dl, dlogdet, None
+
+
+class _DurationLossFn(torch.autograd.Function):
+    """models.py:1089-1092: l_length[b] = sum_t (logw - log(w + 1e-8) * x_mask)^2 / sum(x_mask) in one launch (w: MAS durations,
+    no gradient); backward one more."""
+
+    @staticmethod
+    def forward(ctx, logw, w, x_lengths):
+        L = _lib.lib()
+        B, _, Tx = logw.shape
+        lw = logw.detach().float().contiguous()
+        wc = w.detach().float().contiguous()
+        xl = x_lengths.to(torch.int32).contiguous()
+        out = torch.empty(B, dtype=torch.float32, device=lw.device)
+        _lib.check(L.gt_duration_loss_fwd(_lib.ptr(lw), _lib.ptr(wc), _lib.ptr(xl), B, Tx, _lib.ptr(out), _lib.current_stream(lw.device)),
+                   "gt_duration_loss_fwd")
+        ctx.saved = (lw, wc, xl, logw.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        lw, wc, xl, shape = ctx.saved
+        B, _, Tx = shape
+        gc = g.float().contiguous()
+        d = torch.empty(shape, dtype=torch.float32, device=lw.device)
+        _lib.check(L.gt_duration_loss_bwd(_lib.ptr(lw), _lib.ptr(wc), _lib.ptr(xl), _lib.ptr(gc), B, Tx, _lib.ptr(d), _lib.current_stream(lw.device)),
+                   "gt_duration_loss_bwd")
+        return d, None, None
 
 
 def mle_loss(z, m, logs, logdet, mask):
@@ -634,7 +667,7 @@ class FlowGenerator(nn.Module):
                 if t_ is not None:
                     t_.record_stream(enc_stream)
         with (torch.cuda.stream(enc_stream) if pfork else contextlib.nullcontext()):
-            l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, z_mask, g, l, logw, noise, mas, y_lengths,
+            l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths,
                                                                        y_max_length, pitch_norm, energy_norm)
         if pfork:
             main.wait_stream(enc_stream)
@@ -646,7 +679,7 @@ class FlowGenerator(nn.Module):
         self.last_logp = logp
         return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, l_pitch, l_energy), (None, None, None, None), None
 
-    def _predictor_losses(self, rcx, xb, w, x_mask, z_mask, g, l, logw, noise, mas, y_lengths, y_max_length, pitch_norm, energy_norm):
+    def _predictor_losses(self, rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths, y_max_length, pitch_norm, energy_norm):
         """l_length, l_pitch, l_energy of models.py:1086-1115 (+ logw of the deterministic duration predictor)."""
         if self.use_sdp:                                                       # models.py:1086-1088
             pw = self.encoder.proj_w
@@ -654,10 +687,9 @@ class FlowGenerator(nn.Module):
             nw = None if noise is None else rcx.to_rows(noise[0].float())
             l_length = pw.nll_rows(rcx, xb, w_rows, pw.cond_vec(g, l), nw) / torch.sum(x_mask)
         else:                                                                  # models.py:1089-1092
-            logw_ = torch.log(w + 1e-8) * x_mask
             if logw is None:
                 logw = self._predict_logw(g, l)
-            l_length = torch.sum((logw - logw_) ** 2, [1, 2]) / torch.sum(x_mask)
+            l_length = _DurationLossFn.apply(logw, w, x_lengths)
         l_pitch = l_energy = None
         if self.use_spp or self.use_sep:                                       # models.py:1094-1115
             rcf = ops.make_ctx(y_lengths.to(torch.int32), y_max_length, "f", cfg=self.rows_cfg)

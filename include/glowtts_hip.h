@@ -320,16 +320,24 @@ int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* rowmask, fl
  * z: [B,C,Ty] -> logp [B,Tx,Ty] fp32. */
 int gt_logp_f32(const float* x_m, const float* x_logs, const float* z, float* logp, int B, int C, int Tx, int Ty, void* stream);
 
-/* Prior expansion models.py:1118-1119 as a gather by frame2token (from gt_mas_f32) and its backward as
- * a segment sum over the MAS row intervals (`starts` = gt_mas_f32 workspace, [B, Tx+1]). */
+/* Prior expansion models.py:1118-1119 as a gather by frame2token (from gt_mas_f32; -1 = padded frame) and its backward as
+ * the segment sums over the frames of every token (deterministic: fixed summation order; Tx <= 512). */
 int gt_prior_expand(const float* x_m, const int32_t* frame2token, float* z_m, int B, int C, int Tx, int Ty, void* stream);
-int gt_prior_expand_bwd(const float* dz_m, const int32_t* starts, float* dx_m, int B, int C, int Tx, int Ty, void* stream);
+int gt_prior_expand_bwd(const float* dz_m, const int32_t* frame2token, float* dx_m, int B, int C, int Tx, int Ty, void* stream);
 
 /* mle_loss pieces (commons.py:28-33): acc2[0] += sum(logs), acc2[1] += sum(exp(-2 logs)(z-m)^2);
  * backward: dz = g e^{-2 logs}(z-m), dm = -dz, dlogs = g (1 - e^{-2 logs}(z-m)^2), g = *gscale. */
 int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream);
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
                size_t n, void* stream);
+
+/* mle_loss's scalar tail (commons.py:31-33) in one launch: out2[0] = (acc2[0] + 0.5 acc2[1] - sum logdet) / denom + 0.5 log(2 pi),
+ * out2[1] = denom = C * sum(mask) (acc2 from gt_mle_sums; mask: the n_mask floats of z_mask [B, 1, T]). */
+int gt_mle_finish(const float* acc2, const float* logdet, const float* mask, int n_mask, int B, int C, float* out2, void* stream);
+/* Duration loss of the deterministic predictor (models.py:1089-1092): l_length[b] = sum_t (logw[b,t] - log(w[b,t] + 1e-8) * mask)^2
+ * / sum(mask), logw / w fp32 [B, Tx] (w = MAS durations), mask from x_lengths; backward: dlogw = g[b] * 2 (logw - logw_) / sum(mask). */
+int gt_duration_loss_fwd(const float* logw, const float* w, const int32_t* x_lengths, int B, int Tx, float* l_length, void* stream);
+int gt_duration_loss_bwd(const float* logw, const float* w, const int32_t* x_lengths, const float* g, int B, int Tx, float* dlogw, void* stream);
 
 /* Reverse (inference) direction of the flows — models.py:765-785 with reverse=True.
  *   gt_actnorm_invconv_rev: x = ((W^-1 y) * mask - bias) * exp(-logs) * mask  (InvConvNear^-1 then ActNorm^-1,
