@@ -598,3 +598,35 @@ def test_wn_stack_backward_is_bit_identical_to_the_per_layer_kernels(built, mode
     assert g1.keys() == g2.keys()
     for k in g1:
         assert torch.equal(g1[k], g2[k])
+
+
+@pytest.mark.parametrize("n,lens", [(2, [3]), (3, [40, 1, 2]), (1, [70, 5]), (4, [2])])
+def test_wn_stack_kernels_other_depths_and_tiny_batches(built, n, lens):
+    """gt_wn_stack_fwd / _bwd with 1..4 layers (the rows a workgroup owns: 64 - 4 (n - 1)) and row counts below one tile:
+    equal to the per-layer kernels, forward and backward."""
+    from glow_tts_amd import flow_impl, modules, ops, wgrad
+    H = 192
+    wn = fill_module(modules.WN(160, H, 5, 1, n, 0, 0.05), "wn.").to(dev())
+    modules.prepare_all(wn)
+    T = max(lens)
+    rc = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev()), T, lengths_host=lens, round_to=8)
+    g = torch.Generator().manual_seed(7)
+    h0 = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    dskip = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
+    res = []
+    for stack in (True, False):
+        flow_impl.WN_STACK = stack
+        try:
+            out, saved = flow_impl.wn_fwd(rc, wn, h0, None, True, 9)
+            with wgrad.WgradQueue(dev(), site=wn):
+                dh0, grads, _ = flow_impl.wn_bwd(rc, wn, saved, dskip)
+        finally:
+            flow_impl.WN_STACK = True
+        torch.cuda.synchronize()
+        res.append((saved[3].clone(), [t.clone() for t in saved[1] + saved[2] + saved[0]], dh0.clone(), {id(k): v.clone() for k, v in grads.items()}))
+    (a1, l1, d1, g1), (a2, l2, d2, g2) = res
+    assert torch.equal(a1, a2) and torch.equal(d1, d2)
+    for u, v in zip(l1, l2):
+        assert torch.equal(u, v)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k])
