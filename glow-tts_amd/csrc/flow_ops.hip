@@ -415,6 +415,58 @@ __global__ __launch_bounds__(256) void gt_actnorm_ddi_finish_kernel(const double
   }
 }
 
+
+// ------------------------------------------------------------------ [B, C, T] <-> rows at the public boundary
+// One launch instead of the index arithmetic + gather + mask + cast chain of ~8 host-side tensor ops per conversion: a 64-row x
+// 64-channel tile goes through LDS so that both sides are coalesced (frames are contiguous in [B, C, T], channels in rows).
+__device__ __forceinline__ float ld_any(const void* p, size_t i, int f32) { return f32 ? static_cast<const float*>(p)[i] : bf2f(static_cast<const bf16_t*>(p)[i]); }
+__device__ __forceinline__ void st_any(void* p, size_t i, int f32, float v) { if (f32) static_cast<float*>(p)[i] = v; else static_cast<bf16_t*>(p)[i] = f2bf(v); }
+
+// rows[m, c] = x[b(m), c, t(m)] for frame rows (0 <= t < T), 0 for halo / rounding rows
+__global__ __launch_bounds__(256) void gt_rows_from_bct_kernel(const void* __restrict__ x, int x_f32, void* __restrict__ rows, int rows_f32,
+                                                               const int32_t* __restrict__ row0, int B, int C, int T, int Tp, int R)
+{
+  __shared__ float tile[64][65];
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lr = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int m = m0 + lr;
+  int b = 0, t = -1;
+  if (m < R) { b = gt_row_batch(row0, B, m, Tp); t = m - gt_row_base(row0, b, Tp) - 2; }
+  const bool in = t >= 0 && t < T;
+#pragma unroll 4
+  for (int cc = q; cc < 64; cc += 4) {
+    const int c = c0 + cc;
+    tile[cc][lr] = (in && c < C) ? ld_any(x, ((size_t)b * C + c) * T + t, x_f32) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int rr = q; rr < 64; rr += 4) {
+    const int mm = m0 + rr, c = c0 + lr;
+    if (mm < R && c < C) st_any(rows, (size_t)mm * C + c, rows_f32, tile[lr][rr]);
+  }
+}
+// x[b, c, t] = rows[base(b) + 2 + t, c] for t < len[b], 0 beyond
+__global__ __launch_bounds__(256) void gt_bct_from_rows_kernel(const void* __restrict__ rows, int rows_f32, void* __restrict__ x, int x_f32,
+                                                               const int32_t* __restrict__ len, const int32_t* __restrict__ row0,
+                                                               int B, int C, int T, int Tp, int R)
+{
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int lr = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n = min(len[b], T), base = gt_row_base(row0, b, Tp) + 2;
+#pragma unroll 4
+  for (int rr = q; rr < 64; rr += 4) {
+    const int t = t0 + rr, c = c0 + lr, m = base + t;
+    tile[rr][lr] = (t < n && c < C && m < R) ? ld_any(rows, (size_t)m * C + c, rows_f32) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int cc = q; cc < 64; cc += 4) {
+    const int c = c0 + cc, t = t0 + lr;
+    if (c < C && t < T) st_any(x, ((size_t)b * C + c) * T + t, x_f32, tile[lr][cc]);
+  }
+}
+
 }  // namespace
 
 #define GT_ST(s) static_cast<hipStream_t>(s)
@@ -546,5 +598,22 @@ extern "C" int gt_actnorm_ddi(const float* x, const int32_t* len, int B, int R, 
   const int rpb = 64;
   hipLaunchKernelGGL(gt_actnorm_ddi_stats_kernel, dim3((R + rpb - 1) / rpb), dim3(256), 0, GT_ST(stream), x, R, C, rpb, workspace);
   hipLaunchKernelGGL(gt_actnorm_ddi_finish_kernel, dim3(1), dim3(256), 0, GT_ST(stream), workspace, len, B, C, logs, bias);
+  GT_RET();
+}
+
+extern "C" int gt_rows_from_bct(const void* x, int x_f32, void* rows, int rows_f32, const int32_t* row0, int B, int C, int T, int Tp, int R,
+                                void* stream)
+{
+  if (!x || !rows || B <= 0 || C <= 0 || T <= 0 || Tp <= 0 || R <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_rows_from_bct_kernel, dim3((R + 63) / 64, (C + 63) / 64), dim3(256), 0, GT_ST(stream), x, x_f32, rows, rows_f32, row0,
+                     B, C, T, Tp, R);
+  GT_RET();
+}
+extern "C" int gt_bct_from_rows(const void* rows, int rows_f32, void* x, int x_f32, const int32_t* lengths, const int32_t* row0,
+                                int B, int C, int T, int Tp, int R, void* stream)
+{
+  if (!x || !rows || !lengths || B <= 0 || C <= 0 || T <= 0 || Tp <= 0 || R <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_bct_from_rows_kernel, dim3((T + 63) / 64, (C + 63) / 64, B), dim3(256), 0, GT_ST(stream), rows, rows_f32, x, x_f32,
+                     lengths, row0, B, C, T, Tp, R);
   GT_RET();
 }

@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from .flow_impl import _st, conv_param_grads
 from .ops import conv_rows, grad_accumulator, seed_word, zeros_small
+from .ops import zeros_big as ops_zeros_big
 
 LN_EPS = 1e-4
 
@@ -65,7 +66,7 @@ def mha_fwd(rc, att, xb, p, seed):
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     # the attention kernel writes frame rows only: halo rows must be finite zeros (they meet zero
     # gradients in the wgrad GEMM, and 0 * NaN garbage would poison it)
-    o = torch.zeros(R, C, dtype=torch.bfloat16, device=dev)
+    o = ops_zeros_big((R, C), torch.bfloat16, dev)
     P = torch.empty(rc.B, H, rc.T, rc.T, dtype=torch.float32, device=dev)
     Ek = att.emb_rel_k.detach().reshape(-1, D).contiguous()
     Ev = att.emb_rel_v.detach().reshape(-1, D).contiguous()
@@ -88,7 +89,7 @@ def mha_bwd(rc, att, saved, dy, grads):
     do = conv_rows(dy, att.conv_o.pc, rc, dgrad=True)
     # dq | dk | dv side by side (one K = 3C data-gradient GEMM below); halo / padded rows are never written by the
     # kernel: zero the buffer once
-    dqkv = torch.zeros(R, 3 * C, dtype=torch.bfloat16, device=dev)
+    dqkv = ops_zeros_big((R, 3 * C), torch.bfloat16, dev)
     dq, dk, dv = dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:]
     from .flow_impl import _scratch
     ws_bytes = L.gt_attn_bwd_workspace_bytes(rc.B, rc.T, H)

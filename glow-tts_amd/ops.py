@@ -128,6 +128,42 @@ def arena_end(device):
     a = _ARENA.get(str(device))
     if a is not None:
         a["on"] = False
+    b = _BIG.get(str(device))
+    if b is not None:
+        b["on"] = False
+
+
+# A second, larger pre-zeroed region for the per-layer buffers that kernels only partly write (attention outputs and their
+# gradients: halo rows must read as zero): ONE fill per training step instead of one per buffer (18 launches at cfg 2).
+_BIG = {}
+BIG_BYTES = 96 << 20
+
+
+def big_begin(device):
+    key = str(device)
+    b = _BIG.get(key)
+    if b is None:
+        b = {"buf": torch.zeros(BIG_BYTES, dtype=torch.uint8, device=device), "off": 0, "on": True, "used": 0}
+        _BIG[key] = b
+    else:
+        n = min(BIG_BYTES, (b["used"] + 4095) & ~4095) if b["used"] else BIG_BYTES
+        b["buf"][:n].zero_()                          # only what the previous step dirtied
+    b["off"], b["on"] = 0, True
+
+
+def zeros_big(shape, dtype, device):
+    """Zeroed tensor: a slice of the step's pre-zeroed region inside a Trainer step, torch.zeros otherwise."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    b = _BIG.get(str(device))
+    nbytes = (n * torch.empty(0, dtype=dtype).element_size() + 255) & ~255
+    if b is None or not b["on"] or b["off"] + nbytes > BIG_BYTES:
+        return torch.zeros(shape, dtype=dtype, device=device)
+    off = b["off"]
+    b["off"] = off + nbytes
+    b["used"] = max(b["used"], b["off"])
+    return b["buf"][off:off + nbytes].view(dtype)[:n].view(shape)
 
 
 def zeros_small(shape, dtype, device):
@@ -297,28 +333,46 @@ class RowsCtx:
         return (torch.arange(self.T, device=self.device)[None, :] < self.lengths[:, None]).to(torch.float32)
 
     def to_rows(self, x, dtype=None):
-        """[B, C, T] -> [R, C] (test/boundary helper; zero halos and padding)."""
+        """[B, C, T] -> [R, C] (zero halos and padding rows; frames past an utterance's length are copied as they are — callers
+        mask) — one launch (gt_rows_from_bct) for fp32 / bf16 tensors."""
         B, C, T = x.shape
         assert B == self.B and T == self.T
+        dtype = dtype or x.dtype
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and dtype in (torch.float32, torch.bfloat16):
+            xc = x.contiguous()
+            out = torch.empty(self.R, C, device=x.device, dtype=dtype)
+            _lib.check(_lib.lib().gt_rows_from_bct(_lib.ptr(xc), int(xc.dtype == torch.float32), _lib.ptr(out), int(dtype == torch.float32),
+                                                   _lib.ptr(self.row0) if self.ragged else None, B, C, T, self.Tp, self.R,
+                                                   _lib.current_stream(x.device)), "gt_rows_from_bct")
+            return out
         if not self.ragged:
-            out = torch.zeros(self.B, self.Tp, C, device=x.device, dtype=dtype or x.dtype)
+            out = torch.zeros(self.B, self.Tp, C, device=x.device, dtype=dtype)
             out[:, HALO:HALO + T] = x.transpose(1, 2).to(out.dtype)
             return out.reshape(self.R, C)
-        xt = x.transpose(1, 2).to(dtype or x.dtype)                                  # [B, T, C]
+        xt = x.transpose(1, 2).to(dtype)                                             # [B, T, C]
         inside = (self.rowframe >= 0) & (self.rowframe < T)
         idx = self.rowbatch.long() * T + self.rowframe.clamp(0, T - 1).long()
         return (xt.reshape(B * T, C)[idx] * inside[:, None].to(xt.dtype)).contiguous()
 
     def from_rows(self, xr, dtype=None):
-        """[R, C] -> [B, C, T] (frames that have no row — past an utterance's length — come back as zero)."""
+        """[R, C] -> [B, C, T] (frames that have no row — past an utterance's length — come back as zero) — one launch
+        (gt_bct_from_rows) for fp32 / bf16 rows."""
         C = xr.shape[1]
+        dtype = dtype or xr.dtype
+        if xr.is_cuda and xr.dtype in (torch.float32, torch.bfloat16) and dtype in (torch.float32, torch.bfloat16) and self.ragged:
+            rows = xr.contiguous()
+            out = torch.empty(self.B, C, self.T, device=xr.device, dtype=dtype)
+            _lib.check(_lib.lib().gt_bct_from_rows(_lib.ptr(rows), int(rows.dtype == torch.float32), _lib.ptr(out), int(dtype == torch.float32),
+                                                   _lib.ptr(self.lengths), _lib.ptr(self.row0), self.B, C, self.T, self.Tp, self.R,
+                                                   _lib.current_stream(xr.device)), "gt_bct_from_rows")
+            return out
         if not self.ragged:
             x = xr.reshape(self.B, self.Tp, C)[:, HALO:HALO + self.T].transpose(1, 2)
-            return x.to(dtype or xr.dtype).contiguous()
+            return x.to(dtype).contiguous()
         t = torch.arange(self.T, device=self.device)
         rows = (self.row0[:-1].long()[:, None] + HALO + t[None, :]).clamp_(max=self.R - 1)   # [B, T]
         out = xr[rows.reshape(-1)].reshape(self.B, self.T, C) * self.mask_bt()[:, :, None].to(xr.dtype)
-        return out.transpose(1, 2).to(dtype or xr.dtype).contiguous()
+        return out.transpose(1, 2).to(dtype).contiguous()
 
 
 def make_ctx(lengths, T, which, div=1, cfg=None):

@@ -373,6 +373,7 @@ class Trainer:
             self.stamps.begin_step()
         ops.bump_seed(device)
         ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
+        ops.big_begin(device)                    # ... and one for the partly written per-layer buffers (attention)
         self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None

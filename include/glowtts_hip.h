@@ -339,6 +339,13 @@ int gt_mle_finish(const float* acc2, const float* logdet, const float* mask, int
 int gt_duration_loss_fwd(const float* logw, const float* w, const int32_t* x_lengths, int B, int Tx, float* l_length, void* stream);
 int gt_duration_loss_bwd(const float* logw, const float* w, const int32_t* x_lengths, const float* g, int B, int Tx, float* dlogw, void* stream);
 
+/* [B, C, T] <-> rows at the public boundary (fp32 or bf16 on either side: *_f32 = 1 / 0), one launch each:
+ *   gt_rows_from_bct: rows[m, c] = x[b, c, t] for the frame rows of utterance b (row base(b) + HALO + t, 0 <= t < T), 0 elsewhere;
+ *   gt_bct_from_rows: x[b, c, t] = rows[base(b) + HALO + t, c] for t < lengths[b], 0 beyond.  row0 == NULL: uniform layout. */
+int gt_rows_from_bct(const void* x, int x_f32, void* rows, int rows_f32, const int32_t* row0, int B, int C, int T, int Tp, int R, void* stream);
+int gt_bct_from_rows(const void* rows, int rows_f32, void* x, int x_f32, const int32_t* lengths, const int32_t* row0,
+                     int B, int C, int T, int Tp, int R, void* stream);
+
 /* Reverse (inference) direction of the flows — models.py:765-785 with reverse=True.
  *   gt_actnorm_invconv_rev: x = ((W^-1 y) * mask - bias) * exp(-logs) * mask  (InvConvNear^-1 then ActNorm^-1,
  *     modules.py:647-652,592-594); scal from gt_flow_scalars (holds W^-T); x0_bf16 (optional) = bf16(x[:, :C/2]).
