@@ -472,6 +472,8 @@ class Trainer:
         torch.cuda.synchronize()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and work they launched on another stream would stay outside the captured graph
+        from . import wgrad
+        tables = wgrad.table_arena_begin(ids.device) # the captured weight-gradient kernels' job tables: outside the graph's pool
         g1 = torch.cuda.CUDAGraph()
         if not self.split and self.world == 1:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
@@ -495,6 +497,9 @@ class Trainer:
                 self._optim(ids.device)
             graphs = (g1, g2, g3)
         self.n_captures += 1
+        wgrad.sync_uploads(ids.device)               # fill the tables the captured kernels read (once, not per replay)
+        wgrad.table_arena_end(ids.device)
+        ctxs = dict(ctxs or {}, _wgrad_tables=tables)  # lives (and is evicted) with this key's graphs
         return graphs, static + [cond], out, ctxs
 
     def _rows_key(self, Tx, Ty, lh):
@@ -571,7 +576,7 @@ class Trainer:
         for dst, src in list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src)
-        if ctxs:                                     # per-utterance row offsets / masks of THIS batch (same rounded size)
+        if ctxs and "x" in ctxs:                        # per-utterance row offsets / masks of THIS batch (same rounded size)
             ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
             if "f" in ctxs:
                 ok = ok and ctxs["f"].refresh(static[3] // 2 * 2, [int(v) // 2 * 2 for v in lh[1]])

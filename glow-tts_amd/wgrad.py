@@ -48,6 +48,34 @@ def _fill_pool():
         _POOL.append(torch.empty(_POOL_BYTES, dtype=torch.uint8).pin_memory())
 
 
+_PENDING_UPLOADS = []        # (device table, pinned host copy) of the flushes recorded by the graph capture in progress
+_TABLE_ARENA = {}            # device -> {"buf", "off"}: where a capture's tables live (see _flush)
+
+
+def table_arena_begin(dev, nbytes=8 << 20):
+    """Before a graph capture (outside it): a buffer for the capture's weight-gradient tables; the caller keeps the returned tensor
+    alive as long as the graph."""
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _TABLE_ARENA[str(dev)] = {"buf": buf, "off": 0}
+    _PENDING_UPLOADS.clear()                          # nothing left over from a capture that failed half-way
+    return buf
+
+
+def table_arena_end(dev):
+    _TABLE_ARENA.pop(str(dev), None)
+
+
+
+def sync_uploads(dev):
+    """Right after a graph capture (outside it): fill the tables its weight-gradient kernels read; nothing else ever writes them."""
+    if _PENDING_UPLOADS:
+        assert not torch.cuda.is_current_stream_capturing()
+        for dst, host in _PENDING_UPLOADS:
+            dst.copy_(host, non_blocking=True)
+        _PENDING_UPLOADS.clear()
+        torch.cuda.current_stream(dev).synchronize()
+
+
 def _side_stream(dev):
     key = str(dev)
     if key not in _SIDE:
@@ -210,8 +238,19 @@ class WgradQueue:
                 host = _POOL.pop()[: raw.size]
                 host.numpy()[:] = raw
                 self._keep(host)
-            else:
-                host = torch.from_numpy(raw).pin_memory()
+                # The tables of a captured step never change (the graph's buffers are static).  With a table arena open (the
+                # trainer allocates it BEFORE the capture, outside the graph's memory pool — a pool block would be reused by other
+                # tensors of the step and clobbered at every replay) they are copied ONCE, right after the capture
+                # (sync_uploads), instead of by a memcpy node that every replay runs (12 of them per step at cfg 2).
+                ar = _TABLE_ARENA.get(str(dev))
+                nb = (raw.size + 255) & ~255
+                if ar is not None and ar["off"] + nb <= ar["buf"].numel():
+                    dst = ar["buf"][ar["off"]:ar["off"] + raw.size]
+                    ar["off"] += nb
+                    _PENDING_UPLOADS.append((dst, host))
+                    return dst
+                return host.to(dev, non_blocking=True)
+            host = torch.from_numpy(raw).pin_memory()
             return host.to(dev, non_blocking=True)
 
         if capturing:
