@@ -475,13 +475,14 @@ __global__ __launch_bounds__(1024) void gt_rows_utt_sum_kernel(const void* __res
 // ragged rows layout: row -> (utterance, frame, valid) tables from the row offsets, one launch (was a dozen host-side ops)
 __global__ __launch_bounds__(256) void gt_rows_ctx_fill_kernel(const int32_t* __restrict__ row0, const int32_t* __restrict__ lens,
                                                                int64_t* __restrict__ rowbatch, int32_t* __restrict__ rowframe,
-                                                               float* __restrict__ rowmask, int B, int R)
+                                                               float* __restrict__ rowmask, int32_t* __restrict__ rowutt, int B, int R)
 {
   const int m = blockIdx.x * 256 + threadIdx.x;
   if (m >= R) return;
   const int b = gt_row_batch(row0, B, m, 0);
   const int t = m - row0[b] - HALO;
   rowbatch[m] = b;
+  if (rowutt) rowutt[m] = b;
   rowframe[m] = t;
   rowmask[m] = (t >= 0 && t < lens[b]) ? 1.f : 0.f;
 }
@@ -836,11 +837,11 @@ extern "C" int gt_rows_utt_sum(const void* y, int ldy, int is_f32, const float* 
   else        hipLaunchKernelGGL(gt_rows_utt_sum_kernel<false>, grid, dim3(1024), 0, GT_ST(stream), y, ldy, rowmask, out, ldo, accumulate, B, C, Tp, row0);
   GT_RET();
 }
-extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask,
+extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask, int32_t* rowutt,
                                int B, int R, void* stream)
 {
   if (!row0 || !lens || !rowbatch || !rowframe || !rowmask || B <= 0 || R <= 0) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_rows_ctx_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, GT_ST(stream), row0, lens, rowbatch, rowframe, rowmask, B, R);
+  hipLaunchKernelGGL(gt_rows_ctx_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, GT_ST(stream), row0, lens, rowbatch, rowframe, rowmask, rowutt, B, R);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

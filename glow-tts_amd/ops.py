@@ -276,21 +276,36 @@ class RowsCtx:
         self.rowmask2d = None
         assert not torch.cuda.is_current_stream_capturing(), \
             "a ragged RowsCtx is built outside graph capture (train.Trainer prebuilds and refreshes it)"
-        self.lengths = self.lengths.clone()                         # own storage: refresh() rewrites it in place
-        self.row0 = torch.empty(self.B + 1, dtype=torch.int32, device=self.device)
+        # row0 [B+1] and lengths [B] share ONE device buffer: a refresh is a single host-to-device copy of both
+        self._geo = torch.empty(2 * self.B + 1, dtype=torch.int32, device=self.device)
+        self.row0, self.lengths = self._geo[:self.B + 1], self._geo[self.B + 1:]
+        self._ring, self._ring_i = [], 0                            # pinned host staging buffers of the refreshes in flight
         self.rowbatch = torch.empty(self.R, dtype=torch.int64, device=self.device)
         self.rowframe = torch.empty(self.R, dtype=torch.int32, device=self.device)
         self.rowmask = torch.empty(self.R, dtype=torch.float32, device=self.device)
         self.rowutt = torch.empty(self.R, dtype=torch.int32, device=self.device)
-        self._fill(starts)
+        self._fill(starts, lengths_host)
 
-    def _fill(self, starts):
-        """row0 (host list) -> device row0, row -> utterance, row -> frame, rowmask; all in place."""
-        self.row0.copy_(torch.tensor(starts, dtype=torch.int32))       # pageable source: the copy is staged before returning
+    RING = 8
+
+    def _fill(self, starts, lengths_host):
+        """row0 / lengths (host lists) -> device (ONE non-blocking copy from pinned memory), then row -> utterance, row ->
+        frame, rowmask in ONE launch; all in place, stream-ordered."""
+        if len(self._ring) < self.RING:
+            self._ring.append((torch.empty(2 * self.B + 1, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
+            host, ev = self._ring[-1]
+        else:
+            host, ev = self._ring[self._ring_i % self.RING]
+            ev.synchronize()                                         # the copy that last read this buffer (8 refreshes ago) is done
+        self._ring_i += 1
+        hv = host.numpy()
+        hv[:self.B + 1] = starts
+        hv[self.B + 1:] = [int(v) for v in lengths_host]
+        self._geo.copy_(host, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.device))
         _lib.check(_lib.lib().gt_rows_ctx_fill(_lib.ptr(self.row0), _lib.ptr(self.lengths), _lib.ptr(self.rowbatch),
-                                               _lib.ptr(self.rowframe), _lib.ptr(self.rowmask), self.B, self.R,
+                                               _lib.ptr(self.rowframe), _lib.ptr(self.rowmask), _lib.ptr(self.rowutt), self.B, self.R,
                                                _lib.current_stream(self.device)), "gt_rows_ctx_fill")
-        self.rowutt.copy_(self.rowbatch)                                # int32 twin of rowbatch (predictor kernels)
 
     def row_utt(self):
         """int32 [R]: utterance of every row (rows past the last utterance's frames belong to the last one)."""
@@ -324,8 +339,7 @@ class RowsCtx:
         starts, R = self.row_starts(lengths_host, self.T, self.rnd)
         if R != self.R:
             return False
-        self.lengths.copy_(lengths.to(torch.int32))
-        self._fill(starts)
+        self._fill(starts, lengths_host)                # the host lengths ARE the lengths (the device copy is not read back)
         return True
 
     def mask_bt(self):

@@ -276,6 +276,18 @@ class FlatAdamW:
 CAPTURE_MODE = "thread_local"
 
 
+def _copy_padded(dst, src):
+    """dst[..., :T] = src, dst[..., T:] = 0 where T = src's (shorter or equal) last dimension: a batch goes straight into the
+    padded static buffer of its graph (two launches at most; padding it first and copying the padded tensor took three)."""
+    T = src.shape[-1] if src.dim() else 0
+    if src.dim() == 0 or dst.shape == src.shape:
+        dst.copy_(src)
+        return
+    assert dst.shape[:-1] == src.shape[:-1] and dst.shape[-1] >= T
+    dst[..., :T].copy_(src)
+    dst[..., T:].zero_()
+
+
 class Trainer:
     """zero_grad -> forward -> loss -> backward -> all-reduce -> grad-norm -> AdamW step.
 
@@ -532,11 +544,12 @@ class Trainer:
         """-> (captured entry or None if capture is impossible, padded inputs)"""
         Tx = -(-ids.shape[1] // self.pad_tx) * self.pad_tx
         Ty = -(-y.shape[2] // self.pad_ty) * self.pad_ty
-        ids, y = self._pad_time(ids, Tx), self._pad_time(y, Ty)
-        cond = {k: (self._pad_time(v, Ty) if k in ("pitch", "energy") else v) for k, v in cond.items()}
-        key = self._rows_key(Tx, Ty, lh) + (tuple(ids.shape), tuple(y.shape), tuple(sorted(cond)))
+        key = self._rows_key(Tx, Ty, lh) + (tuple(ids.shape[:-1]) + (Tx,), tuple(y.shape[:-1]) + (Ty,), tuple(sorted(cond)))
         cap = self._captured.get(key)
         if cap is None:
+            # a new key: the capture clones PADDED inputs (a known key's batch goes straight into the padded static buffers)
+            ids, y = self._pad_time(ids, Tx), self._pad_time(y, Ty)
+            cond = {k: (self._pad_time(v, Ty) if k in ("pitch", "energy") else v) for k, v in cond.items()}
             try:
                 cap = self._capture(ids, t_x, y, t_y, lh, cond)
             except Exception as e:                   # e.g. an allocation the capture refuses: keep training, eagerly
@@ -575,11 +588,11 @@ class Trainer:
         graphs, static, out, ctxs = cap
         for dst, src in list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]:
             if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src)
+                _copy_padded(dst, src)
         if ctxs and "x" in ctxs:                        # per-utterance row offsets / masks of THIS batch (same rounded size)
-            ok = ctxs["x"].refresh(static[1], lh[0]) and ctxs["y"].refresh(static[3] // 2, [int(v) // 2 for v in lh[1]])
+            ok = ctxs["x"].refresh(None, lh[0]) and ctxs["y"].refresh(None, [int(v) // 2 for v in lh[1]])
             if "f" in ctxs:
-                ok = ok and ctxs["f"].refresh(static[3] // 2 * 2, [int(v) // 2 * 2 for v in lh[1]])
+                ok = ok and ctxs["f"].refresh(None, [int(v) // 2 * 2 for v in lh[1]])
             assert ok, "row count of the batch does not match the captured graph"
         graphs[0].replay()                           # collectives sit BETWEEN the graphs, never inside one
         if len(graphs) == 2:

@@ -297,8 +297,9 @@ int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, f
 
 /* Ragged rows layout (see GT_HALO above): from the row offsets row0[B+1] and the lengths, fill the per-row tables the
  * host side keeps next to them — rowbatch[m] (utterance of row m, int64), rowframe[m] (m - row0[b] - GT_HALO) and
- * rowmask[m] (1 on valid frames) — in one launch (a replayed HIP graph's contexts are refreshed per batch). */
-int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask,
+ * rowmask[m] (1 on valid frames), rowutt[m] (optional int32 twin of rowbatch) — in one launch (a replayed HIP graph's contexts
+ * are refreshed per batch). */
+int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask, int32_t* rowutt,
                      int B, int R, void* stream);
 
 /* out[m,:] = (x[m,:] + cond[utterance(m),:]) * rowmask[m]: a per-utterance vector added to every valid row — the
