@@ -150,7 +150,8 @@ class BoundaryFwdArgs(ctypes.Structure):
                 ("x_in", c_void_p), ("an_logs", c_void_p), ("an_bias", c_void_p), ("w_ic", c_void_p), ("scal", c_void_p),
                 ("len", c_void_p), ("B", c_int), ("y_next", c_void_p), ("y0_bf16", c_void_p), ("w_start", c_void_p),
                 ("b_start", c_void_p), ("ks_start", c_int), ("h_next", c_void_p), ("rowmask", c_void_p),
-                ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int)]
+                ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int),
+                ("y_bct", c_void_p), ("z_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p)]
 
 
 class BoundaryBwdArgs(ctypes.Structure):
@@ -161,7 +162,8 @@ class BoundaryBwdArgs(ctypes.Structure):
                 ("dz_in", c_void_p), ("logs_raw", c_void_p), ("y", c_void_p), ("dlogdet", c_void_p), ("rowutt", c_void_p),
                 ("sigmoid_scale", c_int), ("dx_out", c_void_p), ("dout", c_void_p), ("w_end_d", c_void_p), ("ks_end_d", c_int),
                 ("dwn_out", c_void_p), ("w_skip_d", c_void_p), ("ks_skip_d", c_int), ("via_skip", c_void_p), ("ldvs", c_int),
-                ("rowmask", c_void_p), ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int)]
+                ("rowmask", c_void_p), ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int),
+                ("dz_bct", c_void_p), ("dx_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p)]
 
 
 def fill_args(cls, **kw):

@@ -617,18 +617,24 @@ __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict
 
 // mle_loss's scalar tail (commons.py:31-33) in one launch: out[0] = loss = (acc[0] + 0.5 acc[1] - sum logdet) / denom + 0.5 log 2pi,
 // out[1] = denom = C * sum(mask)  (= sum(ones_like(z) * mask))
-__global__ __launch_bounds__(256) void gt_mle_finish_kernel(const float* __restrict__ acc, const float* __restrict__ logdet,
-                                                            const float* __restrict__ mask, int n_mask, int B, int C, float* __restrict__ out)
+__global__ __launch_bounds__(1024) void gt_mle_finish_kernel(const float* __restrict__ acc, const float* __restrict__ logdet,
+                                                             const float* __restrict__ mask, int n_mask, int B, int C, float* __restrict__ out)
 {
-  __shared__ float red[2][4];
+  // one workgroup (the result is two scalars), 1024 threads and 16-byte loads: the mask is B x T floats (25 k at cfg 2) and a
+  // 256-thread scalar loop over it sat 40 us on the step's critical path
+  __shared__ float red[2][16];
   float sl = 0.f, sn = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) sl += logdet[b];
-  for (int i = threadIdx.x; i < n_mask; i += 256) sn += mask[i];
+  for (int b = threadIdx.x; b < B; b += 1024) sl += logdet[b];
+  const int n4 = ((reinterpret_cast<uintptr_t>(mask) & 15) == 0) ? n_mask >> 2 : 0;
+  for (int i = threadIdx.x; i < n4; i += 1024) { const float4 v = reinterpret_cast<const float4*>(mask)[i]; sn += (v.x + v.y) + (v.z + v.w); }
+  for (int i = (n4 << 2) + threadIdx.x; i < n_mask; i += 1024) sn += mask[i];
   sl = wave_sum(sl); sn = wave_sum(sn);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sl; red[1][threadIdx.x >> 6] = sn; }
   __syncthreads();
-  sl = red[0][0] + red[0][1] + red[0][2] + red[0][3]; sn = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   if (threadIdx.x == 0) {
+    sl = 0.f; sn = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sl += red[0][i]; sn += red[1][i]; }
     const float denom = sn * (float)C;
     out[0] = (acc[0] + 0.5f * acc[1] - sl) / denom + 0.91893853320467274f;
     out[1] = denom;
@@ -885,7 +891,7 @@ extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, fl
 extern "C" int gt_mle_finish(const float* acc2, const float* logdet, const float* mask, int n_mask, int B, int C, float* out2, void* stream)
 {
   if (!acc2 || !logdet || !mask || !out2 || B <= 0 || C <= 0 || n_mask <= 0) return GT_E_INVAL;
-  hipLaunchKernelGGL(gt_mle_finish_kernel, dim3(1), dim3(256), 0, GT_ST(stream), acc2, logdet, mask, n_mask, B, C, out2);
+  hipLaunchKernelGGL(gt_mle_finish_kernel, dim3(1), dim3(1024), 0, GT_ST(stream), acc2, logdet, mask, n_mask, B, C, out2);
   GT_RET();
 }
 extern "C" int gt_duration_loss_fwd(const float* logw, const float* w, const int32_t* x_lengths, int B, int Tx, float* l_length, void* stream)

@@ -126,6 +126,21 @@ __device__ __forceinline__ void skip_slice(const u32x4_t (&xr)[6], bf16_t* As, c
   }
 }
 
+// commons.squeeze / unsqueeze (commons.py:339-364, n_sqz = 2) folded into the first / last kernels of a pass: squeezed frame t of
+// utterance b, channel p * 80 + c  <->  y[b, c, 2 t + p] of the [B, 80, T] tensor at the decoder's public boundary
+__device__ __forceinline__ float4 sq_gather4(const float* __restrict__ y, int b, int t, int c, int T)
+{
+  const int p = c >= HALF, cc = c - HALF * p;
+  const float* src = y + ((size_t)b * HALF + cc) * T + 2 * t + p;
+  return make_float4(src[0], src[(size_t)T], src[2 * (size_t)T], src[3 * (size_t)T]);
+}
+__device__ __forceinline__ void sq_scatter4(float* __restrict__ y, int b, int t, int c, int T, const float4& v)
+{
+  const int p = c >= HALF, cc = c - HALF * p;
+  float* dst = y + ((size_t)b * HALF + cc) * T + 2 * t + p;
+  dst[0] = v.x; dst[(size_t)T] = v.y; dst[2 * (size_t)T] = v.z; dst[3 * (size_t)T] = v.w;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int F_AS = 0;                                    // acts slices [4][64][AP] bf16; later At [64][AP] (slice 0) / y0 tile
 constexpr int F_O = BM * AP * 2;                           // m | logs tile [64][ZP] fp32 (over slices 1, 2 once they are dead)
@@ -240,8 +255,14 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
         z1 = make_float4((mm.x + __expf(lg[0]) * y1.x) * rm, (mm.y + __expf(lg[1]) * y1.y) * rm,
                          (mm.z + __expf(lg[2]) * y1.z) * rm, (mm.w + __expf(lg[3]) * y1.w) * rm);
         if (!(WNB_EXP & 4)) {
-        *reinterpret_cast<float4*>(a.z + (size_t)gm * C + c) = z0;
-        *reinterpret_cast<float4*>(a.z + (size_t)gm * C + HALF + c) = z1;
+        if (a.z) {
+          *reinterpret_cast<float4*>(a.z + (size_t)gm * C + c) = z0;
+          *reinterpret_cast<float4*>(a.z + (size_t)gm * C + HALF + c) = z1;
+        }
+        if (a.z_bct) {                                             // the unsqueeze: straight into [B, 80, T] (pre-zeroed by the caller)
+          const int b = (int)a.rowbatch[gm], t = a.rowframe[gm];
+          if (t >= 0 && t < a.len[b]) { sq_scatter4(a.z_bct, b, t, c, a.T, z0); sq_scatter4(a.z_bct, b, t, HALF + c, a.T, z1); }
+        }
         *reinterpret_cast<float4*>(a.logs_raw + (size_t)gm * HALF + c) = lr;       // the backward needs logs only
         }
         const float s = (lg[0] + lg[1] + lg[2] + lg[3]) * rm;
@@ -263,7 +284,13 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     for (int k = 0; k < 10; ++k) {
       const int item = threadIdx.x + 256 * k, row = item / 40, c = 4 * (item - row * 40), gm = m0 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gm < R) v = *reinterpret_cast<const float4*>(a.x_in + (size_t)gm * C + c);
+      if (gm < R) {
+        if (a.y_bct) {                                             // the squeeze: straight from [B, 80, T]
+          const int b = (int)a.rowbatch[gm], t = a.rowframe[gm];
+          if (t >= 0 && t < a.len[b]) v = sq_gather4(a.y_bct, b, t, c, a.T);
+          if (a.z) *reinterpret_cast<float4*>(a.z + (size_t)gm * C + c) = v;    // the squeezed rows: ActNorm's input, kept for the backward
+        } else v = *reinterpret_cast<const float4*>(a.x_in + (size_t)gm * C + c);
+      }
       *reinterpret_cast<float4*>(Zt + row * ZP + c) = v;
     }
     __syncthreads();
@@ -433,8 +460,16 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
             *reinterpret_cast<float2*>(Dt + row * ZP + 2 * g) = make_float2(dxv[0], dxv[1]);
             *reinterpret_cast<float2*>(Dt + row * ZP + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
           } else if (gm < R) {
-            *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + 2 * g) = make_float2(dxv[0], dxv[1]);
-            *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
+            if (a.dx_bct) {                                        // the unsqueeze of the decoder's input gradient
+              const int b = (int)a.rowbatch[gm], t = a.rowframe[gm];
+              if (t >= 0 && t < a.len[b]) {
+                float* d0 = a.dx_bct + ((size_t)b * HALF + 2 * g) * a.T + 2 * t;
+                d0[0] = dxv[0]; d0[(size_t)a.T] = dxv[1]; d0[1] = dxv[2]; d0[(size_t)a.T + 1] = dxv[3];
+              }
+            } else {
+              *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + 2 * g) = make_float2(dxv[0], dxv[1]);
+              *reinterpret_cast<float2*>(a.dx_out + (size_t)gm * C + HALF + 2 * g) = make_float2(dxv[2], dxv[3]);
+            }
           }
         }
       }
@@ -465,7 +500,12 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     for (int k = 0; k < 10; ++k) {
       const int item = threadIdx.x + 256 * k, row = item / 40, c = 4 * (item - row * 40), gm = m0 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gm < R) v = *reinterpret_cast<const float4*>(a.dz_in + (size_t)gm * C + c);
+      if (gm < R) {
+        if (a.dz_bct) {
+          const int b = (int)a.rowbatch[gm], t = a.rowframe[gm];
+          if (t >= 0 && t < a.len[b]) v = sq_gather4(a.dz_bct, b, t, c, a.T);
+        } else v = *reinterpret_cast<const float4*>(a.dz_in + (size_t)gm * C + c);
+      }
       *reinterpret_cast<float4*>(Dt + row * ZP + c) = v;
     }
     __syncthreads();
@@ -593,11 +633,12 @@ extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream
   if (!tail && !head) return GT_E_INVAL;
   if (!a.rowmask) return GT_E_INVAL;
   if (tail) {
-    if (!a.w_skip || !a.b_skip || !a.w_end || !a.b_end || !a.y || !a.wn_out || !a.logs_raw || !a.z || !a.logdet || !a.rowutt) return GT_E_INVAL;
+    if (!a.w_skip || !a.b_skip || !a.w_end || !a.b_end || !a.y || !a.wn_out || !a.logs_raw || (!a.z && !a.z_bct) || !a.logdet || !a.rowutt) return GT_E_INVAL;
+    if (a.z_bct && (head || !a.rowbatch || !a.rowframe || !a.len || a.T <= 0)) return GT_E_INVAL;
     if (a.ldacts < NL * H || (a.ldacts & 7) || a.ks_end < H / 16) return GT_E_INVAL;
     if (!al16(a.acts) || !al16(a.w_skip) || !al16(a.w_end) || !al16(a.b_skip) || !al16(a.b_end) || !al16(a.y) || !al16(a.wn_out) ||
         !al16(a.logs_raw) || !al16(a.z)) return GT_E_ALIGN;
-  } else if (!a.x_in || !al16(a.x_in)) return GT_E_INVAL;
+  } else if (a.y_bct ? (!a.rowbatch || !a.rowframe || a.T <= 0) : (!a.x_in || !al16(a.x_in))) return GT_E_INVAL;
   if (head) {
     if (!a.an_logs || !a.an_bias || !a.w_ic || !a.scal || !a.len || a.B <= 0 || !a.logdet || !a.y0_bf16 || !a.w_start || !a.b_start || !a.h_next)
       return GT_E_INVAL;
@@ -627,13 +668,15 @@ extern "C" int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream
   if (a.H != H || a.C != C || a.n_layers != NL) return GT_E_UNSUPPORTED;
   const bool headb = a.dh != nullptr, tailb = a.dout != nullptr;
   if (!headb && !tailb) return GT_E_INVAL;
-  if (!a.rowmask || !a.dx_out || !al16(a.dx_out)) return GT_E_INVAL;
+  if (!a.rowmask || (!a.dx_out && !a.dx_bct) || !al16(a.dx_out)) return GT_E_INVAL;
+  if ((a.dx_bct || a.dz_bct) && (!a.rowbatch || !a.rowframe || !a.len || a.T <= 0)) return GT_E_INVAL;
+  if (a.dx_bct && tailb) return GT_E_INVAL;
   if (headb) {
     if (!a.w_start_d || !a.dx_in || !a.x || !a.an_logs || !a.an_bias || !a.w_ic || !a.scal || !a.len || !a.dlogdet || a.B <= 0 ||
         !a.d_an_logs || !a.d_an_bias || !a.d_w_ic) return GT_E_INVAL;
     if (a.ks_start_d < H / 16) return GT_E_INVAL;
     if (!al16(a.dh) || !al16(a.w_start_d) || !al16(a.dx_in) || !al16(a.x)) return GT_E_ALIGN;
-  } else if (!a.dz_in || !al16(a.dz_in)) return GT_E_INVAL;
+  } else if (!a.dz_bct && (!a.dz_in || !al16(a.dz_in))) return GT_E_INVAL;
   if (tailb) {
     if (!a.logs_raw || !a.y || !a.dlogdet || !a.rowutt || !a.w_end_d || !a.dwn_out || !a.w_skip_d || !a.via_skip) return GT_E_INVAL;
     if (a.ks_end_d < C / 16 || a.ks_skip_d < H / 16 || a.ldvs < NL * H || (a.ldvs & 3)) return GT_E_INVAL;

@@ -520,13 +520,15 @@ def flow_scalars_all(dec):
     return torch.stack([flow_scalars(l, w) for l, w in zip(lgs, Ws)]), Ws
 
 
-def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed):
+def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_bct=None):
     """The decoder's flow chain with ONE kernel between consecutive WaveNets (gt_wn_boundary_fwd: tail of block b-1 + head
     of block b) and one kernel per WaveNet layer: n_blocks * (n_layers + 1) + 1 launches.  rows [R, C] fp32 (squeezed mel),
-    conds[b]: [B, 2*H*n] or None.  Returns (z rows, per-block saved state)."""
+    conds[b]: [B, 2*H*n] or None.  Returns (z rows, per-block saved state).
+    y_bct / z_bct ([B, C/2, T] fp32, T even, z_bct pre-zeroed): the decoder's input / output at the public boundary — the first
+    launch then squeezes (rows = None) and the last one unsqueezes (the returned z rows are None)."""
     L = _lib.lib()
-    dev = rows.device
-    R, C = rows.shape
+    dev = rc.rowmask.device
+    R, C = rc.R, 2 * dec.in_channels
     H, nb, n = dec.hidden_channels, dec.n_blocks, dec.n_layers
     scal, Ws = flow_scalars_all(dec)
     f32 = dict(dtype=torch.float32, device=dev)
@@ -539,20 +541,26 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed):
             acts_all = sv.wn_saved[3]
             sv.wn_out = torch.empty(R, H, **bf)
             sv.logs_raw = torch.empty(R, C // 2, **f32)
-            sv.z = torch.empty(R, C, **f32)
+            last_out = b == nb and z_bct is not None
+            sv.z = None if last_out else torch.empty(R, C, **f32)
             kw.update(acts=acts_all, ldacts=acts_all.stride(0), w_skip=cbp.wn.pc_skipcat_frag.fwd, b_skip=cbp.wn.skip_bias,
                       w_end=cbp.end.pc_frag.fwd, b_end=cbp.end.bias, ks_end=cbp.end.pc_frag.Kp_f // 16, y=sv.y, wn_out=sv.wn_out,
                       logs_raw=sv.logs_raw, z=sv.z, rowutt=rc.rowutt, sigmoid_scale=int(cbp.sigmoid_scale))
+            if last_out:
+                kw.update(z_bct=z_bct, T=z_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe, len=rc.lengths)
         if b < nb:                                         # head of block b
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
             st = _BlockState()
+            if b == 0 and rows is None:
+                rows = torch.empty(R, C, **f32)            # the first launch writes the squeezed rows (ActNorm's input, for the backward)
+                kw.update(y_bct=y_bct, T=y_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe, z=rows)
+            elif b == 0:
+                kw.update(x_in=rows)
             st.x_in = rows if b == 0 else blocks[b - 1].z
             st.y = torch.empty(R, C, **f32)
             st.x0 = torch.empty(R, C // 2, **bf)
             st.h0 = torch.empty(R, H, **bf)
             st.scal, st.w_ic = scal[b], Ws[b]
-            if b == 0:
-                kw.update(x_in=rows)
             kw.update(an_logs=an.logs, an_bias=an.bias, w_ic=st.w_ic, scal=st.scal, len=rc.lengths, B=rc.B, y_next=st.y, y0_bf16=st.x0,
                       w_start=cb.start.pc_frag.fwd, b_start=cb.start.bias, ks_start=cb.start.pc_frag.Kp_f // 16, h_next=st.h0)
             blocks.append(st)
@@ -570,13 +578,15 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed):
     return blocks[-1].z, blocks
 
 
-def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
+def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx_bct=None):
     """Backward of decoder_fwd_fused: gt_wn_boundary_bwd between the WaveNets' layer kernels.  drows [R, C] fp32 = gradient
-    of the decoder's output rows; returns (d input rows [R, C], {param: grad}, [dcond per block])."""
+    of the decoder's output rows; returns (d input rows [R, C], {param: grad}, [dcond per block]).
+    dz_bct / dx_bct ([B, C/2, T] fp32, T even, dx_bct pre-zeroed): the gradients at the public boundary — the first launch then
+    squeezes dz (drows = None), the last one unsqueezes the input gradient (returned rows are None)."""
     import ctypes
     L = _lib.lib()
-    dev = drows.device
-    R, C = drows.shape
+    dev = rc.rowmask.device
+    R, C = rc.R, 2 * dec.in_channels
     H, nb, n = dec.hidden_channels, dec.n_blocks, dec.n_layers
     f32 = dict(dtype=torch.float32, device=dev)
     bf = dict(dtype=torch.bfloat16, device=dev)
@@ -586,7 +596,7 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
     tail = None                                            # (dout, dwn_out, via_skip) of that block
     for b in range(nb, -1, -1):
         kw = dict(rowmask=rc.rowmask, R=R, H=H, C=C, n_layers=n)
-        dx_out = torch.empty(R, C, **f32)
+        dx_out = None if (b == 0 and dx_bct is not None) else torch.empty(R, C, **f32)
         if b < nb:                                         # head of block b: its WaveNet backward has just produced dh0
             an, ic, cb, sv = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2], blocks[b]
             dlogs = grad_accumulator(an.logs, (C,))
@@ -596,6 +606,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
                       an_logs=an.logs, an_bias=an.bias, w_ic=sv.w_ic, scal=sv.scal, len=rc.lengths, B=rc.B,
                       d_an_logs=dlogs, d_an_bias=dbias, d_w_ic=dW, dlogdet=dlogdet)
             grads.update({an.logs: dlogs.view_as(an.logs), an.bias: dbias.view_as(an.bias), ic.weight: dW.view_as(ic.weight)})
+        elif dz_bct is not None:
+            kw.update(dz_bct=dz_bct, T=dz_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe, len=rc.lengths)
         else:
             kw.update(dz_in=drows)
         new_tail = None
@@ -608,7 +620,10 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond):
                       dout=dout, w_end_d=cbp.end.pc_frag.dgrad, ks_end_d=cbp.end.pc_frag.Kp_d // 16, dwn_out=dwn,
                       w_skip_d=cbp.wn.pc_skipcat_frag.dgrad, ks_skip_d=cbp.wn.pc_skipcat_frag.Kp_d // 16, via_skip=via, ldvs=via.stride(0))
             new_tail = (dout, dwn, via)
-        kw.update(dx_out=dx_out)
+        if dx_out is None:
+            kw.update(dx_bct=dx_bct, T=dx_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe)
+        else:
+            kw.update(dx_out=dx_out)
         args = _lib.fill_args(_lib.BoundaryBwdArgs, **kw)
         if BOUNDARY_TRACE is not None:
             BOUNDARY_TRACE.append(("gt_wn_boundary_bwd", args, kw))

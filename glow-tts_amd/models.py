@@ -136,16 +136,22 @@ class _DecoderRunner:
         len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)          # mask[:, :, 1::2] (commons.py:348)
         rc = ops.make_ctx(len_sq, T2, "y", div=2, cfg=self.cfg)
         xin = x.detach().float().contiguous()
-        rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         st = _lib.current_stream(dev)
-        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         logdet = ops.zeros_small(B, torch.float32, dev)
         esig, psig = self._contour_rows(rc, self.energy, B, T2 * 2), self._contour_rows(rc, self.pitch, B, T2 * 2)
         saved = []
-        cur = rows
         # one kernel between consecutive WaveNets (csrc/wn_boundary.hip) unless a block still waits for its data-dependent
         # init (that forward runs round 1's launch sequence once) or per-frame prosody conditioning is on
         fused = dec.fused_boundary and esig is None and psig is None and all(dec.flows[3 * b].initialized for b in range(nb))
+        # ... and then commons.squeeze / unsqueeze ride in its first / last launch (ragged rows, even T)
+        folded = fused and T == T2 * 2 and getattr(rc, "rowbatch", None) is not None
+        if folded:
+            z = ops.zeros_big((B, C, T), torch.float32, dev)
+            _, blocks = flow_impl.decoder_fwd_fused(rc, dec, None, conds, logdet, self.train, self.seed, y_bct=xin, z_bct=z)
+            return (z.to(x.dtype), logdet), (rc, ("fused", blocks), (B, C, T), esig, psig)
+        rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
+        _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
+        cur = rows
         if fused:
             cur, blocks = flow_impl.decoder_fwd_fused(rc, dec, rows, conds, logdet, self.train, self.seed)
             saved = ("fused", blocks)
@@ -199,6 +205,14 @@ class _DecoderRunner:
         T2 = T // 2
         dlogdet = ops.zeros_small(B, torch.float32, dev) if dlogdet is None else dlogdet.contiguous().float()
         grads = {}
+        fused = isinstance(saved, tuple) and len(saved) == 2 and saved[0] == "fused"
+        if fused and dz is not None and T == T2 * 2 and getattr(rc, "rowbatch", None) is not None:
+            # squeeze of d z / unsqueeze of the input gradient inside the first / last launch of the backward chain
+            dzc = dz.float().contiguous()
+            dx = ops.zeros_big((B, C, T), torch.float32, dev)
+            with wgrad.WgradQueue(dev, site=dec):
+                _, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], None, dlogdet, self.has_cond, dz_bct=dzc, dx_bct=dx)
+            return [dx] + (dconds if self.has_cond else []) + [grads.get(p) for p in self.params]
         drows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         if dz is None:
             drows.zero_()
@@ -210,7 +224,6 @@ class _DecoderRunner:
         deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None
         dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None
         cur = drows
-        fused = isinstance(saved, tuple) and len(saved) == 2 and saved[0] == "fused"
         # data-gradient chain now; ALL weight gradients of the decoder go out as one batch when the block ends
         with wgrad.WgradQueue(dev, site=dec):
             if fused:

@@ -439,6 +439,10 @@ typedef struct gt_boundary_fwd_args {
   const void* w_start; const float* b_start; int ks_start;
   void* h_next;                                 /* out: bf16 [R, H] */
   const float* rowmask; int R, H, C, n_layers;
+  /* optional: commons.squeeze / unsqueeze (commons.py:339-364) folded into the first / last launch of the pass —
+   * y_bct (head-only variant, instead of x_in): the decoder's input [B, C/2, T] fp32 (z, if given, then receives the squeezed rows); z_bct (tail-only variant, instead of z): its
+   * output [B, C/2, T] fp32, pre-zeroed by the caller; rowbatch (int64) / rowframe (int32): gt_rows_ctx_fill's tables; len as above */
+  const float* y_bct; float* z_bct; int T; const int64_t* rowbatch; const int32_t* rowframe;
 } gt_boundary_fwd_args;
 typedef struct gt_boundary_bwd_args {
   /* head */
@@ -459,6 +463,9 @@ typedef struct gt_boundary_bwd_args {
   const void* w_skip_d; int ks_skip_d;
   void* via_skip; int ldvs;                     /* out: bf16 [R, >= n_layers*H] */
   const float* rowmask; int R, H, C, n_layers;
+  /* optional, as in the forward: dz_bct (tail-only variant, instead of dz_in) and dx_bct (head-only variant, instead of dx_out;
+   * pre-zeroed) are [B, C/2, T] fp32 */
+  const float* dz_bct; float* dx_bct; int T; const int64_t* rowbatch; const int32_t* rowframe;
 } gt_boundary_bwd_args;
 int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream);
 int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream);
