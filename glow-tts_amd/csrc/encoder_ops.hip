@@ -603,9 +603,12 @@ __global__ __launch_bounds__(256) void gt_mle_sums_kernel(const float* __restric
 // dz = g * exp(-2 logs) (z-m);  dm = -dz;  dlogs = g * (1 - exp(-2 logs)(z-m)^2)   with g = *gscale
 __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict__ z, const float* __restrict__ m,
                                                          const float* __restrict__ logs, const float* __restrict__ gscale,
-                                                         float* __restrict__ dz, float* __restrict__ dm, float* __restrict__ dlogs, size_t n)
+                                                         float* __restrict__ dz, float* __restrict__ dm, float* __restrict__ dlogs, size_t n,
+                                                         const float* __restrict__ gdenom, float* __restrict__ dlogdet, int B)
 {
-  const float g = *gscale;
+  const float g = gdenom ? *gscale / *gdenom : *gscale;
+  if (dlogdet && blockIdx.x == 0)
+    for (int b = threadIdx.x; b < B; b += 256) dlogdet[b] = -g;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float l = logs ? logs[i] : 0.f, e = __expf(-2.0f * l), d = z[i] - m[i];
     const float v = g * e * d;
@@ -613,6 +616,16 @@ __global__ __launch_bounds__(256) void gt_mle_bwd_kernel(const float* __restrict
     if (dm) dm[i] = -v;
     if (dlogs) dlogs[i] = g * (1.0f - e * d * d);
   }
+}
+
+// commons.sequence_mask as floats: mask[b, t] = t < len[b]  (lengths int32 or int64)
+__global__ __launch_bounds__(256) void gt_length_mask_kernel(const void* __restrict__ len, int is64, float* __restrict__ mask, int B, int T)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * T) return;
+  const int b = idx / T, t = idx - b * T;
+  const long long n = is64 ? static_cast<const long long*>(len)[b] : (long long)static_cast<const int32_t*>(len)[b];
+  mask[idx] = t < n ? 1.f : 0.f;
 }
 
 // mle_loss's scalar tail (commons.py:31-33) in one launch: out[0] = loss = (acc[0] + 0.5 acc[1] - sum logdet) / denom + 0.5 log 2pi,
@@ -888,6 +901,12 @@ extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, fl
   hipLaunchKernelGGL(gt_mle_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, acc2, n);
   GT_RET();
 }
+extern "C" int gt_length_mask(const void* lengths, int is_int64, float* mask, int B, int T, void* stream)
+{
+  if (!lengths || !mask || B <= 0 || T <= 0) return GT_E_INVAL;
+  hipLaunchKernelGGL(gt_length_mask_kernel, dim3(((size_t)B * T + 255) / 256), dim3(256), 0, GT_ST(stream), lengths, is_int64, mask, B, T);
+  GT_RET();
+}
 extern "C" int gt_mle_finish(const float* acc2, const float* logdet, const float* mask, int n_mask, int B, int C, float* out2, void* stream)
 {
   if (!acc2 || !logdet || !mask || !out2 || B <= 0 || C <= 0 || n_mask <= 0) return GT_E_INVAL;
@@ -908,11 +927,11 @@ extern "C" int gt_duration_loss_bwd(const float* logw, const float* w, const int
   GT_RET();
 }
 extern "C" int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
-                          size_t n, void* stream)
+                          size_t n, const float* gdenom, float* dlogdet, int B, void* stream)
 {
   if (!z || !m || !gscale) return GT_E_INVAL;
   if (n == 0) return GT_OK;
   size_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(gt_mle_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, gscale, dz, dm, dlogs, n);
+  hipLaunchKernelGGL(gt_mle_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, gscale, dz, dm, dlogs, n, gdenom, dlogdet, B);
   GT_RET();
 }

@@ -133,8 +133,8 @@ class _DecoderRunner:
         B, C, T = x.shape
         dev = x.device
         T2 = T // 2
-        len_sq = (_mask_lengths(self.x_mask) // 2).to(torch.int32)          # mask[:, :, 1::2] (commons.py:348)
-        rc = ops.make_ctx(len_sq, T2, "y", div=2, cfg=self.cfg)
+        # squeezed lengths = mask[:, :, 1::2] (commons.py:348); a callable: a prebuilt (captured-graph) context has them already
+        rc = ops.make_ctx(lambda: (_mask_lengths(self.x_mask) // 2).to(torch.int32), T2, "y", div=2, cfg=self.cfg)
         xin = x.detach().float().contiguous()
         st = _lib.current_stream(dev)
         logdet = ops.zeros_small(B, torch.float32, dev)

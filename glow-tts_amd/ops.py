@@ -389,6 +389,18 @@ class RowsCtx:
         return out.transpose(1, 2).to(dtype).contiguous()
 
 
+def length_mask(lengths, T, dtype=torch.float32):
+    """[B, 1, T] mask of the frames t < lengths[b] (commons.sequence_mask(...).unsqueeze(1)) in one launch."""
+    B = lengths.shape[0]
+    if not lengths.is_cuda or dtype != torch.float32:
+        return (torch.arange(T, device=lengths.device)[None, :] < lengths[:, None]).unsqueeze(1).to(dtype)
+    out = torch.empty(B, 1, T, dtype=torch.float32, device=lengths.device)
+    ln = lengths if lengths.dtype in (torch.int32, torch.int64) else lengths.long()
+    _lib.check(_lib.lib().gt_length_mask(_lib.ptr(ln.contiguous()), int(ln.dtype == torch.int64), _lib.ptr(out), B, T,
+                                         _lib.current_stream(lengths.device)), "gt_length_mask")
+    return out
+
+
 def make_ctx(lengths, T, which, div=1, cfg=None):
     """RowsCtx for the text side (which = "x") or the mel side ("y", div = n_sqz) under the model's RowsConfig: ragged
     when cfg.ragged is on and the host knows the lengths of the batch in flight (FlowGenerator.forward / train.Trainer
@@ -396,9 +408,11 @@ def make_ctx(lengths, T, which, div=1, cfg=None):
     cfg = cfg or DEFAULT_ROWS
     pre = cfg.prebuilt.get(which)
     if pre is not None:                                     # the captured-graph path: context built (and refreshed) outside
-        assert pre.T == int(T) and pre.B == int(lengths.shape[0]), "prebuilt rows context does not fit this batch"
+        assert pre.T == int(T), "prebuilt rows context does not fit this batch"
         rc = pre
     else:
+        if callable(lengths):                               # the lengths tensor costs launches: only computed when it is needed
+            lengths = lengths()
         lh = cfg.host_lengths.get(which) if cfg.ragged else None
         rc = RowsCtx(lengths, T) if lh is None else RowsCtx(lengths, T, lengths_host=[int(v) // div for v in lh], round_to=cfg.row_round)
     if which == "y":

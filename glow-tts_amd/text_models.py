@@ -121,7 +121,7 @@ class TextEncoder(nn.Module):
             prepare_all(self)
         self._step += 1
         T = x.shape[1]
-        x_mask = (torch.arange(T, device=x.device)[None, :] < x_lengths[:, None]).unsqueeze(1).to(torch.float32)
+        x_mask = ops.length_mask(x_lengths, T)
         vec = self.encoder.cond_vec(g)                # speaker vector, added before encoder layer index 2
         lvec = None if l is None else l.squeeze(-1)     # [b, lin]: a differentiable input of the node (emb_l upstream)
         runner = _TextEncoderRunner(self, x, x_lengths, self.training, seed=(self._step * 104729) & 0x7fffffff,
@@ -321,13 +321,16 @@ class _MleLossFn(torch.autograd.Function):
         L = _lib.lib()
         zc, mc, lc, out, ld_shape = ctx.saved
         dev = zc.device
-        gs = (g.float() / out[1]).reshape(1).contiguous()
+        gs = g.float().reshape(1).contiguous()                   # divided by the denominator (out[1]) inside the kernel
         dz = torch.empty_like(zc)
         dm = torch.empty_like(mc)
         dl = None if lc is None else torch.empty_like(lc)
+        nb = 1
+        for d in ld_shape:
+            nb *= int(d)
+        dlogdet = torch.empty(ld_shape, dtype=torch.float32, device=dev)
         _lib.check(L.gt_mle_bwd(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(gs), _lib.ptr(dz), _lib.ptr(dm), _lib.ptr(dl),
-                                zc.numel(), _lib.current_stream(dev)), "gt_mle_bwd")
-        dlogdet = (-gs).expand(ld_shape).contiguous()
+                                zc.numel(), out[1:].data_ptr(), _lib.ptr(dlogdet), nb, _lib.current_stream(dev)), "gt_mle_bwd")
         return dz, dm, dl, dlogdet, None
 
 
@@ -646,7 +649,7 @@ class FlowGenerator(nn.Module):
                 leaf = x_logs.detach().requires_grad_(True)
                 self._deferred.append((x_logs, leaf)); x_logs = leaf
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
-        z_mask = (torch.arange(y_max_length, device=y.device)[None, :] < y_lengths[:, None]).unsqueeze(1).to(x_mask.dtype)
+        z_mask = ops.length_mask(y_lengths, y_max_length, x_mask.dtype)
         pitch_norm, energy_norm = self._contour(pitch, y_max_length), self._contour(energy, y_max_length)
         z, logdet = self.decoder(y, z_mask, g=g, pitch=pitch_norm, energy=energy_norm, prepared=True)
         if fork:

@@ -327,10 +327,13 @@ int gt_prior_expand(const float* x_m, const int32_t* frame2token, float* z_m, in
 int gt_prior_expand_bwd(const float* dz_m, const int32_t* frame2token, float* dx_m, int B, int C, int Tx, int Ty, void* stream);
 
 /* mle_loss pieces (commons.py:28-33): acc2[0] += sum(logs), acc2[1] += sum(exp(-2 logs)(z-m)^2);
- * backward: dz = g e^{-2 logs}(z-m), dm = -dz, dlogs = g (1 - e^{-2 logs}(z-m)^2), g = *gscale. */
+ * backward: dz = g e^{-2 logs}(z-m), dm = -dz, dlogs = g (1 - e^{-2 logs}(z-m)^2), g = *gscale (/ *gdenom when gdenom != NULL:
+ * the loss's denominator stays on the device); dlogdet (optional, [B]) receives -g. */
 int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream);
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
-               size_t n, void* stream);
+               size_t n, const float* gdenom, float* dlogdet, int B, void* stream);
+/* commons.sequence_mask as floats: mask[b, t] = t < lengths[b] (lengths int32 or int64), [B, T] in one launch. */
+int gt_length_mask(const void* lengths, int is_int64, float* mask, int B, int T, void* stream);
 
 /* mle_loss's scalar tail (commons.py:31-33) in one launch: out2[0] = (acc2[0] + 0.5 acc2[1] - sum logdet) / denom + 0.5 log(2 pi),
  * out2[1] = denom = C * sum(mask) (acc2 from gt_mle_sums; mask: the n_mask floats of z_mask [B, 1, T]). */
