@@ -71,6 +71,17 @@ def load_checkpoint(checkpoint_path, model, trainer=None):
     ck = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
     saved = ck["model"]
     cur = model.state_dict()
+    # the reference keeps the model's value for every key the file lacks and says so (utils.py:103-106: "%s is not in the
+    # checkpoint"); keys the FILE holds and this model does not (a cfg 5 checkpoint into a base-config model, say) are reported
+    # too instead of being dropped silently — load_checkpoint.last_report = {"missing": [...], "ignored": [...]}
+    missing = sorted(k for k in cur if k not in saved)
+    ignored = sorted(k for k in saved if k not in cur)
+    load_checkpoint.last_report = {"missing": missing, "ignored": ignored}
+    if missing or ignored:
+        import warnings
+        warnings.warn(f"load_checkpoint({os.path.basename(checkpoint_path)}): {len(missing)} model parameters are not in the checkpoint "
+                      f"(kept: {missing[:4]}{' ...' if len(missing) > 4 else ''}); {len(ignored)} checkpoint entries have no counterpart "
+                      f"in this model (ignored: {ignored[:4]}{' ...' if len(ignored) > 4 else ''})")
     model.load_state_dict({k: saved.get(k, v) for k, v in cur.items()})
     if trainer is not None:
         if "optimizer" in ck:

@@ -86,3 +86,28 @@ def test_warm_start_grows_tensors_and_skips_ignored_layers(tmp_path):
     assert torch.equal(big.encoder.emb.weight[:100], small.encoder.emb.weight) and big.encoder.emb.weight.shape[0] == 148
     assert torch.equal(big.encoder.proj_w.conv_1.weight, keep)
     assert torch.equal(big.decoder.flows[2].wn.in_layers[1].weight_v, small.decoder.flows[2].wn.in_layers[1].weight_v)
+
+
+def test_load_checkpoint_reports_keys_it_cannot_place(tmp_path):
+    """A checkpoint with entries this model does not have (a cfg 5 file into a base-config model) and without some it has:
+    load_checkpoint keeps the model's values for the missing ones, ignores the others and REPORTS both."""
+    import warnings
+    from glow_tts_amd import checkpoint
+    m1, t1 = _trainer(2)
+    path = os.path.join(tmp_path, "G_1.pth")
+    checkpoint.save_checkpoint(t1, 2e-4, 1, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    dropped = "decoder.flows.0.logs"
+    kept = ck["model"].pop(dropped)
+    ck["model"]["proj_pitch.pre.weight"] = torch.zeros(3)
+    torch.save(ck, path)
+    m2, _ = _trainer(5)
+    before = m2.state_dict()[dropped].clone()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        checkpoint.load_checkpoint(path, m2)
+    rep = checkpoint.load_checkpoint.last_report
+    assert rep == {"missing": [dropped], "ignored": ["proj_pitch.pre.weight"]}
+    assert any("proj_pitch.pre.weight" in str(x.message) for x in w)
+    assert torch.equal(m2.state_dict()[dropped], before)
+    assert torch.equal(m2.state_dict()["decoder.flows.1.weight"], m1.state_dict()["decoder.flows.1.weight"])
