@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--marks", action="store_true", help="dev: print the device-clock timeline of the last replayed step (ops.Marks) to stderr")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--one-batch", action="store_true", help="round 1's protocol: the same batch every step")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
@@ -259,6 +260,10 @@ def main():
         torch.cuda.synchronize(dev)
 
     # graphs of every row bucket the rotation meets: captured up front, untimed, without taking a training step
+    if args.marks:
+        from importlib import import_module
+        _ops = import_module(train.__name__.rsplit(".", 1)[0] + ".ops")
+        _ops.MARKS = _ops.Marks(dev)
     t_cap = time.perf_counter()
     tr.precapture([(b["ids"], b["t_x"], b["y"], b["t_y"], b["lh"], b["cond"]) for b in batches])
     torch.cuda.synchronize(dev)
@@ -288,6 +293,9 @@ def main():
     else:
         total_valid = float(valid_total)
     assert torch.isfinite(loss).item(), "training step diverged"
+    if args.marks and rank == 0:
+        for us, name in _ops.MARKS.report():
+            print(f"  {us:9.1f} us  {name}", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3

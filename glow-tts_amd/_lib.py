@@ -79,6 +79,7 @@ PROTOTYPES = {
     "gt_prior_expand_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_mle_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gt_mle_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "gt_mark": (c_int, [c_void_p, c_void_p]),
     "gt_length_mask": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_wn_layer_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                                 c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -265,34 +265,55 @@ __device__ __forceinline__ void pack_rows8(
     bf16_t* tile, float* scl)
 {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int n = Cin * taps;
+  const int n = Cin * taps, n4 = n >> 2;                          // n % 8 == 0
+  // wave w: rows 2w, 2w+1, each held in registers (<= 9 float4 per lane) from ONE batch of loads that are all in flight
+  // together — a load / accumulate loop per row left the launch bound by ~30 dependent HBM latencies per workgroup
+  // (171 us for the 28 M weights of the step; the bytes alone are ~40 us)
+  float4 x[2][PK8_MAXN / 256];
+  const bool al = ((reinterpret_cast<uintptr_t>(v) | ((size_t)n * 4)) & 15) == 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {                                   // wave w: rows 2w, 2w+1
+  for (int k = 0; k < 2; ++k) {
+    const float* vr = v + (size_t)(co0 + 2 * w + k) * n;
+#pragma unroll
+    for (int j = 0; j < PK8_MAXN / 256; ++j) {
+      const int i = lane + 64 * j;
+      x[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n4) {
+        if (al) x[k][j] = *reinterpret_cast<const float4*>(vr + 4 * i);
+        else    x[k][j] = make_float4(vr[4 * i], vr[4 * i + 1], vr[4 * i + 2], vr[4 * i + 3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
     const int rr = 2 * w + k, co = co0 + rr;
     float sc = 1.0f;
     if (g) {
-      const float* vr = v + (size_t)co * n;
       float ss = 0.f;
-      for (int i = lane; i < n; i += 64) { const float x = vr[i]; ss += x * x; }
+#pragma unroll
+      for (int j = 0; j < PK8_MAXN / 256; ++j) ss += x[k][j].x * x[k][j].x + x[k][j].y * x[k][j].y + x[k][j].z * x[k][j].z + x[k][j].w * x[k][j].w;
       ss = wave_sum(ss);
       const float inv = 1.0f / sqrtf(ss);
       if (lane == 0 && inv_norm) inv_norm[co] = inv;
       sc = g[co] * inv;
     }
-    if (lane == 0) scl[rr] = sc;
+#pragma unroll
+    for (int j = 0; j < PK8_MAXN / 256; ++j) {
+      const int i = lane + 64 * j;
+      if (i < n4)
+        *reinterpret_cast<uint2*>(tile + rr * n + 4 * i) =
+            make_uint2((uint32_t)f2bf(x[k][j].x * sc) | ((uint32_t)f2bf(x[k][j].y * sc) << 16),
+                       (uint32_t)f2bf(x[k][j].z * sc) | ((uint32_t)f2bf(x[k][j].w * sc) << 16));
+    }
   }
-  __syncthreads();
-  for (int rr = 0; rr < 8; ++rr) {
-    const float* vr = v + (size_t)(co0 + rr) * n;
-    const float sc = scl[rr];
-    for (int i = tid; i < n; i += 256) tile[rr * n + i] = f2bf(vr[i] * sc);
-  }
+  (void)scl;
   __syncthreads();
   const bool ffrag = gate & 2, dfrag = gate & 4;
   const int C8 = Cin >> 3;
   if (Pf) {
     for (int q = tid; q < 8 * taps * C8; q += 256) {
-      const int rr = q / (taps * C8), rem = q - rr * (taps * C8), tap = rem / C8, c8 = rem - tap * C8;
+      // the 8 rows of the group are the fastest index: their 16-byte pieces are neighbours in the packed image (whole 128-byte lines per store)
+      const int rr = q & 7, rem = q >> 3, tap = rem / C8, c8 = rem - tap * C8;
       const int co = co0 + rr;
       int pn = co;
       if (gate & 1) { const int half = Cout >> 1, c = co < half ? co : co - half; pn = (c >> 5) * 64 + (co < half ? 0 : 32) + (c & 31); }
@@ -320,10 +341,15 @@ __global__ __launch_bounds__(256) void gt_pack_conv_weights_multi8_kernel(const 
 {
   __shared__ __attribute__((aligned(16))) bf16_t tile[8 * PK8_MAXN];
   __shared__ float scl[8];
-  int lo = 0, hi = n - 1;
+  __shared__ int sel;
   const int row = blockIdx.x * 8;
-  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].row_start <= row) lo = mid; else hi = mid - 1; }
-  const gt_pack_desc d = descs[lo];
+  // the conv this row group belongs to = the last descriptor starting at or before it: every lane tests one descriptor (one load
+  // latency instead of a binary search's eight dependent ones)
+  if (threadIdx.x == 0) sel = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) if (descs[i].row_start <= row) atomicMax(&sel, i);
+  __syncthreads();
+  const gt_pack_desc d = descs[sel];
   pack_rows8(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, row - d.row_start,
              d.Cout, d.Cin, d.taps, d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, tile, scl);
 }

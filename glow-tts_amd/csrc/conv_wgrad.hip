@@ -49,11 +49,12 @@ __device__ __forceinline__ void wgrad_tile(
   const int padl = TAPS >> 1;
   const int mbeg = slab * slab_rows;
   const int mend = min(R, mbeg + slab_rows);
-  const bool do_bias = (ci0 == 0) && part_bias;                 // column sums of dY ride along as one more MFMA
+  const int wco = wave >> 1, wci = wave & 1;                    // this wave's 64 output channels / 32 input channels of the tile
+  const bool do_bias = (ci0 == 0) && part_bias && wci == 0;     // column sums of dY ride along as one more MFMA per co block
 
-  f32x16_t acc[TAPS][2], accb;
+  f32x16_t acc[TAPS][2], accb[2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) accb[e] = 0.0f;
+  for (int e = 0; e < 16; ++e) { accb[0][e] = 0.0f; accb[1][e] = 0.0f; }
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -108,18 +109,22 @@ __device__ __forceinline__ void wgrad_tile(
 #pragma unroll
     for (int ks = 0; ks < KB / 16; ++ks) {
       const int kb = ks * 16 + 8 * h;
-      // A: dY^T block (32 co of this wave) — rows kb..kb+7
-      const bf16_t* ya = ysb + (kb + q) * YP + wave * 32 + colhalf + 4 * p;
-      const bf16x8_t af = tr_frag(ya, ya + 4 * YP);
-      if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ones, accb, 0, 0, 0);
+      // wave (wco, wci) owns 64 output channels x 32 input channels x all taps: per k-step 2 dY^T fragments + TAPS X fragments for
+      // 2 * TAPS MFMAs (the first mapping — 32 co x 64 ci per wave — read 1 + 2 * TAPS fragments for the same MFMAs, and the
+      // transposing LDS reads, 2 per fragment, were the kernel's limit: 0.24 of the MFMA peak at k = 5)
+      bf16x8_t af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16_t* ya = ysb + (kb + q) * YP + wco * 64 + i * 32 + colhalf + 4 * p;
+        af[i] = tr_frag(ya, ya + 4 * YP);
+        if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
+        const bf16_t* xa = xsb + (kb + t + q) * XP + wci * 32 + colhalf + 4 * p;
+        const bf16x8_t bfg = tr_frag(xa, xa + 4 * XP);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bf16_t* xa = xsb + (kb + t + q) * XP + j * 32 + colhalf + 4 * p;
-          const bf16x8_t bfg = tr_frag(xa, xa + 4 * XP);
-          acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfg, acc[t][j], 0, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfg, acc[t][i], 0, 0, 0);
       }
     }
     if (has) WG_STORE(buf ^ 1);
@@ -130,24 +135,26 @@ __device__ __forceinline__ void wgrad_tile(
 
   // ---- slab partial: part[slab][tap][co][ci], lane = ci (128-byte rows per register)
   const int r = lane & 31;
+  const int ci = ci0 + wci * 32 + r;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ci = ci0 + j * 32 + r;
+    for (int i = 0; i < 2; ++i) {
       if (ci >= Cin) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (co < Ncols) part[(((size_t)slab * TAPS + t) * Cout + co_begin + co) * Cin + ci] = acc[t][j][e];
+        const int co = co0 + wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (co < Ncols) part[(((size_t)slab * TAPS + t) * Cout + co_begin + co) * Cin + ci] = acc[t][i][e];
       }
     }
   if (do_bias && r == 0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int co = co0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-      if (co < Ncols) part_bias[(size_t)slab * Cout + co_begin + co] = accb[e];
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wco * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (co < Ncols) part_bias[(size_t)slab * Cout + co_begin + co] = accb[i][e];
+      }
   }
 }
 

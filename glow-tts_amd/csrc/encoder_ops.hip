@@ -901,6 +901,15 @@ extern "C" int gt_mle_sums(const float* z, const float* m, const float* logs, fl
   hipLaunchKernelGGL(gt_mle_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, GT_ST(stream), z, m, logs, acc2, n);
   GT_RET();
 }
+__global__ void gt_mark_kernel(unsigned long long* slot) { *slot = (unsigned long long)wall_clock64(); }
+
+extern "C" int gt_mark(unsigned long long* slot, void* stream)
+{
+  if (!slot) return -1;
+  hipLaunchKernelGGL(gt_mark_kernel, dim3(1), dim3(1), 0, GT_ST(stream), slot);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int gt_length_mask(const void* lengths, int is_int64, float* mask, int B, int T, void* stream)
 {
   if (!lengths || !mask || B <= 0 || T <= 0) return GT_E_INVAL;

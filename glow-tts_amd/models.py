@@ -210,8 +210,11 @@ class _DecoderRunner:
             # squeeze of d z / unsqueeze of the input gradient inside the first / last launch of the backward chain
             dzc = dz.float().contiguous()
             dx = ops.zeros_big((B, C, T), torch.float32, dev)
+            ops.mark("dec bwd begin")
             with wgrad.WgradQueue(dev, site=dec):
                 _, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], None, dlogdet, self.has_cond, dz_bct=dzc, dx_bct=dx)
+                ops.mark("dec dgrad end")
+            ops.mark("dec wgrad end")
             return [dx] + (dconds if self.has_cond else []) + [grads.get(p) for p in self.params]
         drows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         if dz is None:

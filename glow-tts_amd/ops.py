@@ -99,6 +99,34 @@ def seed_word(device):
     return t
 
 
+class Marks:
+    """dev (bench.py --marks): named time marks inside the step, each one lane writing the device clock at that point of
+    the current stream — the replayed graph's real timeline (both branches), which rocprofv3 distorts by serialising."""
+
+    def __init__(self, device, n=256):
+        self.buf = torch.zeros(n, dtype=torch.int64, device=device)
+        self.names = []
+
+    def mark(self, name):
+        from . import _lib
+        k = len(self.names)
+        self.names.append(name)
+        _lib.check(_lib.lib().gt_mark(self.buf.data_ptr() + 8 * k, _lib.current_stream(self.buf.device)), "gt_mark")
+
+    def report(self):
+        t = self.buf[:len(self.names)].cpu().tolist()
+        t0 = min(v for v in t if v) if any(t) else 0
+        return sorted(((v - t0) / 100.0, n) for v, n in zip(t, self.names))           # microseconds since the first mark
+
+
+MARKS = None
+
+
+def mark(name):
+    if MARKS is not None:
+        MARKS.mark(name)
+
+
 def bump_seed(device):
     seed_word(device).add_(0x632BE5AB)           # odd constant: full-period walk over 2^32
 

@@ -192,6 +192,7 @@ class _TextEncoderRunner:
         if dxo is None and dx_m is None and (te.mean_only or dx_logs is None):
             return [None] * (len(self.params) + int(self.has_cond) + int(self.has_lang))
         from . import wgrad
+        ops.mark("enc bwd begin")
         with wgrad.WgradQueue(dev, site=te):
             if dx_m is not None:
                 d = rc.to_rows(dx_m.float(), torch.bfloat16)
@@ -210,6 +211,8 @@ class _TextEncoderRunner:
                     dvec = ops.cond_grad(rc, dx, dxb)
             if te.prenet:
                 dx, dxb = encoder_impl.crn_bwd(rc, te.pre, s_pre, dx, dxb, grads)
+            ops.mark("enc dgrad end")
+        ops.mark("enc wgrad end")
         tot, _ = encoder_impl._sum_grads_to_bf16(rc, dx, dxb, C)
         demb = ops.grad_accumulator(te.emb.weight)
         B, T = self.ids.shape
@@ -246,8 +249,10 @@ class _DurationRunner:
         d8[:, 0] = dlogw[:, 0].float()
         dout = rc.to_rows(d8)
         from . import wgrad
+        ops.mark("dp bwd begin")
         with wgrad.WgradQueue(rc.device, site=self.dp):
             dxb = encoder_impl.dp_bwd(rc, self.dp, saved, dout, grads, want_dx=self.has_cond)
+        ops.mark("dp bwd end")
         return ([ops.cond_grad(rc, dxb)] if self.has_cond else []) + [grads.get(p) for p in self.params]
 
 
@@ -617,6 +622,7 @@ class FlowGenerator(nn.Module):
         if (self.use_spp and pitch is None) or (self.use_sep and energy is None):
             raise ValueError("use_spp / use_sep: forward needs the pitch / energy contours (models.py:1057-1115)")
         self.prepare()
+        ops.mark("weights packed")
         self._step += 1
         if self.rows_cfg.ragged:
             lh = lengths_host if lengths_host is not None else (x_lengths.tolist(), y_lengths.tolist())
@@ -636,9 +642,12 @@ class FlowGenerator(nn.Module):
             enc_stream = _encoder_stream(x.device)
             enc_stream.wait_stream(main)
             with torch.cuda.stream(enc_stream):
+                ops.mark("enc fwd begin")
                 xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
+                ops.mark("enc fwd end")
                 if not self.use_sdp:
                     logw = self._predict_logw(g, l)   # needs the encoder's output only (x is detached, models.py:586): same branch
+                    ops.mark("dp fwd end")
         else:
             xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
         self._deferred = []
@@ -651,14 +660,18 @@ class FlowGenerator(nn.Module):
         y, y_lengths, y_max_length = self.preprocess(y, y_lengths, y.size(2))
         z_mask = ops.length_mask(y_lengths, y_max_length, x_mask.dtype)
         pitch_norm, energy_norm = self._contour(pitch, y_max_length), self._contour(energy, y_max_length)
+        ops.mark("dec fwd begin")
         z, logdet = self.decoder(y, z_mask, g=g, pitch=pitch_norm, energy=energy_norm, prepared=True)
+        ops.mark("dec fwd end")
         if fork:
             main.wait_stream(enc_stream)
+            ops.mark("fwd joined")
             for t_ in (xo, x_m, x_logs, x_mask, self.encoder._last_rows[1]) + ((logw,) if logw is not None else ()):
                 t_.record_stream(main)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             attn = mas.path.unsqueeze(1)
+        ops.mark("mas done")
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         rcx, xb = self.encoder._last_rows
         # The stochastic predictors need the alignment, but nothing after them does except the loss: they go onto the

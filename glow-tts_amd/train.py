@@ -383,18 +383,26 @@ class Trainer:
         from . import ops
         if self.stamps is not None:
             self.stamps.begin_step()
+        if ops.MARKS is not None:
+            ops.MARKS.names = []
+            ops.mark("step begin")
         ops.bump_seed(device)
         ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
         ops.big_begin(device)                    # ... and one for the partly written per-layer buffers (attention)
         self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
+        ops.mark("accumulators zeroed")
 
     def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
         self._begin(ids.device)
+        from . import ops
         loss, l_mle = self._loss(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {})))
+        ops.mark("loss")
         loss.backward()
+        ops.mark("backward joined")
         self.buckets.gather()
+        ops.mark("gradients gathered")
         return loss.detach(), l_mle.detach()
 
     def _optim(self, device):
@@ -402,6 +410,7 @@ class Trainer:
         # reference commons.clip_grad_value_(params, None): total grad norm, no clipping — the sum of squares
         # falls out of the optimizer's own pass over the gradients (no ~1.8k .item() syncs)
         self.grad_norm = torch.sqrt(self.opt.step())
+        ops.mark("optimizer done")
         if self.stamps is not None:
             self.stamps.end_step()
         ops.arena_end(device)

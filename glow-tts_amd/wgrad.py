@@ -26,6 +26,8 @@ assert JOB.itemsize == 64 and TILE.itemsize == 16 and WNB.itemsize == 96
 # rows x taps one workgroup reduces over: bigger = fewer slab partials (HBM traffic), smaller = more workgroups
 ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
 MAX_SLABS = 8
+FILL_TILES = int(os.environ.get("GT_WGRAD_FILL_TILES", "512"))      # dev knob
+FILL_MAX_SLABS = 32
 
 # ASYNC (process-level dev knob GT_WGRAD_ASYNC=1, read once at import; off by default): flush() launches on a side stream, so the batched weight-gradient kernels of the
 # decoder overlap with whatever the backward does next (the rest of the data-gradient chain, the text encoder's
@@ -163,10 +165,17 @@ class WgradQueue:
         off = 0
         row = 0
         max_n = 1
+        # slabs: the long jobs (the decoder's) are cut by rows x taps per tile; a launch whose jobs are few and short (the text
+        # encoder's 3 pre-net convs, the duration predictor's 2) would run a dozen workgroups that each walk all the rows — cut those
+        # finer (down to 128-row slabs) until the launch has FILL_TILES tiles
+        base = {5: 0, 3: 0, 1: 0}
+        for conv, R, parts, dv, dg, db in self.items:
+            base[conv.pc.taps] += sum(-(-cc // 128) * -(-conv.pc.Cin // 64) for _, _, _, cc in parts)
         for conv, R, parts, dv, dg, db in self.items:
             pc = conv.pc
             taps, Cin, Cout = pc.taps, pc.Cin, pc.Cout
             S = min(MAX_SLABS, max(1, round(R * taps / ROWTAPS)))
+            S = max(S, min(FILL_MAX_SLABS, -(-FILL_TILES // max(1, base[taps])), max(1, R // 128)))
             slab_rows = -(-(-(-R // S)) // 64) * 64
             S = -(-R // slab_rows)
             part_off, off = off, off + S * taps * Cout * Cin * 4

@@ -333,6 +333,9 @@ int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, 
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
                size_t n, const float* gdenom, float* dlogdet, int B, void* stream);
 /* commons.sequence_mask as floats: mask[b, t] = t < lengths[b] (lengths int32 or int64), [B, T] in one launch. */
+/* dev (bench.py --marks): one lane writes the device wall clock (100 MHz) to *slot — a time mark at this point of `stream`, valid
+ * inside a replayed HIP graph, where the profiler's serialisation would hide which branch is the critical one. */
+int gt_mark(unsigned long long* slot, void* stream);
 int gt_length_mask(const void* lengths, int is_int64, float* mask, int B, int T, void* stream);
 
 /* mle_loss's scalar tail (commons.py:31-33) in one launch: out2[0] = (acc2[0] + 0.5 acc2[1] - sum logdet) / denom + 0.5 log(2 pi),
