@@ -181,7 +181,7 @@ def fill_args(cls, **kw):
     return a
 
 
-GT_TILE_AUTO, GT_TILE_64x64, GT_TILE_64x128, GT_TILE_128x64, GT_TILE_128x128, GT_TILE_256x64 = 0, 1, 2, 3, 4, 5
+GT_TILE_AUTO, GT_TILE_64x64, GT_TILE_64x128, GT_TILE_128x64, GT_TILE_128x128, GT_TILE_256x64, GT_TILE_64x64_TAPS = 0, 1, 2, 3, 4, 5, 6
 GT_DT_F32, GT_DT_I32, GT_DT_F16, GT_DT_BF16, GT_DT_U8 = 0, 1, 2, 3, 4
 GT_ERRORS = {-1: "GT_E_INVAL", -2: "GT_E_UNSUPPORTED", -3: "GT_E_ALIGN", -4: "GT_E_LAUNCH"}
 

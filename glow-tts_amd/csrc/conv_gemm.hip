@@ -186,6 +186,108 @@ __global__ __launch_bounds__(256, BM == 256 ? 1 : 2) void gt_conv_gemm_kernel(Co
 }
 
 // ---------------------------------------------------------------------------------------
+// Short-and-deep variant: 64 rows x 64 channels, ALL taps of a K slice per pipeline stage.  The text encoder's k = 3 / k = 5
+// convs run a few hundred workgroups (at most one or two per CU) through up to 36 (slice, tap) steps of 4 MFMAs each: every
+// step then costs one L2 round trip that nothing hides (47 us for the 768 -> 192, k = 3 FFN conv whose MFMAs take 2 us).
+// One stage = the activation slice + the AT weight tiles of that slice, so the same loads are in flight AT at a time and
+// the step count falls to Kp / 64.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int AT>
+__global__ __launch_bounds__(256, AT == 3 ? 2 : 1) void gt_conv_gemm_taps_kernel(ConvArgs a)
+{
+  constexpr int BM = 64, BN = 64;
+  constexpr int XROWS = BM + MAXTAPS - 1;
+  constexpr int XCH = (XROWS * 8 + 255) / 256;                      // 3
+  constexpr int XS_HALFS = XROWS * LDP, WS_HALFS = BN * LDP;
+  constexpr int EP = BN + 4;
+  constexpr int MAIN_BYTES = 2 * (XS_HALFS + AT * WS_HALFS) * 2, EPI_BYTES = BM * EP * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES];
+  bf16_t (*Xs)[XS_HALFS] = reinterpret_cast<bf16_t (*)[XS_HALFS]>(smem);
+  bf16_t (*Ws)[WS_HALFS] = reinterpret_cast<bf16_t (*)[WS_HALFS]>(smem + 2 * XS_HALFS * 2);       // [stage * AT + tap]
+
+  if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int nct = a.Np / BN, nrt = (a.R + BM - 1) / BM;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int rt = xcd + 8 * (slot / nct), ct = slot - (slot / nct) * nct;
+  if (rt >= nrt) return;
+  const int n0 = ct * BN, m0 = rt * BM;
+  const int taps = a.taps, padl = taps >> 1;
+  const int NS = a.Kp / BK;
+  const int xrows = BM + taps - 1;
+
+  u32x4_t wr[AT][2], xr[XCH];
+  auto load_stage = [&](int slice) {
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+        if (t < taps) wr[t][i] = *reinterpret_cast<const u32x4_t*>(a.W + ((size_t)(t * a.Np + n0 + row) * a.Kp + slice * BK + c8 * 8));
+      }
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+      int gm = m0 - padl + (row < xrows ? row : xrows - 1);
+      gm = gm < 0 ? 0 : (gm >= a.R ? a.R - 1 : gm);
+      const int ch = slice * BK + c8 * 8;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (ch < a.Cin) v = *reinterpret_cast<const u32x4_t*>(a.X + (size_t)gm * a.ldx + ch);
+      xr[i] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+        if (t < taps) *reinterpret_cast<u32x4_t*>(&Ws[buf * AT + t][row * LDP + c8 * 8]) = wr[t][i];
+      }
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+      const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
+      if (row < xrows) *reinterpret_cast<u32x4_t*>(&Xs[buf][row * LDP + c8 * 8]) = xr[i];
+    }
+  };
+
+  f32x16_t acc[1][1];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+
+  load_stage(0); store_stage(0);
+  __syncthreads();
+  const int mrow0 = wm * 32;
+  for (int s = 0; s < NS; ++s) {
+    const bool has = s + 1 < NS;
+    if (has) load_stage(s + 1);
+#pragma unroll
+    for (int t = 0; t < AT; ++t) {
+      if (t < taps) {
+        const bf16_t* wsb = &Ws[(s & 1) * AT + t][(32 * wn + r) * LDP + 8 * h];
+        const bf16_t* xsb = &Xs[s & 1][(mrow0 + r + t) * LDP + 8 * h];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks)
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(wsb + ks * 16),
+                                                              *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16), acc[0][0], 0, 0, 0);
+      }
+    }
+    if (has) store_stage((s + 1) & 1);
+    __syncthreads();
+  }
+  float* es = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<float4*>(&es[(mrow0 + r) * EP + 32 * wn + 8 * g + 4 * h]) =
+        make_float4(acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]);
+  __syncthreads();
+  gtconv::epilogue_plain<256, BM, BN>(a, es, EP, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------
 // Weight preparation: (optional) weight-norm w = g * v / ||v|| (torch weight_norm dim=0, the
 // reference's modules.py:127,132,141 / attentions.py:103), then bf16 packing into
 //   fwd   Pf[tap][pn(co)][ci]              (pn = gate interleave or identity)
@@ -278,6 +380,9 @@ __device__ __forceinline__ void pack_rows8(
     for (int j = 0; j < PK8_MAXN / 256; ++j) {
       const int i = lane + 64 * j;
       x[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef PK_EXP
+      if (PK_EXP & 4) { x[k][j] = make_float4(0.001f * i, 0.5f, 0.25f, 1.f); continue; }
+#endif
       if (i < n4) {
         if (al) x[k][j] = *reinterpret_cast<const float4*>(vr + 4 * i);
         else    x[k][j] = make_float4(vr[4 * i], vr[4 * i + 1], vr[4 * i + 2], vr[4 * i + 3]);
@@ -310,6 +415,10 @@ __device__ __forceinline__ void pack_rows8(
   __syncthreads();
   const bool ffrag = gate & 2, dfrag = gate & 4;
   const int C8 = Cin >> 3;
+#ifdef PK_EXP
+  if (PK_EXP & 1) Pf = nullptr;
+  if (PK_EXP & 2) Pd = nullptr;
+#endif
   if (Pf) {
     for (int q = tid; q < 8 * taps * C8; q += 256) {
       // the 8 rows of the group are the fastest index: their 16-byte pieces are neighbours in the packed image (whole 128-byte lines per store)
@@ -392,7 +501,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if (((uintptr_t)X | (uintptr_t)Wp | (uintptr_t)Y) & 15) return GT_E_ALIGN;
   if (addend && (ldadd & 3)) return GT_E_ALIGN;
   if (cond && (Tp <= 0 || (row0 && B <= 0))) return GT_E_INVAL;
-  if (tile < GT_TILE_AUTO || tile > GT_TILE_256x64) return GT_E_INVAL;
+  if (tile < GT_TILE_AUTO || tile > GT_TILE_64x64_TAPS) return GT_E_INVAL;
   if (Np % 64 || Np < N) return GT_E_INVAL;
   ConvArgs a;
   a.X = static_cast<const bf16_t*>(X); a.ldx = ldx; a.W = static_cast<const bf16_t*>(Wp); a.bias = bias;
@@ -432,6 +541,15 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
   if (tile == GT_TILE_AUTO) {
     const bool short_rows = ((R + 127) / 128) * (Np / bnsel) <= SHORT_TILE_MAX_WGS;
     tile = short_rows ? (bnsel == 128 ? GT_TILE_64x128 : GT_TILE_64x64) : (bnsel == 128 ? GT_TILE_128x128 : GT_TILE_128x64);
+    // short AND deep (the text encoder's k = 3 FFN / k = 5 pre-net convs): all taps of a K slice per pipeline stage
+    if (short_rows && taps > 1 && gate != 1 && ((R + 63) / 64) * (Np / 64) <= 4 * SHORT_TILE_MAX_WGS) tile = GT_TILE_64x64_TAPS;
+  }
+  if (tile == GT_TILE_64x64_TAPS) {
+    if (gate == 1) return GT_E_INVAL;
+    const dim3 grid_t(8 * (((R + 63) / 64 + 7) / 8) * (Np / 64));
+    if (taps <= 3) hipLaunchKernelGGL(gt_conv_gemm_taps_kernel<3>, grid_t, block, 0, st, a);
+    else           hipLaunchKernelGGL(gt_conv_gemm_taps_kernel<5>, grid_t, block, 0, st, a);
+    return gt_launch_status(__func__);
   }
   const int bm = (tile == GT_TILE_64x64 || tile == GT_TILE_64x128) ? 64 : (tile == GT_TILE_256x64 ? 256 : 128);
   const int bn = (tile == GT_TILE_64x128 || tile == GT_TILE_128x128) ? 128 : 64;

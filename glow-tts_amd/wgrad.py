@@ -28,6 +28,7 @@ ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
 MAX_SLABS = 8
 FILL_TILES = int(os.environ.get("GT_WGRAD_FILL_TILES", "512"))      # dev knob
 FILL_MAX_SLABS = 32
+XCDS = 8
 
 # ASYNC (process-level dev knob GT_WGRAD_ASYNC=1, read once at import; off by default): flush() launches on a side stream, so the batched weight-gradient kernels of the
 # decoder overlap with whatever the backward does next (the rest of the data-gradient chain, the text encoder's
@@ -278,13 +279,23 @@ class WgradQueue:
             for taps in (5, 3, 1):
                 n = 0
                 order = sorted(range(len(tiles[taps])), key=lambda i: -tiles[taps][i][0])       # heavy tiles first
+                # XCD-aware order: workgroup i of a launch lands on XCD i % 8 (each XCD has its own L2).  The nco x nci tiles of one
+                # (job, slab) read the same dY / X rows — nci tiles share every dY block, nco tiles every X block — so they are dealt
+                # to ONE XCD (consecutive slots of its queue); dealt round-robin, each of them pulled its own copy over the fabric
+                # (3x the bytes for the decoder's 384 x 192 convs).
+                queues = [[] for _ in range(XCDS)]
                 for i in order:
                     _, jid, nco, nci, S = tiles[taps][i]
-                    g = np.stack(np.meshgrid(np.arange(nco) * 128, np.arange(nci) * 64, np.arange(S), indexing="ij"), -1).reshape(-1, 3)
-                    t = np.zeros(len(g), dtype=TILE)
-                    t["job"], t["co0"], t["ci0"], t["slab"] = jid, g[:, 0], g[:, 1], g[:, 2]
+                    for sl in range(S):
+                        q = min(queues, key=len)
+                        q += [(jid, co * 128, ci * 64, sl) for co in range(nco) for ci in range(nci)]
+                flat = [q[pos] for pos in range(max(map(len, queues), default=0)) for q in queues if pos < len(q)]
+                if flat:
+                    t = np.zeros(len(flat), dtype=TILE)
+                    a = np.array(flat, dtype=np.int64)
+                    t["job"], t["co0"], t["ci0"], t["slab"] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
                     tl.append(t)
-                    n += len(g)
+                    n = len(flat)
                 counts.append(n)
             ta = np.concatenate(tl) if tl else np.zeros(1, dtype=TILE)
             cache["skey"], cache["tiles"], cache["counts"] = skey, upload(ta), counts

@@ -128,6 +128,7 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
 #define GT_TILE_128x64 3
 #define GT_TILE_128x128 4
 #define GT_TILE_256x64 5
+#define GT_TILE_64x64_TAPS 6   /* 64 x 64, all taps of a K slice per pipeline stage (short, deep convs; no gate) */
 int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const float* bias,
                       const float* cond, int ldc, const float* rowmask,
                       void* Y, int ldy, int out_f32, const void* addend, int ldadd,

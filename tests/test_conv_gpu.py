@@ -159,12 +159,14 @@ def test_gate_backward_epilogue_replays_forward_dropout(built):
     assert (nz_s & ~keep_s).float().mean().item() < 0.01 and (~nz_s & keep_s & keep_t).float().mean().item() < 0.02
 
 
-TILES = {"64x64": 1, "64x128": 2, "128x64": 3, "128x128": 4, "256x64": 5}
+TILES = {"64x64": 1, "64x128": 2, "128x64": 3, "128x128": 4, "256x64": 5, "64x64taps": 6}
 
 
 @pytest.mark.parametrize("Cin,Cout,k,tile,big", [
     (192, 192, 1, "64x64", False), (192, 192, 1, "128x64", False), (192, 768, 3, "64x128", False), (192, 768, 3, "128x128", False),
     (384, 192, 5, "128x64", False), (192, 160, 1, "128x64", False), (80, 192, 1, "64x64", False),
+    # all taps of a K slice per stage (the text encoder's short, deep convs): k = 3 / k = 5 / k = 1, ragged channel counts
+    (768, 192, 3, "64x64taps", False), (192, 768, 3, "64x64taps", False), (192, 192, 5, "64x64taps", False), (80, 160, 1, "64x64taps", False),
     # R >= 11k rows: what the library's own choice runs at cfg 2's skip GEMM and at every larger batch
     (192, 192, 1, "auto", True), (768, 192, 1, "auto", True), (192, 768, 3, "auto", True), (192, 192, 5, "128x64", True)])
 def test_conv_every_tile_variant_matches_torch(built, Cin, Cout, k, tile, big):
