@@ -21,6 +21,7 @@ struct ConvArgs {
   const uint32_t* seed_dev;                            // optional device word XOR-ed into drop_seed (graph replay)
   int exp_;                                            // EXPERIMENT bits (dev only)
   int y16;                                             // Y rows allow 16-byte bf16 stores (ldy % 8 == 0, base 16-B aligned)
+  int maskbwd;                                         // epilogue = ReLU / dropout backward: Tout is the SAVED activation, Y = acc * scale where it is non-zero
   int gatebwd;                                         // epilogue = WaveNet-gate backward: Tout/Sout are the SAVED tanh/sigmoid, Y = d pre [R, 2N]
 };
 
@@ -104,6 +105,7 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, const float* e
         tsq[j][0] = *reinterpret_cast<const uint4*>(a.Tout + (size_t)m * a.ldts + n);
         tsq[j][1] = *reinterpret_cast<const uint4*>(a.Sout + (size_t)m * a.ldts + n);
       }
+      if (a.maskbwd) tsq[j][0] = *reinterpret_cast<const uint4*>(a.Tout + (size_t)m * a.ldts + n);
       if (a.addend) {
         if (a.out_f32) {
           const float* ap = static_cast<const float*>(a.addend) + (size_t)m * a.ldadd + n;
@@ -158,6 +160,12 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgs& a, const float* e
     const float rm = rmq[j];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (v[i] + ad[i]) * rm;
+    if (a.maskbwd) {
+      // backward of y = dropout(relu(.)) (attentions.py:368-370, modules.py:97-99) from the saved y: kept and positive <=> y != 0
+      const uint32_t yw[4] = {tsq[j][0].x, tsq[j][0].y, tsq[j][0].z, tsq[j][0].w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ((yw[i >> 1] >> (16 * (i & 1))) & 0x7fff) ? v[i] * a.drop_scale : 0.0f;
+    }
     if (a.gatebwd) {
       // v = d acts.  d pre_t = d*S*(1-T^2), d pre_s = d*T*S*(1-S), times the replayed dropout mask of the conv
       // output (modules.py:153-156 backward); natural [tanh half | sigmoid half] order, N % 8 == 0.

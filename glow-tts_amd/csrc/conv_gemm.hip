@@ -517,6 +517,7 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
 #endif
   a.drop_thresh = 0; a.drop_seed = drop_seed; a.drop_scale = 1.0f; a.seed_dev = seed_dev;
   a.gatebwd = (gate == 2); a.gb_thresh = 0;
+  a.maskbwd = (gate == 3);
   if (drop_p > 0.0f) {
     if (drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     a.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0); a.drop_scale = 1.0f / (1.0f - drop_p);
@@ -525,6 +526,11 @@ extern "C" int gt_conv_gemm_bf16(const void* X, int ldx, const void* Wp, const f
     if (!gate_t || !gate_s || out_f32 || relu || (N & 7) || (ldts & 7) || (ldy & 7)) return GT_E_INVAL;
     if (((uintptr_t)gate_t | (uintptr_t)gate_s) & 15) return GT_E_ALIGN;
     a.gb_thresh = a.drop_thresh; a.drop_thresh = 0;
+  }
+  if (a.maskbwd) {                            // the scale 1 / (1 - p) of the forward's dropout is replayed; no fresh mask is drawn
+    if (!gate_t || out_f32 || relu || (N & 7) || (ldts & 7) || (ldy & 7)) return GT_E_INVAL;
+    if ((uintptr_t)gate_t & 15) return GT_E_ALIGN;
+    a.drop_thresh = 0;
   }
   if (gate == 1) {                            // gate: N = Np = 2 * half, [32 tanh | 32 sigmoid] per 64 packed rows, 128-column tiles
     if (!gate_t || !gate_s || (N & 127) || Np != N || out_f32) return GT_E_INVAL;

@@ -104,8 +104,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
       if (c < p.C) {
         float v = p.a ? p.a[(size_t)m * p.C + c] : 0.f;
         if (p.y) {
-          float yy = bf2f(p.y[(size_t)m * p.ldy + c]);
+          const bf16_t yraw = p.y[(size_t)m * p.ldy + c];
+          float yy = bf2f(yraw);
           if (p.din_thresh) { keep_in[k] = drop_keep(p.din_seed, m, c, p.din_thresh); yy = keep_in[k] ? yy * p.din_scale : 0.f; }
+          if ((p.relu & 2) && !(yraw & 0x7fff)) keep_in[k] = false;      // y is a ReLU's output: no gradient through its zeros
           v += yy;
         }
         xh[k] = (v - mean) * rstd;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
         if (q.dout_bf16) d += bf2f(q.dout_bf16[(size_t)m * q.lddo + c]);
         d *= rm;
         if (p.dout_thresh) d = drop_keep(p.dout_seed, m, c, p.dout_thresh) ? d * p.dout_scale : 0.f;
-        if (p.relu && (xh[k] * p.gamma[c] + p.beta[c]) <= 0.f) d = 0.f;
+        if ((p.relu & 1) && (xh[k] * p.gamma[c] + p.beta[c]) <= 0.f) d = 0.f;
         accg[k] += d * xh[k]; accb[k] += d;
         dn[k] = d * p.gamma[c];
         s1 += dn[k]; s2 += dn[k] * xh[k];
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
       if (c < p.C) {
         const float ds = rstd * (dn[k] - s1 - xh[k] * s2);
         if (q.da) q.da[(size_t)m * p.C + c] = ds;
-        if (q.dy) q.dy[(size_t)m * q.lddy + c] = f2bf(p.din_thresh ? (keep_in[k] ? ds * p.din_scale : 0.f) : ds);
+        if (q.dy) q.dy[(size_t)m * q.lddy + c] = f2bf((p.din_thresh || (p.relu & 2)) ? (keep_in[k] ? ds * p.din_scale : 0.f) : ds);
       }
     }
   }
@@ -509,15 +511,30 @@ __global__ __launch_bounds__(256) void gt_logp_kernel(const float* __restrict__ 
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   float rowc = 0.f;                                       // logp1 + logp4 of row i (lanes kh==0 and kh==1 split d)
-  for (int d = 0; d < C; d += 2) {
-    const int dd = d + kh;                                // this lane's k index
-    float m = 0.f, s = 0.f, zz = 0.f;
-    if (i < Tx) { m = xmb[(size_t)dd * Tx + i]; if (xsb) s = xsb[(size_t)dd * Tx + i]; }
-    if (j < Ty) zz = zb[(size_t)dd * Ty + j];
-    const float e2 = xsb ? __expf(-2.0f * s) : 1.0f;
-    rowc += -0.9189385332046727f - s - 0.5f * m * m * e2;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e2, -0.5f * zz * zz, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(m * e2, zz, acc, 0, 0, 0);
+  // 8 k-pairs per trip with their loads issued together: one trip = one memory round trip for 16 MFMAs (a load / MFMA pair per
+  // trip left the wave waiting on 80 dependent round trips: 33 us for a lattice whose MFMAs take 4)
+  constexpr int U = 8;
+  for (int d0 = 0; d0 < C; d0 += 2 * U) {
+    float m[U], sv[U], zz[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int dd = d0 + 2 * u + kh;                     // this lane's k index
+      m[u] = 0.f; sv[u] = 0.f; zz[u] = 0.f;
+      if (dd < C) {
+        if (i < Tx) { m[u] = xmb[(size_t)dd * Tx + i]; if (xsb) sv[u] = xsb[(size_t)dd * Tx + i]; }
+        if (j < Ty) zz[u] = zb[(size_t)dd * Ty + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = d0 + 2 * u + kh < C;
+      const float e2 = xsb ? __expf(-2.0f * sv[u]) : 1.0f;
+      if (in) rowc += -0.9189385332046727f - sv[u] - 0.5f * m[u] * m[u] * e2;
+      if (d0 + 2 * u < C) {                                 // wave-uniform (C is even): whole k pairs only
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? e2 : 0.f, -0.5f * zz[u] * zz[u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? m[u] * e2 : 0.f, zz[u], acc, 0, 0, 0);
+      }
+    }
   }
   rowc += __shfl_xor(rowc, 32);                           // both k halves -> full sum over d, indexed by r = row i0+r
   // C/D layout: col = lane&31 (= j), row = (e&3) + 8*(e>>2) + 4*kh (= i offset)

@@ -36,7 +36,9 @@ def _ln_fwd(rc, ln, a, y, p_in, seed_in, p_out, seed_out, relu, want_f32, C):
     return out_f32, out_bf, (a, y, mean, rstd, p_in, seed_in, p_out, seed_out, relu, C)
 
 
-def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads):
+def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads, relu_in=False):
+    """relu_in: the bf16 input y is a ReLU's output (conv -> relu -> norm, models.py:591-598): dy is zeroed where y is zero, i.e.
+    the ReLU's backward rides along instead of a launch of its own."""
     L = _lib.lib()
     a, y, mean, rstd, p_in, seed_in, p_out, seed_out, relu, C = saved
     R = rc.R
@@ -47,7 +49,7 @@ def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads):
     db = grad_accumulator(ln.beta, (C,))
     _lib.check(L.gt_layernorm_bwd(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
                                   _lib.ptr(rc.rowmask), _lib.ptr(mean), _lib.ptr(rstd), R, C, LN_EPS,
-                                  float(p_in), int(seed_in), float(p_out), int(seed_out), int(relu),
+                                  float(p_in), int(seed_in), float(p_out), int(seed_out), int(bool(relu)) | (2 if relu_in else 0),
                                   _lib.ptr(seed_word(dev)) if (p_in > 0 or p_out > 0) else None,
                                   _lib.ptr(dout_f32), _lib.ptr(dout_bf), 0 if dout_bf is None else dout_bf.stride(0),
                                   _lib.ptr(da), _lib.ptr(dy), C, _lib.ptr(dg), _lib.ptr(db), _st(dev)), "gt_layernorm_bwd")
@@ -132,10 +134,8 @@ def layer_bwd(rc, enc, i, saved, dx, dxb, grads):
     dev = rc.device
     dx1, df2 = _ln_bwd(rc, enc.norm_layers_2[i], s_ln2, dx, dxb, True, True, grads)
     grads.update(conv_param_grads(ffn.conv_2, f1, df2, R))
-    df1 = conv_rows(df2, ffn.conv_2.pc, rc, dgrad=True)
-    dc1 = torch.empty_like(df1)
-    _lib.check(L.gt_relu_drop_bwd(_lib.ptr(df1), df1.stride(0), _lib.ptr(f1), f1.stride(0), _lib.ptr(dc1), dc1.stride(0),
-                                  R, f1.shape[1], float(p), _st(dev)), "gt_relu_drop_bwd")
+    # d conv_2's input, then the backward of dropout(relu(.)) from the saved activation — in the GEMM's epilogue
+    dc1 = conv_rows(df2, ffn.conv_2.pc, rc, dgrad=True, gate=3, gate_t=f1, drop_p=float(p))
     grads.update(conv_param_grads(ffn.conv_1, xb1, dc1, R))
     dxb1 = conv_rows(dc1, ffn.conv_1.pc, rc, dgrad=True)
     dx0, dy = _ln_bwd(rc, enc.norm_layers_1[i], s_ln1, dx1, dxb1, True, True, grads)
@@ -224,13 +224,9 @@ def dp_bwd(rc, dp, saved, dout, grads, want_dx=False):
     grads[dp.proj.weight] = g[dp.proj_pad.weight][:1].contiguous()
     grads[dp.proj.bias] = g[dp.proj_pad.bias][:1].contiguous()
     dh2 = conv_rows(db, dp.proj_pad.pc, rc, dgrad=True)
-    _, dc2 = _ln_bwd(rc, dp.norm_2, s2, None, dh2, False, True, grads)
-    dr2 = torch.empty_like(dc2)
-    _lib.check(L.gt_relu_drop_bwd(_lib.ptr(dc2), F, _lib.ptr(c2), F, _lib.ptr(dr2), F, R, F, 0.0, _st(dev)), "gt_relu_drop_bwd")
+    _, dr2 = _ln_bwd(rc, dp.norm_2, s2, None, dh2, False, True, grads, relu_in=True)      # through the norm AND the ReLU before it
     grads.update(conv_param_grads(dp.conv_2, h1, dr2, R))
     dh1 = conv_rows(dr2, dp.conv_2.pc, rc, dgrad=True)
-    _, dc1 = _ln_bwd(rc, dp.norm_1, s1, None, dh1, False, True, grads)
-    dr1 = torch.empty_like(dc1)
-    _lib.check(L.gt_relu_drop_bwd(_lib.ptr(dc1), F, _lib.ptr(c1), F, _lib.ptr(dr1), F, R, F, 0.0, _st(dev)), "gt_relu_drop_bwd")
+    _, dr1 = _ln_bwd(rc, dp.norm_1, s1, None, dh1, False, True, grads, relu_in=True)
     grads.update(conv_param_grads(dp.conv_1, xb, dr1, R))
     return conv_rows(dr1, dp.conv_1.pc, rc, dgrad=True) if want_dx else None

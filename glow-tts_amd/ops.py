@@ -545,7 +545,7 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
     else:
         N, Cin, Np, Kp, W = pc.Cout, km * pc.Cin, pc.Np_f, pc.Kp_f, pc.fwd
     assert x.shape[1] >= Cin, (x.shape, Cin)
-    n_out = N // 2 if gate is True or gate == 1 else (2 * N if gate == 2 else N)
+    n_out = N // 2 if gate is True or gate == 1 else (2 * N if gate == 2 else N)      # gate == 3: ReLU / dropout backward from the saved y (gate_t)
     if out is None:
         out = torch.empty(R, n_out, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     out_f32 = out.dtype == torch.float32
@@ -561,7 +561,7 @@ def conv_rows(x, pc, ctx, *, dgrad=False, bias=None, cond=None, mask=False, out=
                              _lib.ptr(addend), 0 if addend is None else addend.stride(0),
                              _lib.ptr(gate_t), _lib.ptr(gate_s), 0 if gate_t is None else gate_t.stride(0),
                              R, N, Cin, pc.taps, ctx.Tp, Np, Kp, int(relu), int(gate), float(drop_p), int(seed),
-                             _lib.ptr(seed_word(x.device)) if drop_p > 0 else None,
+                             _lib.ptr(seed_word(x.device)) if (drop_p > 0 and gate != 3) else None,
                              _lib.ptr(ctx.row0) if (cond is not None and not cond_per_row) else None,
                              0 if cond_per_row else ctx.B, int(tile), _lib.current_stream(x.device))
     KERNEL_TIMER.stop(_ev)

@@ -115,6 +115,9 @@ int gt_mas_lengths_from_mask_f32(const float* mask, int32_t* t_x, int32_t* t_y,
  *   gate == 2 (backward of that gate fused behind a data-gradient GEMM): d = acc + addend is d(T*S);
  *     gate_t / gate_s are the SAVED T / S (read-only); Y is [R, 2N] bf16: Y[m, n] = d*S*(1-T^2), Y[m, N+n] =
  *     d*T*S*(1-S), both times the forward's dropout mask (drop_p / drop_seed as given to the forward call).
+ *   gate == 3 (backward of y = dropout(relu(.)), attentions.py:368-370 / modules.py:97-99, fused behind a data-gradient
+ *     GEMM): gate_t is the SAVED y ([R, ldts] bf16, read-only; gate_s unused); Y[m, n] = (acc + addend) / (1 - drop_p)
+ *     where y[m, n] != 0, else 0 (bf16; N%8, ldts%8, ldy%8 == 0).  No mask is drawn: drop_p only gives the scale.
  *   Wp: weights packed by gt_pack_conv_weights ([taps][Np][Kp] bf16, zero padded).
  * Dropout masks are a counter-based hash of (seed, row, col), replayed by the backward kernels.
  * seed_dev (here and in every entry point that takes it; may be NULL) is a device uint32 XOR-ed into the
@@ -262,7 +265,9 @@ int gt_rows_f32_to_bf16(const float* in, int ldi, void* out, int ldo, const floa
  * surrounding elementwise work fused (attentions.py:79-84, modules.py:95-102, models.py:598-607):
  *   s = a (fp32, optional) + dropout_in(y (bf16, optional));  n = LN(s)*gamma + beta;
  *   o = dropout_out(relu?(n)) * rowmask;  out_f32 / out_bf16 (either optional).  C <= 256.
- * Dropout masks are counter-based (seed) and replayed by the backward. dgamma/dbeta ACCUMULATE. */
+ * Dropout masks are counter-based (seed) and replayed by the backward. dgamma/dbeta ACCUMULATE.
+ * gt_layernorm_bwd: relu bit 0 = the forward's relu flag; bit 1 (value 2) = y is itself a ReLU's output (conv -> relu -> norm,
+ * models.py:591-598): dy is zeroed where y == 0, so the ReLU's backward needs no launch of its own. */
 int gt_layernorm_fwd(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                      float* out_f32, void* out_bf16, int ldo, float* mean, float* rstd, int R, int C, float eps,
                      float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev, void* stream);
