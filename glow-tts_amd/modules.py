@@ -189,8 +189,10 @@ class _PackPlan:
                        "gt_pack_conv_weights_multi")
 
 
-def prepare_all(module):
-    """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step."""
+def prepare_all(module, side=None):
+    """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step.
+    side: a stream that already follows the current one (train.Trainer: the encoder's branch, with the step's accumulator fills
+    on it): the small gathers of the derived biases go there, beside the packing launch, and the current stream joins it at the end."""
     wns, mhas = [], []
     for m in module.modules():
         if isinstance(m, WN):
@@ -199,12 +201,20 @@ def prepare_all(module):
             mhas.append(m)
         elif hasattr(m, "_refresh_padded"):
             m._refresh_padded()
-    with torch.no_grad():
+    import contextlib
+    with torch.no_grad(), (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
         # derived biases of every WN (sum of the layers' skip biases) and every attention layer (q | k | v): ONE
         # gather + ONE reduction for the whole model instead of two small launches per module
+        # (into PERSISTENT buffers: a captured step that leaves the packing to the trainer — FlowGenerator.external_prepare —
+        # has their addresses baked into its kernel arguments)
+        keep = module.__dict__.setdefault("_derived_bias", {})
         if wns and all(w.n_layers == wns[0].n_layers and w.hidden_channels == wns[0].hidden_channels for w in wns):
             H, n = wns[0].hidden_channels, wns[0].n_layers
-            sb = torch.cat([rs.bias[-H:] for w in wns for rs in w.res_skip_layers]).view(len(wns), n, H).sum(1)
+            dev = wns[0].res_skip_layers[0].bias.device
+            sb = keep.get("skip")
+            if sb is None or sb.shape != (len(wns), H) or sb.device != dev:
+                sb = keep["skip"] = torch.empty(len(wns), H, device=dev)
+            torch.sum(torch.cat([rs.bias[-H:] for w in wns for rs in w.res_skip_layers]).view(len(wns), n, H), 1, out=sb)
             for w, row in zip(wns, sb):
                 w.skip_bias = row
         else:
@@ -212,7 +222,11 @@ def prepare_all(module):
                 w._refresh_padded()
         if mhas:
             C = mhas[0].channels
-            qb = torch.cat([c.bias for a in mhas for c in (a.conv_q, a.conv_k, a.conv_v)]).view(len(mhas), 3 * C)
+            dev = mhas[0].conv_q.bias.device
+            qb = keep.get("qkv")
+            if qb is None or qb.shape != (len(mhas), 3 * C) or qb.device != dev:
+                qb = keep["qkv"] = torch.empty(len(mhas), 3 * C, device=dev)
+            torch.cat([c.bias for a in mhas for c in (a.conv_q, a.conv_k, a.conv_v)], out=qb.view(-1))
             for a, row in zip(mhas, qb):
                 a.qkv_bias = row
     plan = getattr(module, "_pack_plan", None)
@@ -232,6 +246,8 @@ def prepare_all(module):
         plan = _PackPlan(module)
         object.__setattr__(module, "_pack_plan", plan)
     plan.run()
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
 
 
 class _RowsFn(torch.autograd.Function):

@@ -581,9 +581,9 @@ class FlowGenerator(nn.Module):
         if pend:
             torch.autograd.backward([s for s, _ in pend], [g for _, g in pend])
 
-    def prepare(self):
-        """Re-pack every conv weight for the MFMA kernels (once per optimizer step)."""
-        prepare_all(self)
+    def prepare(self, side=None):
+        """Re-pack every conv weight for the MFMA kernels (once per optimizer step).  side: see modules.prepare_all."""
+        prepare_all(self, side)
         if not self.use_sdp:
             self.encoder.proj_w.prepare_extra()
 
@@ -621,7 +621,10 @@ class FlowGenerator(nn.Module):
         assert (g is None) == (self.gin_channels == 0), "a speaker / conditioning vector is required exactly when gin_channels != 0"
         if (self.use_spp and pitch is None) or (self.use_sep and energy is None):
             raise ValueError("use_spp / use_sep: forward needs the pitch / energy contours (models.py:1057-1115)")
-        self.prepare()
+        if self.__dict__.pop("_prepared_by_trainer", False):
+            pass                                                   # train.Trainer._begin packed beside its accumulator fills
+        else:
+            self.prepare()
         ops.mark("weights packed")
         self._step += 1
         if self.rows_cfg.ragged:

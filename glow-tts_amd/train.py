@@ -11,6 +11,7 @@ import json
 import math
 import os
 
+import contextlib
 import torch
 import torch.distributed as dist
 
@@ -387,11 +388,22 @@ class Trainer:
             ops.MARKS.names = []
             ops.mark("step begin")
         ops.bump_seed(device)
-        ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
-        ops.big_begin(device)                    # ... and one for the partly written per-layer buffers (attention)
-        self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
+        # The step's head: three accumulator fills, the gathers of the derived biases and the weight-packing launch, all before
+        # either branch can start.  Only the packing is long (~100 us): the rest runs beside it on the encoder's stream.
+        from . import text_models
+        side = None
+        if device.type == "cuda" and text_models.ENCODER_STREAM and hasattr(self.model, "prepare"):
+            side = text_models._encoder_stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
+            ops.big_begin(device)                    # ... and one for the partly written per-layer buffers (attention)
+            self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
+        if side is not None:
+            self.model.prepare(side=side)            # joins `side` at its end
+            self.model._prepared_by_trainer = True
         ops.mark("accumulators zeroed")
 
     def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
