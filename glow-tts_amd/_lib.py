@@ -212,8 +212,34 @@ def lib():
                 raise HipLibraryMissing(f"{LIB_PATH} does not export {name}; rebuild it") from e
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("GT_TRACE_CALLS"):
+            L = _Traced(L, os.environ["GT_TRACE_CALLS"])
         _LIB = L
     return _LIB
+
+
+class _Traced:
+    """dev (GT_TRACE_CALLS=<file>): the name of every C-ABI entry is written to the file BEFORE the call and the device is
+    synchronised after it — after a GPU memory fault (which kills the process) the file names the launch that faulted."""
+
+    def __init__(self, L, path):
+        self._L, self._f, self._n = L, open(path, "w"), 0
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+        if not name.startswith("gt_"):
+            return fn
+
+        def call(*a):
+            import torch
+            self._n += 1
+            self._f.seek(0); self._f.write(f"{self._n} {name}".ljust(96) + "\n"); self._f.flush()
+            rc = fn(*a)
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+            self._f.seek(0); self._f.write(f"{self._n} {name} returned".ljust(96) + "\n"); self._f.flush()
+            return rc
+        return call
 
 
 def check(rc, what):

@@ -52,6 +52,7 @@ def _fill_pool():
 
 
 _PENDING_UPLOADS = []        # (device table, pinned host copy) of the flushes recorded by the graph capture in progress
+_SCRATCH_RETIRED = []
 _TABLE_ARENA = {}            # device -> {"buf", "off"}: where a capture's tables live (see _flush)
 
 
@@ -105,7 +106,11 @@ def _scratch(dev, nbytes):
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None and buf.is_cuda:
-            buf.record_stream(torch.cuda.current_stream(dev))       # kernels of an earlier flush may still read it
+            # A captured step has the address of the buffer it was captured with baked into its kernel arguments, and a later
+            # capture (another row bucket, more slabs) may need a bigger one: the outgrown buffer must stay allocated for as long as
+            # any graph can replay into it — freed, its pages go back to the allocator and the next replay of the older graph
+            # writes its partial sums over whoever owns them then.  They are few (one growth per bucket shape at most).
+            _SCRATCH_RETIRED.append(buf)
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _SCRATCH[key] = buf
     return buf

@@ -366,3 +366,18 @@ def test_two_trainers_in_one_process_do_not_interfere(built):
     for got, want in ((ma, ref_a), (mb, ref_b)):
         worst = max((a - b).abs().max().item() for a, b in zip(got.parameters(), want.parameters()))
         assert worst < 1e-5, worst
+
+
+def test_wgrad_workspace_outgrown_by_a_later_capture_stays_allocated(built):
+    """The partial-sum workspace of the batched weight-gradient launches is shared by every captured step of a stream, and a
+    captured step has its address baked in.  When a later row bucket needs a bigger one, the outgrown buffer must not go back to
+    the allocator: the older graphs still replay into it (cfg 3 faulted with 'write access to a read-only page' when it did)."""
+    from glow_tts_amd import wgrad
+    with torch.cuda.stream(torch.cuda.Stream()):
+        a = wgrad._scratch(dev(), 1 << 20)
+        pa = a.data_ptr()
+        assert wgrad._scratch(dev(), 1 << 19).data_ptr() == pa           # big enough: reused
+        b = wgrad._scratch(dev(), 8 << 20)
+        assert b.numel() >= (8 << 20) and b.data_ptr() != pa
+        del a
+        assert any(t.data_ptr() == pa for t in wgrad._SCRATCH_RETIRED)
