@@ -12,6 +12,7 @@ from . import _lib
 from .ops import KERNEL_TIMER, RowsCtx, conv_rows, grad_accumulator, seed_word, zeros_small  # noqa: F401
 
 _SCRATCH = {}
+_SCRATCH_RETIRED = []
 
 
 def _scratch(name, nbytes, device):
@@ -19,6 +20,8 @@ def _scratch(name, nbytes, device):
     key = (name, str(device))
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _SCRATCH_RETIRED.append(buf)       # a captured graph may still replay into it (see wgrad._scratch)
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _SCRATCH[key] = buf
     return buf
