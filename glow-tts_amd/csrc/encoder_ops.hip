@@ -141,6 +141,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
     float tg = 0.f, tb = 0.f;
 #pragma unroll
     for (int i = 0; i < LNB_WAVES; ++i) { tg += sg[i][c]; tb += sb[i][c]; }
+#ifdef LNB_EXP
+    if (LNB_EXP & 1) { if (tg == 1.2345f) q.dgamma[c] = tb; return; }
+#endif
     atomicAdd(q.dgamma + c, tg);
     atomicAdd(q.dbeta + c, tb);
   }
@@ -758,6 +761,12 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta;
   // geometry: 16 waves x 32 rows per workgroup (the gamma / beta partials are folded in LDS before the atomics) while
   // that still gives >= 64 workgroups; short inputs fall back to 4 waves x 16 rows so the chip is not left idle
+#ifdef LNB_EXP
+  if (LNB_EXP & 2) { q.rows_per_block = 64; hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + 63) / 64), dim3(1024), 0, GT_ST(stream), q); GT_RET(); }
+  if (LNB_EXP & 4) { q.rows_per_block = 32; hipLaunchKernelGGL(gt_layernorm_bwd_kernel<8>, dim3((R + 31) / 32), dim3(512), 0, GT_ST(stream), q); GT_RET(); }
+  if (LNB_EXP & 8) { q.rows_per_block = 16; hipLaunchKernelGGL(gt_layernorm_bwd_kernel<4>, dim3((R + 15) / 16), dim3(256), 0, GT_ST(stream), q); GT_RET(); }
+  if (LNB_EXP & 16) { q.rows_per_block = 16; hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + 15) / 16), dim3(1024), 0, GT_ST(stream), q); GT_RET(); }
+#endif
   if (R >= 64 * 32) {
     q.rows_per_block = 32;
     hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + 31) / 32), dim3(1024), 0, GT_ST(stream), q);

@@ -189,6 +189,9 @@ class _PackPlan:
                        "gt_pack_conv_weights_multi")
 
 
+_RETIRED_PLANS = []
+
+
 def prepare_all(module, side=None):
     """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step.
     side: a stream that already follows the current one (train.Trainer: the encoder's branch, with the step's accumulator fills
@@ -241,6 +244,7 @@ def prepare_all(module, side=None):
             elif hasattr(m, "_pack_entries_extra"):
                 cur += [_pack_key(e) for e in m._pack_entries_extra()]
         if tuple(cur) != plan.key:
+            _RETIRED_PLANS.append(plan)      # a captured graph has the old plan's descriptor table baked in: keep it allocated
             plan = None
     if plan is None:
         plan = _PackPlan(module)

@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from glow_tts_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from glow_tts_amd import ops, encoder_impl
 from glow_tts_amd.modules import LayerNorm
 dev = torch.device("cuda:0")
@@ -29,4 +32,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(20): gr.replay()
 e1.record(); torch.cuda.synchronize()
-print(f"GT_LNB={os.environ.get('GT_LNB','default')} R={R} C={C}: {e0.elapsed_time(e1)/400*1e3:.1f} us per call (incl. 2 arena/zero allocs)")
+print(f"{sys.argv[1] if len(sys.argv) > 1 else 'default'} R={R} C={C}: {e0.elapsed_time(e1)/400*1e3:.1f} us per call (incl. 2 arena/zero allocs)")
