@@ -361,6 +361,10 @@ __device__ __forceinline__ size_t pk_index(bool frag, int t, int nrow, int k, in
   return frag ? ((((size_t)t * (Np >> 5) + (nrow >> 5)) * (Kp >> 4) + (k >> 4)) * 64 + (nrow & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7)
               : ((size_t)t * Np + nrow) * Kp + k;
 }
+#ifndef PK_THREADS
+#define PK_THREADS 256
+#endif
+constexpr int PK_RPW = 8 / (PK_THREADS / 64);       // rows per wave
 __device__ __forceinline__ void pack_rows8(
     const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
     float* __restrict__ inv_norm, int co0, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate,
@@ -371,11 +375,11 @@ __device__ __forceinline__ void pack_rows8(
   // wave w: rows 2w, 2w+1, each held in registers (<= 9 float4 per lane) from ONE batch of loads that are all in flight
   // together — a load / accumulate loop per row left the launch bound by ~30 dependent HBM latencies per workgroup
   // (171 us for the 28 M weights of the step; the bytes alone are ~40 us)
-  float4 x[2][PK8_MAXN / 256];
+  float4 x[PK_RPW][PK8_MAXN / 256];
   const bool al = ((reinterpret_cast<uintptr_t>(v) | ((size_t)n * 4)) & 15) == 0;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float* vr = v + (size_t)(co0 + 2 * w + k) * n;
+  for (int k = 0; k < PK_RPW; ++k) {
+    const float* vr = v + (size_t)(co0 + PK_RPW * w + k) * n;
 #pragma unroll
     for (int j = 0; j < PK8_MAXN / 256; ++j) {
       const int i = lane + 64 * j;
@@ -390,8 +394,8 @@ __device__ __forceinline__ void pack_rows8(
     }
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int rr = 2 * w + k, co = co0 + rr;
+  for (int k = 0; k < PK_RPW; ++k) {
+    const int rr = PK_RPW * w + k, co = co0 + rr;
     float sc = 1.0f;
     if (g) {
       float ss = 0.f;
@@ -420,7 +424,7 @@ __device__ __forceinline__ void pack_rows8(
   if (PK_EXP & 2) Pd = nullptr;
 #endif
   if (Pf) {
-    for (int q = tid; q < 8 * taps * C8; q += 256) {
+    for (int q = tid; q < 8 * taps * C8; q += PK_THREADS) {
       // the 8 rows of the group are the fastest index: their 16-byte pieces are neighbours in the packed image (whole 128-byte lines per store)
       const int rr = q & 7, rem = q >> 3, tap = rem / C8, c8 = rem - tap * C8;
       const int co = co0 + rr;
@@ -435,7 +439,7 @@ __device__ __forceinline__ void pack_rows8(
     }
   }
   if (Pd) {
-    for (int q = tid; q < taps * Cin; q += 256) {
+    for (int q = tid; q < taps * Cin; q += PK_THREADS) {
       const int tap = q / Cin, ci = q - tap * Cin;
       const bf16_t* t = tile + ci * taps + tap;
       uint32_t u[4];
@@ -446,7 +450,7 @@ __device__ __forceinline__ void pack_rows8(
   }
 }
 
-__global__ __launch_bounds__(256) void gt_pack_conv_weights_multi8_kernel(const gt_pack_desc* __restrict__ descs, int n)
+__global__ __launch_bounds__(PK_THREADS) void gt_pack_conv_weights_multi8_kernel(const gt_pack_desc* __restrict__ descs, int n)
 {
   __shared__ __attribute__((aligned(16))) bf16_t tile[8 * PK8_MAXN];
   __shared__ float scl[8];
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256) void gt_pack_conv_weights_multi8_kernel(const 
   // latency instead of a binary search's eight dependent ones)
   if (threadIdx.x == 0) sel = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) if (descs[i].row_start <= row) atomicMax(&sel, i);
+  for (int i = threadIdx.x; i < n; i += PK_THREADS) if (descs[i].row_start <= row) atomicMax(&sel, i);
   __syncthreads();
   const gt_pack_desc d = descs[sel];
   pack_rows8(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, row - d.row_start,
@@ -602,7 +606,7 @@ extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs,
   if (!descs_device || n_convs <= 0 || total_rows <= 0) return GT_E_INVAL;
   if (group8) {
     if (total_rows & 7) return GT_E_INVAL;
-    hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel, dim3(total_rows / 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel, dim3(total_rows / 8), dim3(PK_THREADS), 0, static_cast<hipStream_t>(stream),
                        static_cast<const gt_pack_desc*>(descs_device), n_convs);
     return gt_launch_status(__func__);
   }
