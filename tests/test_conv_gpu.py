@@ -228,3 +228,32 @@ def test_conv_tile_argument_is_validated(built):
         ops.conv_rows(xr, pc, ctx, tile=TILES["64x128"])        # Np = 192 is not a multiple of 128
     with pytest.raises(RuntimeError, match="GT_E_INVAL"):
         ops.conv_rows(xr, pc, ctx, tile=TILES["256x64"])        # gate-only variant
+
+
+@pytest.mark.parametrize("tile,big", [("64x64", False), ("64x128", False), ("64x64taps", False), ("128x128", True), ("auto", True)])
+def test_relu_dropout_backward_in_the_data_gradient_epilogue(built, tile, big):
+    """gate == 3: the backward of y = dropout(relu(conv_1(x))) (attentions.py:368-370) rides in the epilogue of conv_2's data-gradient
+    GEMM — d c1 = d f1 / (1 - p) where the saved y is non-zero, else 0 — on every tile the text encoder's shapes select (64-row tiles
+    at cfg 2, the 128 x 128 tile at cfg 3's row counts), against the unfused pair (data gradient, then gt_relu_drop_bwd)."""
+    from glow_tts_amd import _lib, ops
+    B, T = (30, 400) if big else (3, 150)
+    lens = ([400, 397, 1] + [380 - 3 * i for i in range(27)]) if big else [150, 97, 1]
+    F_, C, k, p = 768, 192, 3, 0.1
+    ctx, x, w, b = make(B, T, F_, C, k, seed=77, lens=lens)          # conv_2: F_ -> C; its data gradient maps [R, C] -> [R, F_]
+    pc = ops.PackedConv(C, F_, k).pack(w.to(torch.bfloat16).float())
+    g = torch.Generator().manual_seed(3)
+    R = ctx.R
+    dy = (torch.randn(R, C, generator=g).to(dev()) * ctx.rowmask[:, None]).to(torch.bfloat16)
+    y = torch.relu(torch.randn(R, F_, generator=g)).to(dev())
+    y = (y * (torch.rand(R, F_, generator=g).to(dev()) > p)).to(torch.bfloat16)       # ~55 % zeros: relu'd or dropped
+    t = TILES.get(tile, 0)
+    want_d = ops.conv_rows(dy, pc, ctx, dgrad=True, tile=0 if t == 6 else t)
+    want = torch.empty_like(want_d)
+    _lib.check(_lib.lib().gt_relu_drop_bwd(_lib.ptr(want_d), F_, _lib.ptr(y), F_, _lib.ptr(want), F_, R, F_, p, _lib.current_stream(dev())),
+               "gt_relu_drop_bwd")
+    got = ops.conv_rows(dy, pc, ctx, dgrad=True, gate=3, gate_t=y, drop_p=p, tile=t)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert ((got != 0) <= (y != 0)).all()                              # nothing leaks through a zero of the saved activation
+    # the fused form scales the fp32 accumulator, the unfused one the bf16-rounded data gradient: one bf16 ulp apart at most
+    scale = want.float().abs().max().item()
+    assert torch.allclose(got.float(), want.float(), atol=1e-2 * scale, rtol=2e-2), (got.float() - want.float()).abs().max().item() / scale
