@@ -347,6 +347,7 @@ class Trainer:
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
+        self._grad_norm_buf = None
         self._captured = OrderedDict()            # key -> (graphs, static inputs, outputs, row contexts); LRU, <= max_graphs
         self.max_graphs = int(max_graphs)
         self.pad_tx, self.pad_ty = int(pad_tx), int(pad_ty)
@@ -421,7 +422,11 @@ class Trainer:
         from . import ops
         # reference commons.clip_grad_value_(params, None): total grad norm, no clipping — the sum of squares
         # falls out of the optimizer's own pass over the gradients (no ~1.8k .item() syncs)
-        self.grad_norm = torch.sqrt(self.opt.step())
+        # into ONE persistent tensor: a replayed graph runs no Python, so a tensor created here would be the last CAPTURED
+        # graph's, stale whenever another row bucket's graph is the one replaying
+        if self._grad_norm_buf is None:
+            self._grad_norm_buf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.grad_norm = torch.sqrt(self.opt.step(), out=self._grad_norm_buf)
         ops.mark("optimizer done")
         if self.stamps is not None:
             self.stamps.end_step()
