@@ -35,6 +35,8 @@ constexpr int XR = BM + TAPS - 1;             // 68 input rows
 constexpr int RING = WNS_RING;
 constexpr int KK2 = H / 16;
 constexpr int STACK_LDS = (2 * XR + BM) * AP * 2;                       // Xa, Xb [68][200] + At [64][200] = 80 000 B
+constexpr int STACK_FWD_LDS = STACK_LDS + 2 * BM * AP * 2;              // forward: + the saved tanh / sigmoid tiles [64][200] each = 131 200 B
+constexpr int CPR = H / 8;                                              // 16-byte chunks per row
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // through an explicit GLOBAL pointer: a pointer that went through `pinned` is generic to the compiler, and flat loads count on
@@ -89,6 +91,8 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
   bf16_t* Xc = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Xn = Xc + XR * AP;
   bf16_t* At = Xn + XR * AP;
+  bf16_t* Tl = At + BM * AP;                                         // saved tanh / sigmoid halves on their way out (see the gate epilogue)
+  bf16_t* Sl = Tl + BM * AP;
   constexpr int KS = H / 16, NBT = 2 * H / 32, NIT = 3 * TAPS;       // 12 k-steps per tap, 12 column blocks, 15 steps of 4 k-steps
 
   // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero)
@@ -202,17 +206,29 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
             vt += ctv[j]; vs += csv[j];
             if (WNS_EXP & 4) { tt[j] = vt; ss[j] = vs; aa[j] = vt + vs; } else { tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j]; }
           }
-          const uint2 pa = pack4(aa[0], aa[1], aa[2], aa[3]);
-          if (t >= halo && t < BM - halo && m < R && !(WNS_EXP & 1)) {    // the rows this workgroup owns
-            *reinterpret_cast<uint2*>(Tt + (size_t)m * H + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
-            *reinterpret_cast<uint2*>(Ss + (size_t)m * H + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
-            *reinterpret_cast<uint2*>(acts + (size_t)m * a.ldacts + c) = pa;
-          }
-          if (!last) *reinterpret_cast<uint2*>(At + t * AP + c) = pa;
+          // T, S and acts leave through LDS: straight from the MFMA layout a store instruction writes 16 bytes to each of 32
+          // rows (2.6 M partial-line requests per launch, the "17 us of stores" of DESIGN 4.9); the tiles below go out as whole rows
+          *reinterpret_cast<uint2*>(Tl + t * AP + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
+          *reinterpret_cast<uint2*>(Sl + t * AP + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
+          *reinterpret_cast<uint2*>(At + t * AP + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
         }
       }
+    __syncthreads();                                                   // At, Tl, Sl complete
+    if (!(WNS_EXP & 1)) {
+      // the rows this workgroup owns are ONE contiguous block of T / S (and 384-byte pieces of the acts rows): 16 bytes per lane,
+      // consecutive lanes on consecutive addresses
+      for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
+        const int row = idx / CPR, c8 = idx - row * CPR, t = halo + row, m = s0 + t;
+        if (m < R) {
+          const uint4 vt = *reinterpret_cast<const uint4*>(Tl + t * AP + c8 * 8), vs = *reinterpret_cast<const uint4*>(Sl + t * AP + c8 * 8),
+                      va = *reinterpret_cast<const uint4*>(At + t * AP + c8 * 8);
+          *reinterpret_cast<uint4*>(Tt + (size_t)m * H + c8 * 8) = vt;
+          *reinterpret_cast<uint4*>(Ss + (size_t)m * H + c8 * 8) = vs;
+          *reinterpret_cast<uint4*>(acts + (size_t)m * a.ldacts + c8 * 8) = va;
+        }
+      }
+    }
     if (last) break;
-    __syncthreads();                                                   // At complete
 
     // stage 2: x_next = (x + acts @ W_res^T + b_res) * mask -> the next layer's LDS tile (+ HBM for the owned rows)
     f32x16_t acc2[3];
@@ -235,7 +251,6 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     {
       const int t = 32 * wm2 + r, m = s0 + t;
       const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
-      const bool mine = t >= halo && t < BM - halo && m < R;
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -247,11 +262,16 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
           const uint2 v = pack4((acc2[bn][4 * g] + b2.x + xv[0]) * rm, (acc2[bn][4 * g + 1] + b2.y + xv[1]) * rm,
                                 (acc2[bn][4 * g + 2] + b2.z + xv[2]) * rm, (acc2[bn][4 * g + 3] + b2.w + xv[3]) * rm);
           *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
-          if (mine && !(WNS_EXP & 1)) *reinterpret_cast<uint2*>(xo + (size_t)m * H + n) = v;
         }
     }
     __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
     bf16_t* tmp = Xc; Xc = Xn; Xn = tmp;
+    if (!(WNS_EXP & 1)) {                                              // x_next of the owned rows, whole rows from the finished tile
+      for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
+        const int row = idx / CPR, c8 = idx - row * CPR, t = halo + row, m = s0 + t;
+        if (m < R) *reinterpret_cast<uint4*>(xo + (size_t)m * H + c8 * 8) = *reinterpret_cast<const uint4*>(Xc + (t + 2) * AP + c8 * 8);
+      }
+    }
     if (threadIdx.x < 4 * 24) {                                        // rows 0, 1, 66, 67 of the tile after next
       const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
@@ -376,7 +396,6 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   const bool mine_row = t >= halo && t < BM - halo && m < R;
   {
     const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
-    bf16_t* dx = static_cast<bf16_t*>(a.dx[J]);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -386,12 +405,20 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
         if (J < n_layers - 1) unpack4(*reinterpret_cast<const uint2*>(At + t * AP + n), ad);
         const uint2 v = pack4((sum[bn][4 * g] + ad[0]) * rm, (sum[bn][4 * g + 1] + ad[1]) * rm,
                               (sum[bn][4 * g + 2] + ad[2]) * rm, (sum[bn][4 * g + 3] + ad[3]) * rm);
-        if (mine_row) *reinterpret_cast<uint2*>(dx + (size_t)m * H + n) = v;
         *reinterpret_cast<uint2*>(At + t * AP + n) = v;
       }
   }
-  if (J == 0) return;                                               // bottom: dX_0 is the gradient at the WaveNet's input
   __syncthreads();
+  {
+    // dX_j of the owned rows leaves as whole rows from the finished tile (the MFMA layout gives a store 16 bytes in each of 32 rows)
+    bf16_t* dx = static_cast<bf16_t*>(a.dx[J]);
+    const int own = BM - 2 * halo;
+    for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
+      const int row = idx / CPR, c8 = idx - row * CPR, tt = halo + row, mm = s0 + tt;
+      if (mm < R) *reinterpret_cast<uint4*>(dx + (size_t)mm * H + c8 * 8) = *reinterpret_cast<const uint4*>(At + tt * AP + c8 * 8);
+    }
+  }
+  if (J == 0) return;                                               // bottom: dX_0 is the gradient at the WaveNet's input
 
   // d acts_{j-1} = dX_j W_res + skip-path gradient -> gate backward -> d pre_{j-1}: the next tile (+ HBM for the owned rows)
   f32x16_t acc2[3];
@@ -414,7 +441,6 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   {
     const bf16_t* Tt = static_cast<const bf16_t*>(a.gate_t[JL]);
     const bf16_t* Ss = static_cast<const bf16_t*>(a.gate_s[JL]);
-    bf16_t* dpre = static_cast<bf16_t*>(a.dpre[JL]);
     bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
     const uint32_t seed = (a.drop_seed + (uint32_t)JL) ^ seed_x;
     const bool in = m >= 0 && m < R;
@@ -432,13 +458,9 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
 #pragma unroll
           for (int q = 0; q < 4; ++q) dd[q] = acc2[bn][4 * g + q] + vs[q];
           gate_bwd4(dd, tt, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
-          if (mine_row) {
-            *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + n) = pt;
-            *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + H + n) = ps;
-            if (dpre_c) {
-              *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
-              *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
-            }
+          if (mine_row && dpre_c) {                                  // (speaker-conditioned configs only)
+            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
+            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
           }
         }
         *reinterpret_cast<uint2*>(Dt + (t + 2) * DP + n) = pt;
@@ -446,6 +468,16 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       }
   }
   __syncthreads();                                                   // the next conv's input tile is complete
+  {
+    // d pre_{j-1} of the owned rows: whole 768-byte rows from the tile (read-only until the next step's exchange, which follows a barrier)
+    bf16_t* dpre = static_cast<bf16_t*>(a.dpre[JL]);
+    const int own = BM - 2 * halo;
+    constexpr int CPR2 = 2 * H / 8;
+    for (int idx = threadIdx.x; idx < own * CPR2; idx += 256) {
+      const int row = idx / CPR2, c8 = idx - row * CPR2, tt = halo + row, mm = s0 + tt;
+      if (mm < R) *reinterpret_cast<uint4*>(dpre + (size_t)mm * 2 * H + c8 * 8) = *reinterpret_cast<const uint4*>(Dt + (tt + 2) * DP + c8 * 8);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_args a, uint32_t drop_thresh, float drop_scale)
@@ -512,7 +544,7 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
   if (a.R < 0) return GT_E_INVAL;
   if (a.R == 0) return GT_OK;
   if (a.H != H || a.taps != TAPS || a.n_layers < 1 || a.n_layers > NLMAX) return GT_E_UNSUPPORTED;
-  if (!a.x0 || !a.rowmask || !a.acts || a.ldacts < a.n_layers * H || (a.ldacts & 3) || (a.cond && (a.ldc & 3))) return GT_E_INVAL;
+  if (!a.x0 || !a.rowmask || !a.acts || a.ldacts < a.n_layers * H || (a.ldacts & 7) || (a.cond && (a.ldc & 3))) return GT_E_INVAL;
   if (!al16(a.x0) || !al16(a.acts) || !al16(a.cond)) return GT_E_ALIGN;
   for (int i = 0; i < a.n_layers; ++i) {
     if (!a.w_in[i] || !a.b_in[i] || !a.gate_t[i] || !a.gate_s[i]) return GT_E_INVAL;
@@ -528,13 +560,13 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
   }
   static bool attr = false;                    // > 64 KB of LDS: opt in once per process
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_LDS) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_FWD_LDS) != hipSuccess)
       return GT_E_LAUNCH;
     attr = true;
   }
   const int own = BM - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
-  hipLaunchKernelGGL(gt_wn_stack_fwd_kernel, grid, block, STACK_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  hipLaunchKernelGGL(gt_wn_stack_fwd_kernel, grid, block, STACK_FWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }
 
