@@ -292,7 +292,7 @@ constexpr int DP = 2 * H + 8;                 // d pre tile pitch (halfs): 784 B
 constexpr int EX_BYTES = 4 * 3 * 16 * 64 * 4; // partial-sum exchange [4 waves][3 blocks][16][64 lanes] fp32: aliases the d pre tile
 constexpr int BWD_DT = XR * DP * 2;           // 53 312 B
 static_assert(EX_BYTES <= BWD_DT, "the exchange buffer lives in the d pre tile");
-constexpr int SBWD_LDS = BWD_DT + BM * AP * 2;
+constexpr int SBWD_LDS = BWD_DT + 4 * BM * AP * 2;       // d pre tile | dX tile | skip-gradient, tanh, sigmoid staging tiles = 155 712 B
 
 __device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)[4], const float (&s)[4], uint32_t seed, int m, int n,
                                           uint32_t thresh, float scale, uint2& pt, uint2& ps, uint2& ct, uint2& cs)
@@ -421,6 +421,27 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   if (J == 0) return;                                               // bottom: dX_0 is the gradient at the WaveNet's input
 
   // d acts_{j-1} = dX_j W_res + skip-path gradient -> gate backward -> d pre_{j-1}: the next tile (+ HBM for the owned rows)
+  // the gate backward's three row operands (skip-path gradient, saved tanh, saved sigmoid of layer j-1, all 64 rows of the tile) are
+  // fetched as whole rows under the GEMM below and handed to the epilogue through LDS — read in the MFMA layout, every load
+  // instruction touched 16 bytes in each of 32 rows
+  constexpr int JLp = J > 0 ? J - 1 : 0;
+  constexpr int NPRE = (BM * CPR + 255) / 256;                       // 6 chunks per thread and operand
+  bf16_t* Vl = At + BM * AP; bf16_t* Tl = Vl + BM * AP; bf16_t* Sl = Tl + BM * AP;
+  uint4 pre[3][NPRE];
+  {
+    const bf16_t* Tg = static_cast<const bf16_t*>(a.gate_t[JLp]);
+    const bf16_t* Sg = static_cast<const bf16_t*>(a.gate_s[JLp]);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, mm = s0 + row;
+      pre[0][i] = pre[1][i] = pre[2][i] = make_uint4(0, 0, 0, 0);
+      if (mm >= 0 && mm < R) {
+        pre[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)mm * a.ldvs + JLp * H + c8 * 8);
+        pre[1][i] = *reinterpret_cast<const uint4*>(Tg + (size_t)mm * H + c8 * 8);
+        pre[2][i] = *reinterpret_cast<const uint4*>(Sg + (size_t)mm * H + c8 * 8);
+      }
+    }
+  }
   f32x16_t acc2[3];
 #pragma unroll
   for (int bn = 0; bn < 3; ++bn)
@@ -438,9 +459,15 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
+    *reinterpret_cast<uint4*>(Vl + row * AP + c8 * 8) = pre[0][i];
+    *reinterpret_cast<uint4*>(Tl + row * AP + c8 * 8) = pre[1][i];
+    *reinterpret_cast<uint4*>(Sl + row * AP + c8 * 8) = pre[2][i];
+  }
+  __syncthreads();
   {
-    const bf16_t* Tt = static_cast<const bf16_t*>(a.gate_t[JL]);
-    const bf16_t* Ss = static_cast<const bf16_t*>(a.gate_s[JL]);
     bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
     const uint32_t seed = (a.drop_seed + (uint32_t)JL) ^ seed_x;
     const bool in = m >= 0 && m < R;
@@ -452,9 +479,9 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
         uint2 pt = make_uint2(0, 0), ps = pt, ct = pt, cs = pt;
         if (in) {
           float vs[4], tt[4], sg[4], dd[4];
-          unpack4(*reinterpret_cast<const uint2*>(via + (size_t)m * a.ldvs + JL * H + n), vs);
-          unpack4(*reinterpret_cast<const uint2*>(Tt + (size_t)m * H + n), tt);
-          unpack4(*reinterpret_cast<const uint2*>(Ss + (size_t)m * H + n), sg);
+          unpack4(*reinterpret_cast<const uint2*>(Vl + t * AP + n), vs);
+          unpack4(*reinterpret_cast<const uint2*>(Tl + t * AP + n), tt);
+          unpack4(*reinterpret_cast<const uint2*>(Sl + t * AP + n), sg);
 #pragma unroll
           for (int q = 0; q < 4; ++q) dd[q] = acc2[bn][4 * g + q] + vs[q];
           gate_bwd4(dd, tt, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
@@ -577,7 +604,7 @@ extern "C" int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream)
   if (a.R < 0) return GT_E_INVAL;
   if (a.R == 0) return GT_OK;
   if (a.H != H || a.taps != TAPS || a.n_layers < 1 || a.n_layers > NLMAX) return GT_E_UNSUPPORTED;
-  if (!a.via_skip || !a.rowmask || a.ldvs < a.n_layers * H || (a.ldvs & 3)) return GT_E_INVAL;
+  if (!a.via_skip || !a.rowmask || a.ldvs < a.n_layers * H || (a.ldvs & 7)) return GT_E_INVAL;
   if (!al16(a.via_skip)) return GT_E_ALIGN;
   for (int i = 0; i < a.n_layers; ++i) {
     if (!a.w_in_d[i] || !a.gate_t[i] || !a.gate_s[i] || !a.dpre[i] || !a.dx[i]) return GT_E_INVAL;
