@@ -141,6 +141,19 @@ __device__ __forceinline__ void sq_scatter4(float* __restrict__ y, int b, int t,
   dst[0] = v.x; dst[(size_t)T] = v.y; dst[2 * (size_t)T] = v.z; dst[3 * (size_t)T] = v.w;
 }
 
+// A finished [64][AP] bf16 tile -> global rows m0 .. m0 + 63 (row stride ld, 192 channels): 16 bytes per lane, consecutive lanes on
+// consecutive addresses.  Stored straight from the MFMA accumulator layout, one instruction writes 16 bytes to each of 32 rows —
+// partial lines that the memory pipeline handles one request at a time (wn_stack.hip measured the difference: -5 us per launch).
+__device__ __forceinline__ void coop_store_rows(bf16_t* __restrict__ dst, int ld, const bf16_t* __restrict__ tile, int m0, int R)
+{
+  constexpr int CPR = H / 8;
+#pragma unroll
+  for (int i = 0; i < BM * CPR / 256; ++i) {
+    const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, gm = m0 + row;
+    if (gm < R) *reinterpret_cast<uint4*>(dst + (size_t)gm * ld + c8 * 8) = *reinterpret_cast<const uint4*>(tile + row * AP + c8 * 8);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int F_AS = 0;                                    // acts slices [4][64][AP] bf16; later At [64][AP] (slice 0) / y0 tile
 constexpr int F_O = BM * AP * 2;                           // m | logs tile [64][ZP] fp32 (over slices 1, 2 once they are dead)
@@ -206,10 +219,10 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
         const float4 b4 = *reinterpret_cast<const float4*>(a.b_skip + n);
         const uint2 v = pack4((acc[bn][4 * g] + b4.x) * rm_l, (acc[bn][4 * g + 1] + b4.y) * rm_l,
                               (acc[bn][4 * g + 2] + b4.z) * rm_l, (acc[bn][4 * g + 3] + b4.w) * rm_l);
-        if (mrow < R && !(WNB_EXP & 4)) *reinterpret_cast<uint2*>(wn_out + (size_t)mrow * H + n) = v;
         *reinterpret_cast<uint2*>(As + (32 * wm + r) * AP + n) = v;
       }
     __syncthreads();
+    if (!(WNB_EXP & 4)) coop_store_rows(wn_out, H, As, m0, R);       // whole rows from the tile (see coop_store_rows)
     // end conv: [m | logs] = wn_out @ Wend^T + b   (N = 160: blocks 0..4, block 5 is the image's zero padding)
     // the coupling's inputs (this block's y, written by the previous launch) fly under the end conv
     float4 cy0[5], cy1[5];
@@ -338,18 +351,19 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     acc_zero<3>(acc3);
     gemm_run<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, X0t + (32 * wm + r) * XP + 8 * h, lane, ring3, acc3);
     bf16_t* h0 = static_cast<bf16_t*>(a.h_next);
-    if (mrow < R) {
+    bf16_t* Hst = reinterpret_cast<bf16_t*>(smem + F_O);             // the m | logs tile is dead: the h tile on its way out
 #pragma unroll
-      for (int bn = 0; bn < 3; ++bn)
+    for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
-          const float4 b4 = *reinterpret_cast<const float4*>(a.b_start + n);
-          *reinterpret_cast<uint2*>(h0 + (size_t)mrow * H + n) =
-              pack4((acc3[bn][4 * g] + b4.x) * rm_l, (acc3[bn][4 * g + 1] + b4.y) * rm_l,
-                    (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
-        }
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        const float4 b4 = *reinterpret_cast<const float4*>(a.b_start + n);
+        *reinterpret_cast<uint2*>(Hst + (32 * wm + r) * AP + n) =
+            pack4((acc3[bn][4 * g] + b4.x) * rm_l, (acc3[bn][4 * g + 1] + b4.y) * rm_l,
+                  (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
+      }
+    __syncthreads();
+    coop_store_rows(h0, H, Hst, m0, R);
   }
 }
 
@@ -571,18 +585,17 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     for (int p = 0; p < RD; ++p)                             // the skip stage's first fragments fly under this epilogue
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn) ring3[p][bn] = ldfrag(Wsd, (6 * (p / KS2) + 3 * wn + bn) * a.ks_skip_d + p % KS2, lane);
-    bf16_t* dwn = static_cast<bf16_t*>(a.dwn_out);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
         const uint2 v = pack4(acc[bn][4 * g] * rm_l, acc[bn][4 * g + 1] * rm_l, acc[bn][4 * g + 2] * rm_l, acc[bn][4 * g + 3] * rm_l);
-        if (mrow < R) *reinterpret_cast<uint2*>(dwn + (size_t)mrow * H + n) = v;
         *reinterpret_cast<uint2*>(At + (32 * wm + r) * AP + n) = v;
       }
   }
   __syncthreads();
+  coop_store_rows(static_cast<bf16_t*>(a.dwn_out), H, At, m0, R);
   // skip data gradient: d acts_l (skip path) = d wn_out @ Wskip_l, one layer window per pass
   bf16_t* via = static_cast<bf16_t*>(a.via_skip);
   const bf16_t* brow = At + (32 * wm + r) * AP + 8 * h;
@@ -600,15 +613,17 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
         if (nx < NS) ring3[st % RD][bn] = ldfrag(Wsd, (6 * (nx / KS2) + 3 * wn + bn) * a.ks_skip_d + nx % KS2, lane);
       }
     }
-    if (mrow < R) {
+    // out through one of two dead tiles (the fp32 gradient tile / the d[m | logs] tile), alternating: one barrier per layer window
+    bf16_t* Vst = reinterpret_cast<bf16_t*>(smem + ((l & 1) ? B_DO : B_D));
 #pragma unroll
-      for (int bn = 0; bn < 3; ++bn)
+    for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = l * H + 32 * (3 * wn + bn) + 8 * g + 4 * h;
-          *reinterpret_cast<uint2*>(via + (size_t)mrow * a.ldvs + n) = pack4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
-        }
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
+        *reinterpret_cast<uint2*>(Vst + (32 * wm + r) * AP + n) = pack4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
+      }
+    __syncthreads();
+    coop_store_rows(via + l * H, a.ldvs, Vst, m0, R);
   }
 }
 
@@ -679,7 +694,7 @@ extern "C" int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream
   } else if (!a.dz_bct && (!a.dz_in || !al16(a.dz_in))) return GT_E_INVAL;
   if (tailb) {
     if (!a.logs_raw || !a.y || !a.dlogdet || !a.rowutt || !a.w_end_d || !a.dwn_out || !a.w_skip_d || !a.via_skip) return GT_E_INVAL;
-    if (a.ks_end_d < C / 16 || a.ks_skip_d < H / 16 || a.ldvs < NL * H || (a.ldvs & 3)) return GT_E_INVAL;
+    if (a.ks_end_d < C / 16 || a.ks_skip_d < H / 16 || a.ldvs < NL * H || (a.ldvs & 7)) return GT_E_INVAL;
     if (!al16(a.logs_raw) || !al16(a.y) || !al16(a.dout) || !al16(a.w_end_d) || !al16(a.dwn_out) || !al16(a.w_skip_d) || !al16(a.via_skip))
       return GT_E_ALIGN;
   }
