@@ -3,7 +3,10 @@ over) and with streaming weights (48 different layers round-robin, as in the ste
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from glow_tts_amd import _lib, modules, ops, flow_impl
+from glow_tts_amd import _lib
+if len(sys.argv) > 2:                      # wn_layer_bench.py quick <lib.so>: an experiment build (tools: exp_variant2.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
+from glow_tts_amd import modules, ops, flow_impl
 
 dev = torch.device("cuda:0")
 L = _lib.lib()
