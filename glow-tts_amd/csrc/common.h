@@ -13,9 +13,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {       // round-to-nearest-even
 }
 __device__ __forceinline__ uint32_t pack2bf(float a, float b) { return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// The reciprocal is the hardware's (v_rcp_f32, 1 ulp): an IEEE-exact `1.0f / x` is a ten-instruction sequence, and the gate
+// epilogues evaluate two of them per element (20 us of a WaveNet forward's 84 were this VALU work).  The results
+// are rounded to bf16 right away, 16 bits below the ulp in question.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {      // 1 - 2/(e^{2x}+1): exact limits at +-inf
-  return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
 // Counter-based RNG for dropout: one 32-bit hash per element index, replayable in backward.
