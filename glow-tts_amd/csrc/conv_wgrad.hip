@@ -18,7 +18,10 @@
 
 namespace {
 
-constexpr int KB = 64;                        // rows per staging step
+#ifndef WG_KB
+#define WG_KB 64
+#endif
+constexpr int KB = WG_KB;                     // rows per staging step
 constexpr int MAXTAPS = 5;
 constexpr int YP = 128 + 32;                  // dY tile pitch in halfs (320 B)
 constexpr int XP = 64 + 32;                   // X tile pitch in halfs (192 B)
@@ -71,32 +74,28 @@ __device__ __forceinline__ void wgrad_tile(
   const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
-  // register prefetch of the next 64-row step (named scalars: see conv_gemm.hip)
-  uint4 y0 = {}, y1 = {}, y2 = {}, y3 = {}, x0 = {}, x1 = {}, x2 = {};
-  auto ldy1 = [&](int mb, int i) -> uint4 {
-    const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
-    const int m = mb + row, co = co0 + c8 * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (m < mend && co < Ncols) v = *reinterpret_cast<const uint4*>(dY + (size_t)m * ldy + co);
-    return v;
-  };
-  auto ldx1 = [&](int mb, int i) -> uint4 {
-    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-    const int m = mb - padl + row, ci = ci0 + c8 * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < KB + TAPS - 1 && m >= 0 && m < R && ci < Cin) v = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + ci);
-    return v;
-  };
-  auto sty1 = [&](int buf, int i, const uint4& v) {
-    const int chunk = tid + 256 * i, row = chunk >> 4, c8 = chunk & 15;
-    *reinterpret_cast<uint4*>(&Ys[buf][row * YP + c8 * 8]) = v;
-  };
-  auto stx1 = [&](int buf, int i, const uint4& v) {
-    const int chunk = tid + 256 * i, row = chunk >> 3, c8 = chunk & 7;
-    if (row < KB + TAPS - 1) *reinterpret_cast<uint4*>(&Xs[buf][row * XP + c8 * 8]) = v;
-  };
-#define WG_LOAD(mb)  do { y0 = ldy1(mb, 0); y1 = ldy1(mb, 1); y2 = ldy1(mb, 2); y3 = ldy1(mb, 3); x0 = ldx1(mb, 0); x1 = ldx1(mb, 1); x2 = ldx1(mb, 2); } while (0)
-#define WG_STORE(bf) do { sty1(bf, 0, y0); sty1(bf, 1, y1); sty1(bf, 2, y2); sty1(bf, 3, y3); stx1(bf, 0, x0); stx1(bf, 1, x1); stx1(bf, 2, x2); } while (0)
+  // register prefetch of the next KB-row step
+  constexpr int YCH = KB * 16 / 256, XCH = (XROWS * 8 + 255) / 256;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t yr[YCH], xr[XCH];
+#define WG_LOAD(mb) do { \
+    _Pragma("unroll") for (int i_ = 0; i_ < YCH; ++i_) { \
+      const int chunk = tid + 256 * i_, row = chunk >> 4, c8 = chunk & 15, m = (mb) + row, co = co0 + c8 * 8; \
+      u32x4_t v = {0u, 0u, 0u, 0u}; \
+      if (m < mend && co < Ncols) v = *reinterpret_cast<const u32x4_t*>(dY + (size_t)m * ldy + co); \
+      yr[i_] = v; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < XCH; ++i_) { \
+      const int chunk = tid + 256 * i_, row = chunk >> 3, c8 = chunk & 7, m = (mb) - padl + row, ci = ci0 + c8 * 8; \
+      u32x4_t v = {0u, 0u, 0u, 0u}; \
+      if (row < KB + TAPS - 1 && m >= 0 && m < R && ci < Cin) v = *reinterpret_cast<const u32x4_t*>(X + (size_t)m * ldx + ci); \
+      xr[i_] = v; } } while (0)
+#define WG_STORE(bf) do { \
+    _Pragma("unroll") for (int i_ = 0; i_ < YCH; ++i_) { \
+      const int chunk = tid + 256 * i_, row = chunk >> 4, c8 = chunk & 15; \
+      *reinterpret_cast<u32x4_t*>(&Ys[bf][row * YP + c8 * 8]) = yr[i_]; } \
+    _Pragma("unroll") for (int i_ = 0; i_ < XCH; ++i_) { \
+      const int chunk = tid + 256 * i_, row = chunk >> 3, c8 = chunk & 7; \
+      if (row < KB + TAPS - 1) *reinterpret_cast<u32x4_t*>(&Xs[bf][row * XP + c8 * 8]) = xr[i_]; } } while (0)
 
   if (mbeg < mend) { WG_LOAD(mbeg); WG_STORE(0); }
   __syncthreads();
