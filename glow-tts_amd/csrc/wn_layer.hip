@@ -139,7 +139,7 @@ __device__ __forceinline__ void s2_gemm(const bf16_t* __restrict__ W2, const bf1
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-constexpr int FWD_LDS = 2 * XROWS * LDP * 2 + BM * AP * 2;                  // X [2][68][72] + At [64][200] = 45 184 B
+constexpr int FWD_LDS = 2 * XROWS * LDP * 2 + 3 * BM * AP * 2;              // X [2][68][72] + At, Tl, Sl [64][200] = 96 384 B
 
 template <bool RES>
 __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
   const int m0 = blockIdx.x * BM;
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
   bf16_t* At = Xs + 2 * XROWS * LDP;
+  bf16_t* Tl = At + BM * AP;                                         // saved tanh / sigmoid tiles on their way out
+  bf16_t* Sl = Tl + BM * AP;
   constexpr int NS = H / BK, NIT = NS * TAPS, KS = H / 16, NBT = 2 * H / 32;  // 3 slices, 15 steps, 12 k-steps per tap, 12 column blocks
 
   f32x16_t acc[3][2];
@@ -251,15 +253,28 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
             tt[j] = tanhf_(vt); ss[j] = sigmoidf_(vs); aa[j] = tt[j] * ss[j];
 #endif
           }
-          *reinterpret_cast<uint2*>(a.Tt + (size_t)m * a.ldts + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
-          *reinterpret_cast<uint2*>(a.Ss + (size_t)m * a.ldts + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
-          *reinterpret_cast<uint2*>(a.acts + (size_t)m * a.ldacts + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
         }
-        if (RES) *reinterpret_cast<uint2*>(At + row * AP + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
+        // T, S and acts leave as whole rows through LDS tiles (wn_stack.hip, DESIGN 4.9: the accumulator layout gives a store
+        // instruction 16 bytes in each of 32 rows)
+        *reinterpret_cast<uint2*>(Tl + row * AP + c) = pack4(tt[0], tt[1], tt[2], tt[3]);
+        *reinterpret_cast<uint2*>(Sl + row * AP + c) = pack4(ss[0], ss[1], ss[2], ss[3]);
+        *reinterpret_cast<uint2*>(At + row * AP + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
       }
     }
+  __syncthreads();                                                   // At, Tl, Sl complete
+  {
+    constexpr int CPR = H / 8;
+#pragma unroll
+    for (int i = 0; i < BM * CPR / 256; ++i) {
+      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, m = m0 + row;
+      if (m < a.R) {
+        *reinterpret_cast<uint4*>(a.Tt + (size_t)m * a.ldts + c8 * 8) = *reinterpret_cast<const uint4*>(Tl + row * AP + c8 * 8);
+        *reinterpret_cast<uint4*>(a.Ss + (size_t)m * a.ldts + c8 * 8) = *reinterpret_cast<const uint4*>(Sl + row * AP + c8 * 8);
+        *reinterpret_cast<uint4*>(a.acts + (size_t)m * a.ldacts + c8 * 8) = *reinterpret_cast<const uint4*>(At + row * AP + c8 * 8);
+      }
+    }
+  }
   if (!RES) { stamp_end(a); return; }
-  __syncthreads();                                                   // At complete
 
   f32x16_t acc2[3];
   s2_gemm(a.W2, At, wn2, wm2, lane, ring2, acc2);
@@ -462,7 +477,7 @@ extern "C" int gt_wn_layer_fwd(const void* x, int ldx, const void* w_in_frag, co
   if (Hc != H || taps != TAPS) return GT_E_UNSUPPORTED;
   if (!x || !w_in_frag || !bias_in || !rowmask || !acts || !gate_t || !gate_s) return GT_E_INVAL;
   if (w_res_frag && (!bias_res || !x_next)) return GT_E_INVAL;
-  if ((ldx & 7) || (ldacts & 3) || (ldts & 3) || (w_res_frag && (ldxn & 3)) || (cond && (ldc & 3))) return GT_E_ALIGN;
+  if ((ldx & 7) || (ldacts & 7) || (ldts & 7) || (w_res_frag && (ldxn & 3)) || (cond && (ldc & 3))) return GT_E_ALIGN;
   if (!al16(x) || !al16(w_in_frag) || !al16(acts) || !al16(gate_t) || !al16(gate_s) || !al16(w_res_frag) || !al16(x_next) ||
       !al16(bias_in) || !al16(bias_res) || !al16(cond)) return GT_E_ALIGN;
   if (cond && (Tp <= 0 || (row0 && B <= 0))) return GT_E_INVAL;
