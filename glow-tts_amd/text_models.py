@@ -375,6 +375,7 @@ def mle_loss(z, m, logs, logdet, mask):
 
 ENCODER_STREAM = os.environ.get("GT_ENC_STREAM", "1") != "0"
 PREDICTOR_BRANCH = os.environ.get("GT_PRED_BRANCH", "1") != "0"     # stochastic predictors on the encoder's stream (cfg 5)
+ENERGY_ON_MAIN = os.environ.get("GT_ENERGY_MAIN", "1") != "0"       # ... except the energy predictor: on the main stream (dev switch)
 _ENC_STREAMS = {}
 
 
@@ -687,7 +688,8 @@ class FlowGenerator(nn.Module):
                     t_.record_stream(enc_stream)
         with (torch.cuda.stream(enc_stream) if pfork else contextlib.nullcontext()):
             l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths,
-                                                                       y_max_length, pitch_norm, energy_norm)
+                                                                       y_max_length, pitch_norm, energy_norm,
+                                                                       energy_stream=main if (pfork and ENERGY_ON_MAIN) else None)
         if pfork:
             main.wait_stream(enc_stream)
             for t_ in (l_length, l_pitch, l_energy):
@@ -698,8 +700,11 @@ class FlowGenerator(nn.Module):
         self.last_logp = logp
         return (z, z_m, z_logs, logdet, z_mask), (x_m, x_logs, x_mask), (attn, l_length, l_pitch, l_energy), (None, None, None, None), None
 
-    def _predictor_losses(self, rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths, y_max_length, pitch_norm, energy_norm):
-        """l_length, l_pitch, l_energy of models.py:1086-1115 (+ logw of the deterministic duration predictor)."""
+    def _predictor_losses(self, rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths, y_max_length, pitch_norm, energy_norm,
+                          energy_stream=None):
+        """l_length, l_pitch, l_energy of models.py:1086-1115 (+ logw of the deterministic duration predictor).
+        energy_stream: the energy predictor's chain goes there (the caller's main stream, idle between MAS and the loss) instead of
+        queueing behind the duration and pitch predictors on the current (encoder) stream."""
         if self.use_sdp:                                                       # models.py:1086-1088
             pw = self.encoder.proj_w
             w_rows = rcx.to_rows(w.float())[:, 0].contiguous()
@@ -714,12 +719,20 @@ class FlowGenerator(nn.Module):
             rcf = ops.make_ctx(y_lengths.to(torch.int32), y_max_length, "f", cfg=self.rows_cfg)
             xf = self._gather_features(rcx, xb, rcf, mas.frame2token)
             zsum = torch.sum(z_mask)
+            ready = None
+            if energy_stream is not None and xf.is_cuda and self.use_spp and self.use_sep:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(xf.device))           # xf, zsum, the frame-row context: what both chains read
             if self.use_spp:
                 pp = self.proj_pitch
                 npz = None if noise is None else rcf.to_rows(noise[1].float())[:, 0].contiguous()
                 l_pitch = torch.sum(pp.nll_rows(rcf, xf, rcf.to_rows(pitch_norm.float())[:, 0].contiguous(), pp.cond_vec(g), npz) / zsum)
             if self.use_sep:
-                pe = self.proj_energy
-                nez = None if noise is None else rcf.to_rows(noise[2].float())[:, 0].contiguous()
-                l_energy = torch.sum(pe.nll_rows(rcf, xf, rcf.to_rows(energy_norm.float())[:, 0].contiguous(), pe.cond_vec(g), nez) / zsum)
+                es = energy_stream if ready is not None else None
+                if es is not None:
+                    es.wait_event(ready)                                    # not the pitch chain queued behind it
+                with (torch.cuda.stream(es) if es is not None else contextlib.nullcontext()):
+                    pe = self.proj_energy
+                    nez = None if noise is None else rcf.to_rows(noise[2].float())[:, 0].contiguous()
+                    l_energy = torch.sum(pe.nll_rows(rcf, xf, rcf.to_rows(energy_norm.float())[:, 0].contiguous(), pe.cond_vec(g), nez) / zsum)
         return l_length, l_pitch, l_energy, logw
