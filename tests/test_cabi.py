@@ -59,3 +59,43 @@ def test_ops_fail_loudly_without_gpu(built):
     from glow_tts_amd import monotonic_align
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         monotonic_align.maximum_path(torch.zeros(1, 2, 3), torch.ones(1, 2, 3))
+
+
+def test_wgrad_planner_slabs_cover_the_rows_and_fill_short_launches():
+    """glow_tts_amd.wgrad.WgradQueue._plan (host logic, no GPU): every job's row slabs are 64-row multiples that cover its rows exactly
+    once, the partial-sum workspace has room for all of them, and a launch with few short jobs (the duration predictor's two convs)
+    is cut into enough tiles to cover the chip — the form that once left a dozen workgroups walking all the rows."""
+    import types
+
+    import torch
+    from glow_tts_amd import wgrad
+
+    def conv(cout, cin, taps):
+        pc = types.SimpleNamespace(taps=taps, Cin=cin, Cout=cout, inv_norm=None)
+        return types.SimpleNamespace(pc=pc, weight_norm=False, weight=torch.zeros(cout, cin, taps), bias=torch.zeros(cout))
+
+    def plan(shapes, R):
+        q = wgrad.WgradQueue(torch.device("cpu"))
+        for cout, cin, taps in shapes:
+            c = conv(cout, cin, taps)
+            q.add(c, R, [(torch.zeros(R, cin, dtype=torch.bfloat16), torch.zeros(R, cout, dtype=torch.bfloat16), 0, cout)])
+        return q._plan()
+
+    for shapes, R in (([(256, 192, 3), (256, 256, 3)], 3584), ([(256, 192, 3), (256, 256, 3)], 8704),
+                      ([(384, 192, 5)] * 48, 9216), ([(192, 192, 5)] * 3, 4096), ([(8, 256, 1)], 4096)):
+        jobs, tiles, wnbs, rows, max_n, nbytes = plan(shapes, R)
+        assert len(jobs) == len(shapes) and rows == sum(s[0] for s in shapes)
+        end = 0
+        for (xp, dyp, part_off, pb_off, ldx, ldy, r, cin, cout, co_begin, co_count, slab_rows), w in zip(jobs, wnbs):
+            S = w[8]
+            taps = w[11]
+            assert r == R and slab_rows % 64 == 0 and (S - 1) * slab_rows < R <= S * slab_rows
+            assert part_off >= end and pb_off >= part_off + S * taps * cout * cin * 4          # partials, then the bias partials
+            end = pb_off + S * cout * 4
+        assert nbytes >= end
+        for taps in (5, 3, 1):
+            n_tiles = sum(nco * nci * S for _, _, nco, nci, S in tiles[taps])
+            base = sum(nco * nci for _, _, nco, nci, S in tiles[taps])
+            if base:
+                # (slab counts are capped at FILL_MAX_SLABS and rounded to 64-row multiples: allow a quarter below the target)
+                assert n_tiles >= 0.75 * min(wgrad.FILL_TILES, base * min(wgrad.FILL_MAX_SLABS, max(1, R // 128))), (shapes[0], R, n_tiles)
