@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-graph", type=int, default=None, choices=[0, 1],
+                    help="dev: force (1) / forbid (0) the phased, three-graph step (Trainer(split_graph=)); at N = 1 it shows what "
+                         "that schedule costs without any collective (6.0 vs 4.84 ms: why one backward is the default at every N)")
     ap.add_argument("--marks", action="store_true", help="dev: print the device-clock timeline of the last replayed step (ops.Marks) to stderr")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--one-batch", action="store_true", help="round 1's protocol: the same batch every step")
@@ -249,7 +252,8 @@ def main():
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
     use_graph = not args.no_graph
-    tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True, grad_wire=args.grad_wire)
+    tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True, grad_wire=args.grad_wire,
+                       split_graph=None if args.split_graph is None else bool(args.split_graph))
     nb = 1 if args.one_batch else N_BATCHES
     batches = [make_batch(wl, rank, dev, i) for i in range(nb)]
     call = lambda b: tr.step(b["ids"], b["t_x"], b["y"], b["t_y"], lengths_host=b["lh"], **b["cond"])      # noqa: E731
@@ -317,8 +321,10 @@ def main():
                        "capture_s_untimed": round(t_cap, 2),
                        "parallelism": f"dp{world} (utterance-sharded, RCCL gradient all-reduce, {args.grad_wire} on the wire)",
                        "launch": (("one HIP graph per step (one per ragged-row bucket, captured up front)" if world == 1 else
-                                   "three HIP graphs per step (forward + decoder-side backward | encoder backward | optimizer), the RCCL "
-                                   "all-reduces of the flat gradient buffer launched between them") if tr.graph_mode else "eager launches"),
+                                   ("three HIP graphs per step (forward + decoder-side backward | encoder backward | optimizer), the RCCL "
+                                    "all-reduces of the flat gradient buffer launched between them" if tr.split else
+                                    "two HIP graphs per step (forward + backward | optimizer) with the RCCL all-reduce of the flat gradient "
+                                    "buffer between them")) if tr.graph_mode else "eager launches"),
                        "sub_graph": ("the reference's own FlowGenerator.forward for this config (models.py:1007-1133)" if wl.get("full") else
                                      "upstream-equivalent live sub-graph of the base configs (one WN per coupling block, deterministic "
                                      "DurationPredictor) — SURVEY F1/F2/F4: the fork's class does not construct for them"),

@@ -319,12 +319,15 @@ class Trainer:
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32"):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
-        None keeps lr / betas constant.  split_graph forces the phased, several-graph form (default: world > 1)."""
+        None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
+        encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
+        decoder's, which is worth 1.16 ms of a 4.84 ms step (bench.py --split-graph 1 at N = 1: 6.0 ms) — and then the whole flat
+        buffer on the wire (114 MB fp32: ~0.3-0.7 ms exposed on an 8-GPU xGMI node) between the two graphs."""
         from collections import OrderedDict
         self.model = model
         self.world = world
         self.graph_mode = bool(graph)
-        self.split = (world > 1) if split_graph is None else bool(split_graph)
+        self.split = bool(split_graph)
         accum = []
         for mod in model.modules():
             kind = type(mod).__name__
