@@ -36,6 +36,15 @@ constexpr int ZP = C + 4;                     // fp32 tile pitch (floats)
 #define WNB_EXP 0                             // dev experiments (bit mask), 0 in every build that ships
 #endif
 constexpr int RD = 8;                         // weight-fragment ring: k-steps in flight per wave
+#ifndef WNB_PHASES
+#define WNB_PHASES 0                          // dev: per-phase shader-clock stamps of wave 0 (tools/wn_stack_phases.py), 0 in every build that ships
+#endif
+#if WNB_PHASES
+__device__ unsigned long long g_wnb_ph[1024 * 48];
+#define PH(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_wnb_ph[blockIdx.x * 48 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));   // plain vector: staging arrays of it stay in registers
 
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
   float* rowsum = reinterpret_cast<float*>(smem + F_RS);
   const int mrow = m0 + 32 * wm + r;                        // this lane's row in the MFMA epilogues
   const float rm_l = mrow < R ? a.rowmask[mrow] : 0.0f;
+  PH(0);
 
   if (TAIL) {
     const bf16_t* acts = static_cast<const bf16_t*>(a.acts);
@@ -200,12 +210,14 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     for (int p = 0; p < RD; ++p)
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn) ring[p][bn] = ldfrag(Wskip, (3 * wn + bn) * KK + p, lane);
+    PH(1);
     if (!(WNB_EXP & 2)) {
     skip_slice<0>(xr[0], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<1>(xr[1], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<2>(xr[2], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<3>(xr[3], As, Wskip, wm, wn, r, h, lane, ring, acc);
     } else { acc[0][0] = __uint_as_float(xr[0][0].x ^ xr[1][1].x ^ xr[2][2].x ^ xr[3][3].x ^ ring[0][0].x); __syncthreads(); }
+    PH(2);
     // the end conv's first weight fragments fly under this epilogue
     WRing<3, H / 16> ring2;
     gemm_prefetch<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, lane, ring2);
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
         *reinterpret_cast<uint2*>(As + (32 * wm + r) * AP + n) = v;
       }
     __syncthreads();
+    PH(3);
     if (!(WNB_EXP & 4)) coop_store_rows(wn_out, H, As, m0, R);       // whole rows from the tile (see coop_store_rows)
     // end conv: [m | logs] = wn_out @ Wend^T + b   (N = 160: blocks 0..4, block 5 is the image's zero padding)
     // the coupling's inputs (this block's y, written by the previous launch) fly under the end conv
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     f32x16_t acc2[3];
     acc_zero<3>(acc2);
     gemm_run<3, H / 16>(static_cast<const bf16_t*>(a.w_end), a.ks_end, 3 * wn, As + (32 * wm + r) * AP + 8 * h, lane, ring2, acc2);
+    PH(4);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -249,6 +263,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
         }
       }
     __syncthreads();
+    PH(5);
     // affine coupling on (row, 4 channels): z = [y0 | (m + exp(logs) y1) mask]
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -287,10 +302,12 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       }
     }
     __syncthreads();
+    PH(6);
     if (wave == 0) {
       const int gm = m0 + lane < R ? m0 + lane : R - 1;
       utt_atomic_add(a.logdet, rowsum[lane], a.rowutt[gm], lane);
     }
+    PH(7);
   } else {
     // first block: the squeezed mel rows are the flow state
 #pragma unroll
@@ -345,11 +362,13 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     }
   }
   __syncthreads();
+  PH(8);
   // start conv: h = (y0 @ Wstart^T + b) * mask   (K = 80: 5 k-steps)
   {
     f32x16_t acc3[3];
     acc_zero<3>(acc3);
     gemm_run<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, X0t + (32 * wm + r) * XP + 8 * h, lane, ring3, acc3);
+    PH(9);
     bf16_t* h0 = static_cast<bf16_t*>(a.h_next);
     bf16_t* Hst = reinterpret_cast<bf16_t*>(smem + F_O);             // the m | logs tile is dead: the h tile on its way out
 #pragma unroll
@@ -363,8 +382,10 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
                   (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
       }
     __syncthreads();
+    PH(10);
     coop_store_rows(h0, H, Hst, m0, R);
   }
+  PH(11);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -386,6 +407,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
   bf16_t* Dout = reinterpret_cast<bf16_t*>(smem + B_DO);
   const int mrow = m0 + 32 * wm + r;
   const float rm_l = mrow < R ? a.rowmask[mrow] : 0.0f;
+  PH(0);
 
   if (HEADB) {
     // d y0 (start conv part) = d h @ Wstart: N = 80 (blocks 0..2 of the padded image; wave wn takes 2 wn, 2 wn + 1)
@@ -399,6 +421,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     WRing<2, H / 16> ring1;
     gemm_prefetch<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, lane, ring1);
     __syncthreads();
+    PH(1);
     f32x16_t acc[2];
     acc_zero<2>(acc);
     gemm_run<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, Dh + (32 * wm + r) * AP + 8 * h, lane, ring1, acc);
@@ -411,6 +434,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
           *reinterpret_cast<float4*>(Dt + (32 * wm + r) * ZP + n) = make_float4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
       }
     __syncthreads();
+    PH(2);
     // ActNorm + InvConvNear backward: wave = row phase (rows ph, ph + 4, ..), lane = channel group
     float* sL = reinterpret_cast<float*>(smem + B_RED);
     float* sB = sL + 4 * 64 * 4;
@@ -488,6 +512,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
         }
       }
     }
+    PH(3);
     // one atomic per channel per workgroup (same-address float atomics serialise at L2): fold the row phases in LDS
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sL[(ph * 64 + g) * 4 + k] = accL[k]; sB[(ph * 64 + g) * 4 + k] = accB[k]; }
@@ -507,6 +532,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       }
     }
     if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, sW[threadIdx.x] + sW[16 + threadIdx.x] + sW[32 + threadIdx.x] + sW[48 + threadIdx.x]);
+    PH(4);
     if (!TAILB) return;
   } else {
     // last block: the squeezed gradient of the decoder's output is d z
@@ -572,6 +598,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     }
   }
   __syncthreads();
+  PH(5);
   // end conv data gradient: d wn_out = (d out @ Wend) * mask   (K = 160: 10 k-steps)
   bf16_t* At = Dh;                                           // the d h tile is dead
   const bf16_t* Wsd = static_cast<const bf16_t*>(a.w_skip_d);
@@ -581,6 +608,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     f32x16_t acc[3];
     acc_zero<3>(acc);
     gemm_run<3, C / 16>(static_cast<const bf16_t*>(a.w_end_d), a.ks_end_d, 3 * wn, Dout + (32 * wm + r) * AP + 8 * h, lane, ring2, acc);
+    PH(6);
 #pragma unroll
     for (int p = 0; p < RD; ++p)                             // the skip stage's first fragments fly under this epilogue
 #pragma unroll
@@ -595,7 +623,9 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       }
   }
   __syncthreads();
+  PH(7);
   coop_store_rows(static_cast<bf16_t*>(a.dwn_out), H, At, m0, R);
+  PH(8);
   // skip data gradient: d acts_l (skip path) = d wn_out @ Wskip_l, one layer window per pass
   bf16_t* via = static_cast<bf16_t*>(a.via_skip);
   const bf16_t* brow = At + (32 * wm + r) * AP + 8 * h;
@@ -624,6 +654,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       }
     __syncthreads();
     coop_store_rows(via + l * H, a.ldvs, Vst, m0, R);
+    PH(9 + l);
   }
 }
 
@@ -636,6 +667,13 @@ int opt_in_lds(K kernel, int bytes)
 }
 
 }  // namespace
+
+#if WNB_PHASES
+extern "C" int gt_dev_wnb_phases(void* dst, size_t bytes)
+{
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wnb_ph), bytes < sizeof(g_wnb_ph) ? bytes : sizeof(g_wnb_ph)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream)
 {

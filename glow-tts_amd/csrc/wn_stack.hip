@@ -32,10 +32,23 @@ constexpr int XR = BM + TAPS - 1;             // 68 input rows
 #ifndef WNS_RING
 #define WNS_RING 3
 #endif
+#ifndef WNS_FIXA
+#define WNS_FIXA 1                            // loads ahead of stores (see the forward kernel)
+#endif
 constexpr int RING = WNS_RING;
+#ifndef WNS_PHASES
+#define WNS_PHASES 0                          // dev: per-phase shader-clock stamps of wave 0 (tools/wn_stack_phases.py), 0 in every build that ships
+#endif
+#if WNS_PHASES
+__device__ unsigned long long g_wns_ph[1024 * 48];
+#define PH(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_wns_ph[blockIdx.x * 48 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH(i) do { } while (0)
+#endif
 constexpr int KK2 = H / 16;
 constexpr int STACK_LDS = (2 * XR + BM) * AP * 2;                       // Xa, Xb [68][200] + At [64][200] = 80 000 B
-constexpr int STACK_FWD_LDS = STACK_LDS + 2 * BM * AP * 2;              // forward: + the saved tanh / sigmoid tiles [64][200] each = 131 200 B
+constexpr int FWD_BIAS_FLOATS = NLMAX * 2 * H + (NLMAX - 1) * H;        // every layer's biases, staged once (see the forward kernel)
+constexpr int STACK_FWD_LDS = STACK_LDS + 2 * BM * AP * 2 + FWD_BIAS_FLOATS * 4;   // forward: + the saved tanh / sigmoid tiles [64][200] each + biases = 139 648 B
 constexpr int CPR = H / 8;                                              // 16-byte chunks per row
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -76,11 +89,15 @@ __device__ __forceinline__ T pick(T const (&arr)[NLMAX], int i)        // scalar
 // The forward keeps a RUNTIME layer loop: the compiler then forms the layer's 180 fragment offsets once (hoisted out of the loop,
 // parked in the accumulation registers the MFMAs do not use) — measured 8 % faster than the straight-line, scalar-addressed form
 // the backward kernel needs (its register budget has no room for them).
+// COND / DROP are compile-time: as run-time (uniform) branches around the conditioning loads and the dropout hashes they cost a
+// branch per element and a conservative `s_waitcnt vmcnt(0)` at every join.
+template <bool COND, bool DROP>
 __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_args a, uint32_t drop_thresh, float drop_scale)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (a.stamps && threadIdx.x == 0)
     atomicMin(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)), (unsigned long long)wall_clock64());
+  PH(0);
   const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -93,19 +110,80 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
   bf16_t* At = Xn + XR * AP;
   bf16_t* Tl = At + BM * AP;                                         // saved tanh / sigmoid halves on their way out (see the gate epilogue)
   bf16_t* Sl = Tl + BM * AP;
+  // Every layer's biases live in LDS from the start: read from global memory inside the epilogues (two float4 per 4 gate channels,
+  // each waited for where it is used) they cost a full L2 round trip per (column block, channel group) — 5 k of a layer's 12 k
+  // epilogue cycles (tools/wn_stack_phases.py).
+  float* Bs = reinterpret_cast<float*>(Sl + BM * AP);                // [n][2H] in_layer biases | [n-1][H] residual biases
   constexpr int KS = H / 16, NBT = 2 * H / 32, NIT = 3 * TAPS;       // 12 k-steps per tap, 12 column blocks, 15 steps of 4 k-steps
 
-  // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero)
+  // Vector-memory operations retire IN ORDER on one counter (vmcnt): a wait for a weight fragment also waits for every store issued
+  // before that load.  So the loads a layer needs first are issued BEFORE the stores that precede their use: the next layer's first
+  // ring steps ahead of the T / S / acts / x_next stores, and layer 0's here, ahead of (and overlapping) the input tile's loads.
+  uint4 ring[RING][4][3];
+  float rm2;
+  // Fragment addresses are left to the compiler: it forms the layer's per-lane offsets once, outside the layer loop, and every load
+  // is then ONE instruction with an immediate offset.  Measured against scalar bases formed next to each load (`pinned`, as the
+  // backward needs for its register budget: + 7 us per launch — one wave per SIMD issues in order, so every scalar instruction in
+  // front of a load is time the matrix pipe idles), against buffer loads with the descriptor in SGPRs (+ 2.5 us), and against
+  // pinning each load between two MFMAs (sched_group_barrier: + 5 us — a vector-memory instruction holds the wave's issue for
+  // longer than the MFMA it was meant to hide behind): tools/stack_variants.sh, round 3.
+  auto w_frag = [&](const bf16_t* W, int it, int ks, int bn) {
+    const int kg = it / TAPS, tap = it - kg * TAPS;
+    return ldfrag(W, (tap * NBT + 3 * wave + bn) * KS + kg * 4 + ks, lane);
+  };
+  auto w_load_l = [&](const bf16_t* W, int it, uint4 (&dst)[4][3]) {
+    if ((WNS_EXP & 2) && it > RING) return;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = w_frag(W, it, ks, bn);
+  };
+  // layer-0 input: rows s0 - 2 .. s0 + 65, all 192 channels (rows outside [0, R) read as zero); every layer's biases; the row
+  // mask of the one row this lane finishes in every residual stage (32 * (wave >> 1) + r).  All of these loads are issued first,
+  // then layer 0's first ring steps (a wait for the tile must not wait for the weights behind it), then the LDS writes.
   {
     const bf16_t* x0 = static_cast<const bf16_t*>(a.x0);
+    constexpr int NX = (XR * CPR + 255) / 256, NB = (FWD_BIAS_FLOATS / 4 + 255) / 256;   // 7 and 3 per thread
+    uint4 xin[NX];
+    float4 bin[NB];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int chunk = threadIdx.x + 256 * i, u = chunk / 24, c8 = chunk - u * 24, gm = s0 - 2 + u;
-      if (u < XR) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gm >= 0 && gm < R) v = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
-        *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = v;
+    for (int i = 0; i < NX; ++i) {
+      const int chunk = threadIdx.x + 256 * i, u = chunk / CPR, c8 = chunk - u * CPR, gm = s0 - 2 + u;
+      xin[i] = make_uint4(0, 0, 0, 0);
+      if (u < XR && gm >= 0 && gm < R) xin[i] = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      bin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < NLMAX * 2 * H / 4) {
+        const int l = idx / (2 * H / 4), o = idx - l * (2 * H / 4);
+        if (l < n_layers) bin[i] = reinterpret_cast<const float4*>(pick(a.b_in, l))[o];
+      } else if (idx < FWD_BIAS_FLOATS / 4) {
+        const int q = idx - NLMAX * 2 * H / 4, l = q / (H / 4), o = q - l * (H / 4);
+        if (l < n_layers - 1) bin[i] = reinterpret_cast<const float4*>(pick(a.b_res, l))[o];
       }
+    }
+    {
+      const int m = s0 + 32 * (wave >> 1) + r;
+      rm2 = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+    }
+#if WNS_FIXA
+    {
+      const bf16_t* W10 = static_cast<const bf16_t*>(a.w_in[0]);
+#pragma unroll
+      for (int p = 0; p < RING - 1; ++p) w_load_l(W10, p, ring[p]);
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int chunk = threadIdx.x + 256 * i, u = chunk / CPR, c8 = chunk - u * CPR;
+      if (u < XR) *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = xin[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < FWD_BIAS_FLOATS / 4) reinterpret_cast<float4*>(Bs)[idx] = bin[i];
     }
     if (threadIdx.x < 4 * 24) {                                       // the next tile's rows 0, 1, 66, 67 are never produced
       const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
@@ -113,13 +191,24 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     }
   }
   __syncthreads();
+  PH(1);
+
+  // per-utterance conditioning: the utterance of this lane's two rows (one binary search each, once per launch)
+  int cb[2] = {0, 0};
+  if (COND) {
+#pragma unroll
+    for (int bm = 0; bm < 2; ++bm) {
+      const int m = s0 + 32 * bm + r, mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
+      cb[bm] = a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc;
+    }
+  }
 
   for (int layer = 0; layer < n_layers; ++layer) {
     const bool last = layer == n_layers - 1;
     const bf16_t* W1 = static_cast<const bf16_t*>(pick(a.w_in, layer));
     const bf16_t* W2 = static_cast<const bf16_t*>(pick(a.w_res, layer));
-    const float* bias1 = pick(a.b_in, layer);
-    const float* bias2 = pick(a.b_res, layer);
+    const float* bias1 = Bs + layer * 2 * H;
+    const float* bias2 = Bs + NLMAX * 2 * H + layer * H;
     bf16_t* Tt = static_cast<bf16_t*>(pick(a.gate_t, layer));
     bf16_t* Ss = static_cast<bf16_t*>(pick(a.gate_s, layer));
     bf16_t* xo = static_cast<bf16_t*>(pick(a.x_out, layer));
@@ -133,17 +222,11 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
 
-    uint4 ring[RING][4][3];
-    auto w_load = [&](int it, uint4 (&dst)[4][3]) {
-      if ((WNS_EXP & 2) && it > RING) return;
-      const int kg = it / TAPS, tap = it - kg * TAPS;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int bn = 0; bn < 3; ++bn) dst[ks][bn] = ldfrag(W1, (tap * NBT + 3 * wave + bn) * KS + kg * 4 + ks, lane);
-    };
+    auto w_load = [&](int it, uint4 (&dst)[4][3]) { w_load_l(W1, it, dst); };
+#if !WNS_FIXA
 #pragma unroll
     for (int p = 0; p < RING - 1; ++p) w_load(p, ring[p]);
+#endif
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int kg = it / TAPS, tap = it - kg * TAPS;
@@ -163,33 +246,39 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    PH(2 + 6 * layer);
+    // the thread index as a value formed HERE: the copy loops' per-thread addresses and the epilogue's 24 per-channel hash bases
+    // are otherwise computed in front of the layer loop and carried (spilled) across the K loops
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int r_e = tid_e & 31, h_e = (tid_e >> 5) & 1, wave_e = tid_e >> 6;
     // second-stage weights start flying now, under the gate epilogue
     const int wn2 = wave & 1, wm2 = wave >> 1;
-    uint4 ring2[KK2 / 2][3];
+    constexpr int R2 = KK2 / 2;
+    uint4 ring2[R2][3];
     if (!last) {
 #pragma unroll
-      for (int kk = 0; kk < KK2 / 2; ++kk)
+      for (int kk = 0; kk < R2; ++kk)
 #pragma unroll
         for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk, lane);
     }
 
     // gate epilogue in registers (see wn_layer.hip): block 3*wave + bn holds [16 tanh | 16 sigmoid] of channels 16*(3*wave+bn)..+15
     bf16_t* acts = static_cast<bf16_t*>(a.acts) + layer * H;
-    const float* cond = a.cond ? a.cond + (size_t)layer * 2 * H : nullptr;
+    const float* cond = COND ? a.cond + (size_t)layer * 2 * H : nullptr;
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int c = 16 * (3 * wave + bn) + 8 * g + 4 * h;
+        const int c = 16 * (3 * wave_e + bn) + 8 * g + 4 * h_e;
         const float4 bt = *reinterpret_cast<const float4*>(bias1 + c), bs = *reinterpret_cast<const float4*>(bias1 + H + c);
         const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
         for (int bm = 0; bm < 2; ++bm) {
-          const int t = 32 * bm + r, m = s0 + t;
-          const int mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
+          const int t = 32 * bm + r_e, m = s0 + t;
           float ctv[4] = {}, csv[4] = {};
-          if (cond) {
-            const float* cp = cond + (size_t)(a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc) * a.ldc + c;
+          if (COND) {
+            const float* cp = cond + (size_t)cb[bm] * a.ldc + c;
             const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
             ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
           }
@@ -197,7 +286,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float vt = acc[bn][bm][4 * g + j] + btv[j], vs = acc[bn][bm][4 * g + j + 8] + bsv[j];
-            if (drop_thresh && !(WNS_EXP & 4)) {                       // x_in = drop(conv(x)) (modules.py:153)
+            if (DROP && !(WNS_EXP & 4)) {                              // x_in = drop(conv(x)) (modules.py:153)
               bool kt, ks;
               drop_keep_gate(seed, m, c + j, drop_thresh16(drop_thresh), kt, ks);
               vt = kt ? vt * drop_scale : 0.0f;
@@ -213,21 +302,39 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
           *reinterpret_cast<uint2*>(At + t * AP + c) = pack4(aa[0], aa[1], aa[2], aa[3]);
         }
       }
+    PH(3 + 6 * layer);
     __syncthreads();                                                   // At, Tl, Sl complete
-    if (!(WNS_EXP & 1)) {
+    PH(4 + 6 * layer);
+    auto store_gate_tiles = [&]() {
+      if (WNS_EXP & 1) return;
       // the rows this workgroup owns are ONE contiguous block of T / S (and 384-byte pieces of the acts rows): 16 bytes per lane,
-      // consecutive lanes on consecutive addresses
-      for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
-        const int row = idx / CPR, c8 = idx - row * CPR, t = halo + row, m = s0 + t;
-        if (m < R) {
-          const uint4 vt = *reinterpret_cast<const uint4*>(Tl + t * AP + c8 * 8), vs = *reinterpret_cast<const uint4*>(Sl + t * AP + c8 * 8),
-                      va = *reinterpret_cast<const uint4*>(At + t * AP + c8 * 8);
-          *reinterpret_cast<uint4*>(Tt + (size_t)m * H + c8 * 8) = vt;
-          *reinterpret_cast<uint4*>(Ss + (size_t)m * H + c8 * 8) = vs;
-          *reinterpret_cast<uint4*>(acts + (size_t)m * a.ldacts + c8 * 8) = va;
+      // consecutive lanes on consecutive addresses; all the LDS reads first, then the stores (as a rolled loop every chunk paid its
+      // own LDS round trip)
+      constexpr int NC = (BM * CPR + 255) / 256, NP = 2;               // <= 6 chunks per thread and tile, in passes of NP
+#pragma unroll 1
+      for (int i0 = 0; i0 < NC; i0 += NP) {
+        uint4 vt[NP], vs[NP], va[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int idx = tid_e + 256 * (i0 + i), row = idx / CPR, c8 = idx - row * CPR, t = halo + row;
+          vt[i] = vs[i] = va[i] = make_uint4(0, 0, 0, 0);
+          if (idx < own * CPR) {
+            vt[i] = *reinterpret_cast<const uint4*>(Tl + t * AP + c8 * 8); vs[i] = *reinterpret_cast<const uint4*>(Sl + t * AP + c8 * 8);
+            va[i] = *reinterpret_cast<const uint4*>(At + t * AP + c8 * 8);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int idx = tid_e + 256 * (i0 + i), row = idx / CPR, c8 = idx - row * CPR, m = s0 + halo + row;
+          if (idx < own * CPR && m < R) {
+            *reinterpret_cast<uint4*>(Tt + (size_t)m * H + c8 * 8) = vt[i];
+            *reinterpret_cast<uint4*>(Ss + (size_t)m * H + c8 * 8) = vs[i];
+            *reinterpret_cast<uint4*>(acts + (size_t)m * a.ldacts + c8 * 8) = va[i];
+          }
         }
       }
-    }
+    };
+    if (!WNS_FIXA || last) store_gate_tiles();
     if (last) break;
 
     // stage 2: x_next = (x + acts @ W_res^T + b_res) * mask -> the next layer's LDS tile (+ HBM for the owned rows)
@@ -243,14 +350,23 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
         const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
 #pragma unroll
         for (int bn = 0; bn < 3; ++bn) {
-          acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
-          if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk + KK2 / 2, lane);
+          acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % R2][bn]), bfm, acc2[bn], 0, 0, 0);
+          if (R2 < KK2 && kk + R2 < KK2) ring2[kk % R2][bn] = ldfrag(W2, (3 * wn2 + bn) * KK2 + kk + R2, lane);
         }
       }
     }
+    PH(5 + 6 * layer);
+#if WNS_FIXA
+    {                                          // the next layer's first ring steps, ahead of the x_next stores
+      const bf16_t* W1n = static_cast<const bf16_t*>(pick(a.w_in, layer + 1));
+#pragma unroll
+      for (int p = 0; p < RING - 1; ++p) w_load_l(W1n, p, ring[p]);
+    }
+    store_gate_tiles();                        // T, S, acts: the tiles are untouched until the next layer's epilogue
+#endif
     {
-      const int t = 32 * wm2 + r, m = s0 + t;
-      const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+      const int t = 32 * wm2 + r;
+      const float rm = rm2;
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -265,18 +381,33 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
         }
     }
     __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
+    PH(6 + 6 * layer);
     bf16_t* tmp = Xc; Xc = Xn; Xn = tmp;
     if (!(WNS_EXP & 1)) {                                              // x_next of the owned rows, whole rows from the finished tile
-      for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
-        const int row = idx / CPR, c8 = idx - row * CPR, t = halo + row, m = s0 + t;
-        if (m < R) *reinterpret_cast<uint4*>(xo + (size_t)m * H + c8 * 8) = *reinterpret_cast<const uint4*>(Xc + (t + 2) * AP + c8 * 8);
+      constexpr int NC = (BM * CPR + 255) / 256, NP = 3;
+#pragma unroll 1
+      for (int i0 = 0; i0 < NC; i0 += NP) {
+        uint4 vx[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int idx = tid_e + 256 * (i0 + i), row = idx / CPR, c8 = idx - row * CPR;
+          vx[i] = make_uint4(0, 0, 0, 0);
+          if (idx < own * CPR) vx[i] = *reinterpret_cast<const uint4*>(Xc + (halo + row + 2) * AP + c8 * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int idx = tid_e + 256 * (i0 + i), row = idx / CPR, c8 = idx - row * CPR, m = s0 + halo + row;
+          if (idx < own * CPR && m < R) *reinterpret_cast<uint4*>(xo + (size_t)m * H + c8 * 8) = vx[i];
+        }
       }
     }
     if (threadIdx.x < 4 * 24) {                                        // rows 0, 1, 66, 67 of the tile after next
       const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
     }
+    PH(7 + 6 * layer);
   }
+  PH(40);
   if (a.stamps && threadIdx.x == 0)
     atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
 }
@@ -294,6 +425,7 @@ constexpr int BWD_DT = XR * DP * 2;           // 53 312 B
 static_assert(EX_BYTES <= BWD_DT, "the exchange buffer lives in the d pre tile");
 constexpr int SBWD_LDS = BWD_DT + 4 * BM * AP * 2;       // d pre tile | dX tile | skip-gradient, tanh, sigmoid staging tiles = 155 712 B
 
+template <bool DROP>
 __device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)[4], const float (&s)[4], uint32_t seed, int m, int n,
                                           uint32_t thresh, float scale, uint2& pt, uint2& ps, uint2& ct, uint2& cs)
 {
@@ -301,7 +433,7 @@ __device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)
 #pragma unroll
   for (int j = 0; j < 4; ++j) { gt[j] = dd[j] * s[j] * (1.0f - t[j] * t[j]); gs[j] = dd[j] * t[j] * s[j] * (1.0f - s[j]); }
   ct = pack4(gt[0], gt[1], gt[2], gt[3]); cs = pack4(gs[0], gs[1], gs[2], gs[3]);      // before the dropout mask: d cond
-  if (thresh) {
+  if (DROP) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bool kt, ks;
@@ -313,17 +445,40 @@ __device__ __forceinline__ void gate_bwd4(const float (&dd)[4], const float (&t)
   pt = pack4(gt[0], gt[1], gt[2], gt[3]); ps = pack4(gs[0], gs[1], gs[2], gs[3]);
 }
 
+constexpr int RB = 2 * RING - 1;               // backward ring: half the fragments per step, twice the depth for the same registers
+constexpr int B_NS = 2 * H / 64, B_NIT = B_NS * TAPS, B_KS = 2 * H / 16, B_NBT = H / 32;  // 6 slices, 30 steps, 24 k-steps per tap, 6 blocks
+
+// step `it` of a data-gradient conv's weight stream: this wave's column half (wn) and K half (wk)
+__device__ __forceinline__ void bwd_w_load(const bf16_t* W1, int it, int wn, int wk, int lane, uint4 (&dst)[2][3])
+{
+  const int slice = it / TAPS, tap = it - slice * TAPS;
+  const bf16_t* Wt = pinned(W1 + (size_t)((tap * B_NBT + 3 * wn) * B_KS + slice * 4 + 2 * wk) * 512);
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+    for (int bn = 0; bn < 3; ++bn) dst[k2][bn] = ldfrag(Wt, bn * B_KS + k2, lane);
+}
+// the first RB - 1 steps: issued by the PREVIOUS step (or the kernel's head) ahead of its stores — vmcnt retires in order, so a
+// wait for these fragments would otherwise also wait for every store issued before them (see the forward kernel)
+__device__ __forceinline__ void bwd_ring_prologue(const void* w, int lane, uint4 (&ring)[RB][2][3])
+{
+  const int wave = wave_scalar(), wn = wave & 1, wk = wave >> 1;
+  const bf16_t* W1 = pinned(static_cast<const bf16_t*>(w));
+#pragma unroll
+  for (int p = 0; p < RB - 1; ++p) bwd_w_load(W1, p, wn, wk, lane, ring[p]);
+}
+
 // one step j of the chain (compile-time j: every pointer is a kernel argument, every fragment address is formed where it is used)
-template <int J>
+template <int J, bool COND, bool DROP>
 __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t drop_thresh, float drop_scale, uint32_t seed_x,
-                                         bf16_t* Dt, float* Ex, bf16_t* At, int s0, int halo, int lane, int wave)
+                                         bf16_t* Dt, float* Ex, bf16_t* At, int s0, int halo, int lane, int wave, uint4 (&ring)[RB][2][3], float rm)
 {
   const int r = lane & 31, h = lane >> 5;
   wave = wave_scalar();
   const int wn = wave & 1, wk = wave >> 1;     // stage 1: column half, K half;  afterwards wk doubles as the row half
   const int n_layers = a.n_layers, R = a.R;
   const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
-  constexpr int NS = 2 * H / 64, NIT = NS * TAPS, KS = 2 * H / 16, NBT = H / 32;  // 6 slices, 30 steps, 24 k-steps per tap, 6 blocks
+  constexpr int NIT = B_NIT;
   const bf16_t* W1 = pinned(static_cast<const bf16_t*>(a.w_in_d[J]));
   f32x16_t acc[3][2];
 #pragma unroll
@@ -332,18 +487,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
     for (int bm = 0; bm < 2; ++bm)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
-  constexpr int RB = 2 * RING - 1;             // half the fragments per step: twice the depth for the same registers
-  uint4 ring[RB][2][3];
-  auto w_load = [&](int it, uint4 (&dst)[2][3]) {
-    const int slice = it / TAPS, tap = it - slice * TAPS;
-    const bf16_t* Wt = pinned(W1 + (size_t)((tap * NBT + 3 * wn) * KS + slice * 4 + 2 * wk) * 512);
-#pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-      for (int bn = 0; bn < 3; ++bn) dst[k2][bn] = ldfrag(Wt, bn * KS + k2, lane);
-  };
-#pragma unroll
-  for (int p = 0; p < RB - 1; ++p) w_load(p, ring[p]);
+  auto w_load = [&](int it, uint4 (&dst)[2][3]) { bwd_w_load(W1, it, wn, wk, lane, dst); };
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int slice = it / TAPS, tap = it - slice * TAPS;
@@ -362,15 +506,36 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  PH(2 + 8 * (3 - J));
   // second-stage weights (the layer below): this wave's 96 columns (wn), rows 32*wk
   constexpr int JL = J > 0 ? J - 1 : 0;
   const bf16_t* W2 = pinned(static_cast<const bf16_t*>(a.w_res_d[JL]));
-  uint4 ring2[KK2 / 2][3];
+  uint4 ring2[KK2][3];                         // all of them now: reloaded inside the 36-MFMA loop they arrived after it needed them
   if (J > 0) {
 #pragma unroll
-    for (int kk = 0; kk < KK2 / 2; ++kk)
+    for (int kk = 0; kk < KK2; ++kk)
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn) ring2[kk][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk, lane);
+  }
+  // the gate backward's three row operands (skip-path gradient, saved tanh, saved sigmoid of layer j-1, all 64 rows of the tile) are
+  // fetched as whole rows — read in the MFMA layout, every load instruction touched 16 bytes in each of 32 rows — and handed to the
+  // epilogue through LDS; they are issued here, ahead of this step's stores
+  constexpr int JLp = J > 0 ? J - 1 : 0;
+  constexpr int NPRE = (BM * CPR + 255) / 256;                       // 6 chunks per thread and operand
+  uint4 pre[3][NPRE];
+  if (J > 0) {
+    const bf16_t* Tg = static_cast<const bf16_t*>(a.gate_t[JLp]);
+    const bf16_t* Sg = static_cast<const bf16_t*>(a.gate_s[JLp]);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, mm = s0 + row;
+      pre[0][i] = pre[1][i] = pre[2][i] = make_uint4(0, 0, 0, 0);
+      if (mm >= 0 && mm < R) {
+        pre[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)mm * a.ldvs + JLp * H + c8 * 8);
+        pre[1][i] = *reinterpret_cast<const uint4*>(Tg + (size_t)mm * H + c8 * 8);
+        pre[2][i] = *reinterpret_cast<const uint4*>(Sg + (size_t)mm * H + c8 * 8);
+      }
+    }
   }
   __syncthreads();                            // every wave is done with the d pre tile: the exchange buffer may overwrite it
 
@@ -391,11 +556,11 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
 #pragma unroll
       for (int e = 0; e < 16; ++e) sum[bn][e] = (wk ? acc[bn][1][e] : acc[bn][0][e]) + theirs[(bn * 16 + e) * 64 + lane];
   }
+  PH(3 + 8 * (3 - J));
   // dX_j = (conv^T(d pre_j) + dX_{j+1}) * mask -> HBM (owned rows) and the stage-2 tile (which still holds dX_{j+1})
   const int t = 32 * wk + r, m = s0 + t;
   const bool mine_row = t >= halo && t < BM - halo && m < R;
   {
-    const float rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -409,39 +574,29 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       }
   }
   __syncthreads();
-  {
+  PH(4 + 8 * (3 - J));
+  auto store_dx = [&]() {
     // dX_j of the owned rows leaves as whole rows from the finished tile (the MFMA layout gives a store 16 bytes in each of 32 rows)
     bf16_t* dx = static_cast<bf16_t*>(a.dx[J]);
     const int own = BM - 2 * halo;
-    for (int idx = threadIdx.x; idx < own * CPR; idx += 256) {
-      const int row = idx / CPR, c8 = idx - row * CPR, tt = halo + row, mm = s0 + tt;
-      if (mm < R) *reinterpret_cast<uint4*>(dx + (size_t)mm * H + c8 * 8) = *reinterpret_cast<const uint4*>(At + tt * AP + c8 * 8);
+    constexpr int NC = (BM * CPR + 255) / 256;
+    uint4 vx[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
+      vx[i] = make_uint4(0, 0, 0, 0);
+      if (idx < own * CPR) vx[i] = *reinterpret_cast<const uint4*>(At + (halo + row) * AP + c8 * 8);
     }
-  }
-  if (J == 0) return;                                               // bottom: dX_0 is the gradient at the WaveNet's input
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, mm = s0 + halo + row;
+      if (idx < own * CPR && mm < R) *reinterpret_cast<uint4*>(dx + (size_t)mm * H + c8 * 8) = vx[i];
+    }
+  };
+  if (J == 0) { store_dx(); return; }                               // bottom: dX_0 is the gradient at the WaveNet's input
 
   // d acts_{j-1} = dX_j W_res + skip-path gradient -> gate backward -> d pre_{j-1}: the next tile (+ HBM for the owned rows)
-  // the gate backward's three row operands (skip-path gradient, saved tanh, saved sigmoid of layer j-1, all 64 rows of the tile) are
-  // fetched as whole rows under the GEMM below and handed to the epilogue through LDS — read in the MFMA layout, every load
-  // instruction touched 16 bytes in each of 32 rows
-  constexpr int JLp = J > 0 ? J - 1 : 0;
-  constexpr int NPRE = (BM * CPR + 255) / 256;                       // 6 chunks per thread and operand
   bf16_t* Vl = At + BM * AP; bf16_t* Tl = Vl + BM * AP; bf16_t* Sl = Tl + BM * AP;
-  uint4 pre[3][NPRE];
-  {
-    const bf16_t* Tg = static_cast<const bf16_t*>(a.gate_t[JLp]);
-    const bf16_t* Sg = static_cast<const bf16_t*>(a.gate_s[JLp]);
-#pragma unroll
-    for (int i = 0; i < NPRE; ++i) {
-      const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, mm = s0 + row;
-      pre[0][i] = pre[1][i] = pre[2][i] = make_uint4(0, 0, 0, 0);
-      if (mm >= 0 && mm < R) {
-        pre[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)mm * a.ldvs + JLp * H + c8 * 8);
-        pre[1][i] = *reinterpret_cast<const uint4*>(Tg + (size_t)mm * H + c8 * 8);
-        pre[2][i] = *reinterpret_cast<const uint4*>(Sg + (size_t)mm * H + c8 * 8);
-      }
-    }
-  }
   f32x16_t acc2[3];
 #pragma unroll
   for (int bn = 0; bn < 3; ++bn)
@@ -454,11 +609,13 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(ab + kk * 16);
 #pragma unroll
       for (int bn = 0; bn < 3; ++bn) {
-        acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk % (KK2 / 2)][bn]), bfm, acc2[bn], 0, 0, 0);
-        if (kk + KK2 / 2 < KK2) ring2[kk % (KK2 / 2)][bn] = ldfrag(W2, (3 * wn + bn) * KK2 + kk + KK2 / 2, lane);
+        acc2[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring2[kk][bn]), bfm, acc2[bn], 0, 0, 0);
       }
     }
   }
+  PH(5 + 8 * (3 - J));
+  bwd_ring_prologue(a.w_in_d[JL], lane, ring);                      // the next step's first fragments, then this step's stores
+  store_dx();                                                       // (the dX tile stays as it is until the next step's epilogue)
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) {
     const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
@@ -467,6 +624,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
     *reinterpret_cast<uint4*>(Sl + row * AP + c8 * 8) = pre[2][i];
   }
   __syncthreads();
+  PH(6 + 8 * (3 - J));
   {
     bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
     const uint32_t seed = (a.drop_seed + (uint32_t)JL) ^ seed_x;
@@ -484,8 +642,8 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
           unpack4(*reinterpret_cast<const uint2*>(Sl + t * AP + n), sg);
 #pragma unroll
           for (int q = 0; q < 4; ++q) dd[q] = acc2[bn][4 * g + q] + vs[q];
-          gate_bwd4(dd, tt, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
-          if (mine_row && dpre_c) {                                  // (speaker-conditioned configs only)
+          gate_bwd4<DROP>(dd, tt, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
+          if (COND && mine_row) {                                    // (speaker-conditioned configs only)
             *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
             *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
           }
@@ -494,22 +652,38 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
         *reinterpret_cast<uint2*>(Dt + (t + 2) * DP + H + n) = ps;
       }
   }
+  PH(7 + 8 * (3 - J));
   __syncthreads();                                                   // the next conv's input tile is complete
+  PH(8 + 8 * (3 - J));
   {
     // d pre_{j-1} of the owned rows: whole 768-byte rows from the tile (read-only until the next step's exchange, which follows a barrier)
     bf16_t* dpre = static_cast<bf16_t*>(a.dpre[JL]);
     const int own = BM - 2 * halo;
-    constexpr int CPR2 = 2 * H / 8;
-    for (int idx = threadIdx.x; idx < own * CPR2; idx += 256) {
-      const int row = idx / CPR2, c8 = idx - row * CPR2, tt = halo + row, mm = s0 + tt;
-      if (mm < R) *reinterpret_cast<uint4*>(dpre + (size_t)mm * 2 * H + c8 * 8) = *reinterpret_cast<const uint4*>(Dt + (tt + 2) * DP + c8 * 8);
+    constexpr int CPR2 = 2 * H / 8, NC = (BM * CPR2 + 255) / 256, NP = 4;      // 12 chunks per thread, in passes of NP
+#pragma unroll
+    for (int i0 = 0; i0 < NC; i0 += NP) {
+      uint4 vx[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int idx = threadIdx.x + 256 * (i0 + i), row = idx / CPR2, c8 = idx - row * CPR2;
+        vx[i] = make_uint4(0, 0, 0, 0);
+        if (idx < own * CPR2) vx[i] = *reinterpret_cast<const uint4*>(Dt + (halo + row + 2) * DP + c8 * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int idx = threadIdx.x + 256 * (i0 + i), row = idx / CPR2, c8 = idx - row * CPR2, mm = s0 + halo + row;
+        if (idx < own * CPR2 && mm < R) *reinterpret_cast<uint4*>(dpre + (size_t)mm * 2 * H + c8 * 8) = vx[i];
+      }
     }
   }
+  PH(9 + 8 * (3 - J));
 }
 
+template <bool COND, bool DROP>
 __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_args a, uint32_t drop_thresh, float drop_scale)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  PH(0);
   const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_layers = a.n_layers, R = a.R;
@@ -519,8 +693,17 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
   float* Ex = reinterpret_cast<float*>(smem);
   bf16_t* At = reinterpret_cast<bf16_t*>(smem + BWD_DT);
   const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
+  uint4 ring[RB][2][3];
+  bwd_ring_prologue(pick(a.w_in_d, n_layers - 1), lane, ring);      // ahead of the head's d pre stores
+  float rm;                                                         // the row mask of the row this lane finishes in every dX epilogue
+  {
+    const int m = s0 + 32 * (wave >> 1) + (lane & 31);
+    rm = (m >= 0 && m < R) ? a.rowmask[m] : 0.0f;
+  }
 
-  // top layer: d acts = the skip-path gradient only -> d pre on all 68 rows of the tile (row-local)
+  // top layer: d acts = the skip-path gradient only -> d pre on all 68 rows of the tile (row-local).  Whole rows, 16 bytes per lane,
+  // EVERY load issued before the first use: as a loop of 8-byte loads, each waited for where it was used, this head was 13 serial
+  // L2 round trips = 30 k of the launch's 189 k cycles (tools/wn_stack_phases.py).
   {
     const int L = n_layers - 1;
     const bf16_t* Tt = static_cast<const bf16_t*>(pick(a.gate_t, L));
@@ -528,39 +711,66 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
     bf16_t* dpre = static_cast<bf16_t*>(pick(a.dpre, L));
     bf16_t* dpre_c = static_cast<bf16_t*>(pick(a.dpre_c, L));
     const uint32_t seed = (a.drop_seed + (uint32_t)L) ^ seed_x;
-    for (int item = threadIdx.x; item < XR * (H / 4); item += 256) {
-      const int u = item / (H / 4), n = 4 * (item - u * (H / 4)), m = s0 - 2 + u;
-      uint2 pt = make_uint2(0, 0), ps = pt, ct = pt, cs = pt;
+    constexpr int NH = (XR * CPR + 255) / 256;                       // 7 chunks of 8 channels per thread
+    uint4 hv[3][NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = threadIdx.x + 256 * i, u = idx / CPR, c8 = idx - u * CPR, m = s0 - 2 + u;
+      hv[0][i] = hv[1][i] = hv[2][i] = make_uint4(0, 0, 0, 0);
+      if (u < XR && m >= 0 && m < R) {
+        hv[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)m * a.ldvs + L * H + c8 * 8);
+        hv[1][i] = *reinterpret_cast<const uint4*>(Tt + (size_t)m * H + c8 * 8);
+        hv[2][i] = *reinterpret_cast<const uint4*>(Ss + (size_t)m * H + c8 * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int idx = threadIdx.x + 256 * i, u = idx / CPR, c8 = idx - u * CPR, m = s0 - 2 + u, n = c8 * 8;
+      if (u >= XR) continue;
+      uint2 pt[2], ps[2], ct[2], cs[2];
+      pt[0] = pt[1] = ps[0] = ps[1] = ct[0] = ct[1] = cs[0] = cs[1] = make_uint2(0, 0);
       if (m >= 0 && m < R) {
-        float dd[4], t[4], sg[4];
-        unpack4(*reinterpret_cast<const uint2*>(via + (size_t)m * a.ldvs + L * H + n), dd);
-        unpack4(*reinterpret_cast<const uint2*>(Tt + (size_t)m * H + n), t);
-        unpack4(*reinterpret_cast<const uint2*>(Ss + (size_t)m * H + n), sg);
-        gate_bwd4(dd, t, sg, seed, m, n, drop_thresh, drop_scale, pt, ps, ct, cs);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float dd[4], t[4], sg[4];
+          unpack4(q ? make_uint2(hv[0][i].z, hv[0][i].w) : make_uint2(hv[0][i].x, hv[0][i].y), dd);
+          unpack4(q ? make_uint2(hv[1][i].z, hv[1][i].w) : make_uint2(hv[1][i].x, hv[1][i].y), t);
+          unpack4(q ? make_uint2(hv[2][i].z, hv[2][i].w) : make_uint2(hv[2][i].x, hv[2][i].y), sg);
+          gate_bwd4<DROP>(dd, t, sg, seed, m, n + 4 * q, drop_thresh, drop_scale, pt[q], ps[q], ct[q], cs[q]);
+        }
         if (u - 2 >= halo && u - 2 < BM - halo) {
-          *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + n) = pt;
-          *reinterpret_cast<uint2*>(dpre + (size_t)m * 2 * H + H + n) = ps;
-          if (dpre_c) {
-            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + n) = ct;
-            *reinterpret_cast<uint2*>(dpre_c + (size_t)m * 2 * H + H + n) = cs;
+          *reinterpret_cast<uint4*>(dpre + (size_t)m * 2 * H + n) = make_uint4(pt[0].x, pt[0].y, pt[1].x, pt[1].y);
+          *reinterpret_cast<uint4*>(dpre + (size_t)m * 2 * H + H + n) = make_uint4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
+          if (COND) {
+            *reinterpret_cast<uint4*>(dpre_c + (size_t)m * 2 * H + n) = make_uint4(ct[0].x, ct[0].y, ct[1].x, ct[1].y);
+            *reinterpret_cast<uint4*>(dpre_c + (size_t)m * 2 * H + H + n) = make_uint4(cs[0].x, cs[0].y, cs[1].x, cs[1].y);
           }
         }
       }
-      *reinterpret_cast<uint2*>(Dt + u * DP + n) = pt;
-      *reinterpret_cast<uint2*>(Dt + u * DP + H + n) = ps;
+      *reinterpret_cast<uint4*>(Dt + u * DP + n) = make_uint4(pt[0].x, pt[0].y, pt[1].x, pt[1].y);
+      *reinterpret_cast<uint4*>(Dt + u * DP + H + n) = make_uint4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
     }
   }
   __syncthreads();
+  PH(1);
   // the chain, top to bottom (workgroup-uniform branches; each step is its own straight-line code)
-  if (n_layers > 3) bwd_step<3>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
-  if (n_layers > 2) bwd_step<2>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
-  if (n_layers > 1) bwd_step<1>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
-  bwd_step<0>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave);
+  if (n_layers > 3) bwd_step<3, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  if (n_layers > 2) bwd_step<2, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  if (n_layers > 1) bwd_step<1, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  bwd_step<0, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  PH(40);
 }
 
 inline bool al16(const void* p) { return !((uintptr_t)p & 15); }
 
 }  // namespace
+
+#if WNS_PHASES
+extern "C" int gt_dev_wns_phases(void* dst, size_t bytes)
+{
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wns_ph), bytes < sizeof(g_wns_ph) ? bytes : sizeof(g_wns_ph)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int gt_wn_stack_rows_per_workgroup(int n_layers) { return BM - 4 * (n_layers - 1); }
 
@@ -585,15 +795,19 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
     if (a.drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
   }
+  typedef void (*kern_t)(gt_wn_stack_fwd_args, uint32_t, float);
+  static const kern_t kerns[4] = {gt_wn_stack_fwd_kernel<false, false>, gt_wn_stack_fwd_kernel<false, true>,
+                                  gt_wn_stack_fwd_kernel<true, false>, gt_wn_stack_fwd_kernel<true, true>};
   static bool attr = false;                    // > 64 KB of LDS: opt in once per process
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_FWD_LDS) != hipSuccess)
-      return GT_E_LAUNCH;
+    for (kern_t k : kerns)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_FWD_LDS) != hipSuccess)
+        return GT_E_LAUNCH;
     attr = true;
   }
   const int own = BM - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
-  hipLaunchKernelGGL(gt_wn_stack_fwd_kernel, grid, block, STACK_FWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  hipLaunchKernelGGL(kerns[(a.cond ? 2 : 0) + (thresh ? 1 : 0)], grid, block, STACK_FWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }
 
@@ -617,14 +831,21 @@ extern "C" int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream)
     if (a.drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
   }
+  bool cond = false;                           // d cond outputs: all layers or none
+  for (int i = 0; i < a.n_layers; ++i) cond = cond || a.dpre_c[i];
+  for (int i = 0; i < a.n_layers; ++i) if (cond && !a.dpre_c[i]) return GT_E_INVAL;
+  typedef void (*kern_t)(gt_wn_stack_bwd_args, uint32_t, float);
+  static const kern_t kerns[4] = {gt_wn_stack_bwd_kernel<false, false>, gt_wn_stack_bwd_kernel<false, true>,
+                                  gt_wn_stack_bwd_kernel<true, false>, gt_wn_stack_bwd_kernel<true, true>};
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_wn_stack_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SBWD_LDS) != hipSuccess)
-      return GT_E_LAUNCH;
+    for (kern_t k : kerns)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, SBWD_LDS) != hipSuccess)
+        return GT_E_LAUNCH;
     attr = true;
   }
   const int own = BM - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
-  hipLaunchKernelGGL(gt_wn_stack_bwd_kernel, grid, block, SBWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  hipLaunchKernelGGL(kerns[(cond ? 2 : 0) + (thresh ? 1 : 0)], grid, block, SBWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }

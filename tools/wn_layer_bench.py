@@ -96,9 +96,14 @@ def bwd_wn(wn, stack_on):
 for w in wns:
     bwd_wn(w, True)
 timeit("WN backward chain: ONE stack launch", lambda k: bwd_wn(wns[k % 12], True), launches=24)
-timeit("WN backward chain: gate_bwd + 4 layer launches", lambda k: bwd_wn(wns[k % 12], False), launches=24)
+STACK_ONLY = len(sys.argv) > 1 and sys.argv[1] == 'stack'
+if not STACK_ONLY:
+    timeit("WN backward chain: gate_bwd + 4 layer launches", lambda k: bwd_wn(wns[k % 12], False), launches=24)
 timeit("WN forward, 4 layers: ONE stack launch", lambda k: stack(wns[k % 12]), launches=24)
-timeit("WN forward, 4 layers: four layer launches", lambda k: layers(wns[k % 12]), launches=24)
+if not STACK_ONLY:
+    timeit("WN forward, 4 layers: four layer launches", lambda k: layers(wns[k % 12]), launches=24)
+if len(sys.argv) > 1 and sys.argv[1] == 'stack':          # the stack kernels only (tools/stack_variants.sh)
+    sys.exit(0)
 QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 for frac in ((1,) if QUICK else (1, 2, 4, 8)):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
     Rs = R // frac // 64 * 64
