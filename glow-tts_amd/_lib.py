@@ -92,6 +92,8 @@ PROTOTYPES = {
     "gt_wn_stack_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_bwd": (c_int, [c_void_p, c_void_p]),
+    "gt_boundary_param_partials": (c_int, []),
+    "gt_boundary_param_reduce": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_dds_sep_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_dds_out_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),
@@ -165,7 +167,8 @@ class BoundaryBwdArgs(ctypes.Structure):
                 ("sigmoid_scale", c_int), ("dx_out", c_void_p), ("dout", c_void_p), ("w_end_d", c_void_p), ("ks_end_d", c_int),
                 ("dwn_out", c_void_p), ("w_skip_d", c_void_p), ("ks_skip_d", c_int), ("via_skip", c_void_p), ("ldvs", c_int),
                 ("rowmask", c_void_p), ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int),
-                ("dz_bct", c_void_p), ("dx_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p)]
+                ("dz_bct", c_void_p), ("dx_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p),
+                ("pg_partial", c_void_p)]
 
 
 def fill_args(cls, **kw):

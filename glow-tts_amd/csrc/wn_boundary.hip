@@ -84,14 +84,24 @@ template <int NB, int KK>
 __device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ W, int KS, int nb0, const bf16_t* Brow, int lane, WRing<NB, KK>& ring,
                                          f32x16_t (&acc)[NB])
 {
-  constexpr int D = KK < RD ? KK : RD;
+  // blocks of CH k-steps: their MFMAs, then the loads that refill the ring slots those MFMAs have just read.  (A load placed behind
+  // every MFMA holds the wave's issue for longer than the MFMA it was meant to hide behind: wn_stack.hip, round 3.)
+  constexpr int D = KK < RD ? KK : RD, CH = 4;
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) {
-    const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(Brow + kk * 16);
+  for (int k0 = 0; k0 < KK; k0 += CH) {
 #pragma unroll
-    for (int bn = 0; bn < NB; ++bn) {
-      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring.v[kk % D][bn]), bfm, acc[bn], 0, 0, 0);
-      if (kk + D < KK) ring.v[kk % D][bn] = ldfrag(W, (nb0 + bn) * KS + kk + D, lane);
+    for (int kk = k0; kk < k0 + CH && kk < KK; ++kk) {
+      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(Brow + kk * 16);
+#pragma unroll
+      for (int bn = 0; bn < NB; ++bn) acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring.v[kk % D][bn]), bfm, acc[bn], 0, 0, 0);
+    }
+    if (k0 + D < KK) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = k0; kk < k0 + CH && kk + D < KK; ++kk)
+#pragma unroll
+        for (int bn = 0; bn < NB; ++bn) ring.v[kk % D][bn] = ldfrag(W, (nb0 + bn) * KS + kk + D, lane);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -124,13 +134,23 @@ __device__ __forceinline__ void skip_slice(const u32x4_t (&xr)[6], bf16_t* As, c
   }
   __syncthreads();
   const bf16_t* brow = As + (L * BM + 32 * wm + r) * AP + 8 * h;
+  constexpr int CH = 4;
 #pragma unroll
-  for (int k2 = 0; k2 < H / 16; ++k2) {
-    const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
+  for (int k0 = 0; k0 < H / 16; k0 += CH) {
 #pragma unroll
-    for (int bn = 0; bn < 3; ++bn) {
-      acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[(kbase + k2) % RD][bn]), bfm, acc[bn], 0, 0, 0);
-      if (kbase + k2 + RD < KK && !(WNB_EXP & 8)) ring[(kbase + k2) % RD][bn] = ldfrag(Wskip, (3 * wn + bn) * KK + kbase + k2 + RD, lane);
+    for (int k2 = k0; k2 < k0 + CH; ++k2) {
+      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + k2 * 16);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn) acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[(kbase + k2) % RD][bn]), bfm, acc[bn], 0, 0, 0);
+    }
+    if (kbase + k0 + RD < KK && !(WNB_EXP & 8)) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k2 = k0; k2 < k0 + CH; ++k2)
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn)
+          if (kbase + k2 + RD < KK) ring[(kbase + k2) % RD][bn] = ldfrag(Wskip, (3 * wn + bn) * KK + kbase + k2 + RD, lane);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -168,7 +188,8 @@ constexpr int F_AS = 0;                                    // acts slices [4][64
 constexpr int F_O = BM * AP * 2;                           // m | logs tile [64][ZP] fp32 (over slices 1, 2 once they are dead)
 constexpr int F_Z = F_O + BM * ZP * 4;                     // z tile [64][ZP] fp32
 constexpr int F_RS = (F_Z + BM * ZP * 4 > NL * BM * AP * 2 ? F_Z + BM * ZP * 4 : NL * BM * AP * 2);   // row sums [64] fp32
-constexpr int FWD_LDS = F_RS + BM * 4;
+constexpr int F_BIAS = F_RS + BM * 4;                      // b_skip [192] | b_end [160 (+ 32 zero)] | b_start [192] fp32, staged once
+constexpr int FWD_LDS = F_BIAS + 3 * H * 4 + BM * 4;       // + the tile's row mask [64]
 static_assert(F_O + BM * ZP * 4 <= 3 * BM * AP * 2, "the m | logs tile must stay clear of acts slice 3");
 
 template <bool TAIL, bool HEAD>
@@ -184,6 +205,21 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
   float* rowsum = reinterpret_cast<float*>(smem + F_RS);
   const int mrow = m0 + 32 * wm + r;                        // this lane's row in the MFMA epilogues
   const float rm_l = mrow < R ? a.rowmask[mrow] : 0.0f;
+  // the three convs' biases: read from global memory inside the MFMA epilogues they cost an L2 round trip per (block, group)
+  float* Bs = reinterpret_cast<float*>(smem + F_BIAS);
+  if (threadIdx.x < 3 * H / 4) {
+    const int which = threadIdx.x / (H / 4), o = threadIdx.x - which * (H / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (which == 0) { if (TAIL) v = reinterpret_cast<const float4*>(a.b_skip)[o]; }
+    else if (which == 1) { if (TAIL && o < C / 4) v = reinterpret_cast<const float4*>(a.b_end)[o]; }
+    else if (HEAD) v = reinterpret_cast<const float4*>(a.b_start)[o];
+    reinterpret_cast<float4*>(Bs)[threadIdx.x] = v;
+  }
+  float* Rm = Bs + 3 * H;                                    // the tile's row mask (a global load inside a loop that also stores waits
+  if (threadIdx.x >= 192) {                                  // for those stores: vector-memory operations retire in order)
+    const int row = threadIdx.x - 192;
+    Rm[row] = m0 + row < R ? a.rowmask[m0 + row] : 0.0f;
+  }
   PH(0);
 
   if (TAIL) {
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
-        const float4 b4 = *reinterpret_cast<const float4*>(a.b_skip + n);
+        const float4 b4 = *reinterpret_cast<const float4*>(Bs + n);
         const uint2 v = pack4((acc[bn][4 * g] + b4.x) * rm_l, (acc[bn][4 * g + 1] + b4.y) * rm_l,
                               (acc[bn][4 * g + 2] + b4.z) * rm_l, (acc[bn][4 * g + 3] + b4.w) * rm_l);
         *reinterpret_cast<uint2*>(As + (32 * wm + r) * AP + n) = v;
@@ -257,7 +293,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       for (int g = 0; g < 4; ++g) {
         const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
         if (n < C) {
-          const float4 b4 = *reinterpret_cast<const float4*>(a.b_end + n);
+          const float4 b4 = *reinterpret_cast<const float4*>(Bs + H + n);
           *reinterpret_cast<float4*>(Ot + (32 * wm + r) * ZP + n) =
               make_float4(acc2[bn][4 * g] + b4.x, acc2[bn][4 * g + 1] + b4.y, acc2[bn][4 * g + 2] + b4.z, acc2[bn][4 * g + 3] + b4.w);
         }
@@ -303,7 +339,9 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     }
     __syncthreads();
     PH(6);
-    if (wave == 0) {
+    // (the per-utterance log-det atomics are issued at the very end of the kernel: vector-memory operations retire in order, and a
+    // float atomic takes microseconds to come back — issued here, every later wait for a load waited for them too)
+    if (!HEAD && wave == 0) {
       const int gm = m0 + lane < R ? m0 + lane : R - 1;
       utt_atomic_add(a.logdet, rowsum[lane], a.rowutt[gm], lane);
     }
@@ -328,37 +366,42 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
   if (!HEAD) return;
 
   // ActNorm + InvConvNear of the next block on (row, channel group g): members {2g, 2g+1, 80+2g, 80+2g+1}
-  if (blockIdx.x == 0) {                                     // its log-det: (sum logs + (C/4) logdet W) * len_b
-    const float per_frame = a.scal[0] + (float)G * a.scal[1];
-    for (int b = threadIdx.x; b < a.B; b += 256) atomicAdd(a.logdet + b, per_frame * (float)a.len[b]);
-  }
   bf16_t* X0t = reinterpret_cast<bf16_t*>(smem + F_AS);      // At is dead: every wave is past the end conv
   WRing<3, HALF / 16> ring3;                                 // the start conv's weights fly under the ActNorm / InvConvNear phase
   gemm_prefetch<3, HALF / 16>(static_cast<const bf16_t*>(a.w_start), a.ks_start, 3 * wn, lane, ring3);
   {
+    // thread = (channel group g, row phase): the group's ActNorm scale / bias are formed ONCE per thread (as items tid + 256 k every
+    // item had another group: eight parameter loads and four exponentials per item, 8 k of the launch's 47 k cycles)
     float Wm[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Wm[i] = a.w_ic[i];
     bf16_t* y0b = static_cast<bf16_t*>(a.y0_bf16);
+    constexpr int NPH = 256 / G;                               // 6 row phases of 40 threads (16 threads idle)
+    const int g = threadIdx.x % G, ph = threadIdx.x / G;
+    if (ph < NPH) {
+      const float e0 = __expf(a.an_logs[2 * g]), e1 = __expf(a.an_logs[2 * g + 1]);
+      const float e2 = __expf(a.an_logs[HALF + 2 * g]), e3 = __expf(a.an_logs[HALF + 2 * g + 1]);
+      const float c0 = a.an_bias[2 * g], c1 = a.an_bias[2 * g + 1], c2 = a.an_bias[HALF + 2 * g], c3 = a.an_bias[HALF + 2 * g + 1];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const int item = threadIdx.x + 256 * k, row = item / G, g = item - row * G, gm = m0 + row;
-      const float rm = gm < R ? a.rowmask[gm] : 0.0f;
-      const float2 xa = *reinterpret_cast<const float2*>(Zt + row * ZP + 2 * g);
-      const float2 xb = *reinterpret_cast<const float2*>(Zt + row * ZP + HALF + 2 * g);
-      const float a0 = a.an_bias[2 * g] + __expf(a.an_logs[2 * g]) * xa.x, a1 = a.an_bias[2 * g + 1] + __expf(a.an_logs[2 * g + 1]) * xa.y;
-      const float a2 = a.an_bias[HALF + 2 * g] + __expf(a.an_logs[HALF + 2 * g]) * xb.x;
-      const float a3 = a.an_bias[HALF + 2 * g + 1] + __expf(a.an_logs[HALF + 2 * g + 1]) * xb.y;
-      float o[4];
+      for (int k = 0; k < (BM + NPH - 1) / NPH; ++k) {
+        const int row = ph + NPH * k, gm = m0 + row;
+        if (row < BM) {
+          const float rm = Rm[row];
+          const float2 xa = *reinterpret_cast<const float2*>(Zt + row * ZP + 2 * g);
+          const float2 xb = *reinterpret_cast<const float2*>(Zt + row * ZP + HALF + 2 * g);
+          const float a0 = c0 + e0 * xa.x, a1 = c1 + e1 * xa.y, a2 = c2 + e2 * xb.x, a3 = c3 + e3 * xb.y;
+          float o[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (Wm[q * 4] * a0 + Wm[q * 4 + 1] * a1 + Wm[q * 4 + 2] * a2 + Wm[q * 4 + 3] * a3) * rm;
-      const uint32_t p01 = pack2bf(o[0], o[1]);
-      if (gm < R) {
-        *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + 2 * g) = make_float2(o[0], o[1]);
-        *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + HALF + 2 * g) = make_float2(o[2], o[3]);
-        *reinterpret_cast<uint32_t*>(y0b + (size_t)gm * HALF + 2 * g) = p01;
+          for (int q = 0; q < 4; ++q) o[q] = (Wm[q * 4] * a0 + Wm[q * 4 + 1] * a1 + Wm[q * 4 + 2] * a2 + Wm[q * 4 + 3] * a3) * rm;
+          const uint32_t p01 = pack2bf(o[0], o[1]);
+          if (gm < R) {
+            *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + 2 * g) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2*>(a.y_next + (size_t)gm * C + HALF + 2 * g) = make_float2(o[2], o[3]);
+            *reinterpret_cast<uint32_t*>(y0b + (size_t)gm * HALF + 2 * g) = p01;
+          }
+          *reinterpret_cast<uint32_t*>(X0t + row * XP + 2 * g) = p01;
+        }
       }
-      *reinterpret_cast<uint32_t*>(X0t + row * XP + 2 * g) = p01;
     }
   }
   __syncthreads();
@@ -376,7 +419,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
-        const float4 b4 = *reinterpret_cast<const float4*>(a.b_start + n);
+        const float4 b4 = *reinterpret_cast<const float4*>(Bs + 2 * H + n);
         *reinterpret_cast<uint2*>(Hst + (32 * wm + r) * AP + n) =
             pack4((acc3[bn][4 * g] + b4.x) * rm_l, (acc3[bn][4 * g + 1] + b4.y) * rm_l,
                   (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
@@ -385,10 +428,55 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     PH(10);
     coop_store_rows(h0, H, Hst, m0, R);
   }
+  if (TAIL && wave == 0) {                                   // the coupling's log-det (row sums folded in LDS above)
+    const int gm = m0 + lane < R ? m0 + lane : R - 1;
+    utt_atomic_add(a.logdet, rowsum[lane], a.rowutt[gm], lane);
+  }
+  if (blockIdx.x == 0) {                                     // ActNorm + InvConvNear's log-det: (sum logs + (C/4) logdet W) * len_b
+    const float per_frame = a.scal[0] + (float)G * a.scal[1];
+    for (int b = threadIdx.x; b < a.B; b += 256) atomicAdd(a.logdet + b, per_frame * (float)a.len[b]);
+  }
   PH(11);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// ActNorm / InvConvNear parameter gradients of one workgroup: the four row phases' sums (sL, sB [4][64][4], sW [4][16] in LDS) ->
+// one atomic per channel
+constexpr int PG = 2 * C + 16;                 // a workgroup's partial sums: d logs [C] | d bias [C] | d W [16]
+
+// The same sums as ONE ROW of partials per workgroup (plain stores; gt_boundary_param_reduce adds the rows up after the pass):
+// 152 workgroups adding to the same 336 addresses serialise at L2 — ~10 us per launch that either sit in front of every later
+// wait (issued mid-kernel) or hold the kernel open (issued at its end).  extra = this launch's log-det bookkeeping term (workgroup 0).
+__device__ __forceinline__ void param_grad_partials(const gt_boundary_bwd_args& a, const float* sL, const float* sB, const float* sW, float extra)
+{
+  float* row = a.pg_partial + (size_t)blockIdx.x * PG;
+  for (int t = threadIdx.x; t < PG; t += 256) {              // 336 values, 256 threads
+    if (t < 2 * C) {
+      const int c = t < C ? t : t - C, hi = c >= HALF, cc = c - HALF * hi, g = cc >> 1, k = 2 * hi + (cc & 1);
+      const float* sp = t < C ? sL : sB;
+      float v = sp[g * 4 + k] + sp[(64 + g) * 4 + k] + sp[(128 + g) * 4 + k] + sp[(192 + g) * 4 + k];
+      if (t < C) v += extra;
+      row[t] = v;
+    } else {
+      const int i = t - 2 * C;
+      row[t] = sW[i] + sW[16 + i] + sW[32 + i] + sW[48 + i] + (float)G * extra * a.scal[2 + i];
+    }
+  }
+}
+
+__device__ __forceinline__ void param_grad_atomics(const gt_boundary_bwd_args& a, const float* sL, const float* sB, const float* sW, int ph, int g)
+{
+  if (ph == 0 && g < G) {
+    const int ch[4] = {2 * g, 2 * g + 1, HALF + 2 * g, HALF + 2 * g + 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(a.d_an_logs + ch[k], sL[g * 4 + k] + sL[(64 + g) * 4 + k] + sL[(128 + g) * 4 + k] + sL[(192 + g) * 4 + k]);
+      atomicAdd(a.d_an_bias + ch[k], sB[g * 4 + k] + sB[(64 + g) * 4 + k] + sB[(128 + g) * 4 + k] + sB[(192 + g) * 4 + k]);
+    }
+  }
+  if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, sW[threadIdx.x] + sW[16 + threadIdx.x] + sW[32 + threadIdx.x] + sW[48 + threadIdx.x]);
+}
+
 constexpr int B_DH = 0;                                    // d h tile [64][AP] bf16; later d wn_out tile
 constexpr int B_D = BM * AP * 2;                           // fp32 gradient tile [64][ZP]
 constexpr int B_DO = B_D + BM * ZP * 4;                    // d[m | logs] tile [64][AP] bf16
@@ -440,6 +528,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     float* sB = sL + 4 * 64 * 4;
     float* sW = sB + 4 * 64 * 4;
     float* sred = sW + 4 * 16;
+    float extra = 0.f;
     if (blockIdx.x == 0) {                                   // backward of the log-det bookkeeping (see flow_ops.hip)
       float sv = 0.f;
       for (int b = threadIdx.x; b < a.B; b += 256) sv += a.dlogdet[b] * (float)a.len[b];
@@ -447,8 +536,11 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       if (lane == 0) sred[wave] = sv;
       __syncthreads();
       sv = sred[0] + sred[1] + sred[2] + sred[3];
-      for (int c = threadIdx.x; c < C; c += 256) atomicAdd(a.d_an_logs + c, sv);
-      if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, (float)G * sv * a.scal[2 + threadIdx.x]);
+      if (a.pg_partial) extra = sv;
+      else {
+        for (int c = threadIdx.x; c < C; c += 256) atomicAdd(a.d_an_logs + c, sv);
+        if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, (float)G * sv * a.scal[2 + threadIdx.x]);
+      }
     }
     const int g = lane, ph = wave;
     float accW[16], accL[4] = {0, 0, 0, 0}, accB[4] = {0, 0, 0, 0};
@@ -523,17 +615,16 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       for (int i = 0; i < 16; ++i) sW[ph * 16 + i] = accW[i];
     }
     __syncthreads();
-    if (ph == 0 && g < G) {
-      const int ch[4] = {2 * g, 2 * g + 1, HALF + 2 * g, HALF + 2 * g + 1};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        atomicAdd(a.d_an_logs + ch[k], sL[g * 4 + k] + sL[(64 + g) * 4 + k] + sL[(128 + g) * 4 + k] + sL[(192 + g) * 4 + k]);
-        atomicAdd(a.d_an_bias + ch[k], sB[g * 4 + k] + sB[(64 + g) * 4 + k] + sB[(128 + g) * 4 + k] + sB[(192 + g) * 4 + k]);
-      }
-    }
-    if (threadIdx.x < 16) atomicAdd(a.d_w_ic + threadIdx.x, sW[threadIdx.x] + sW[16 + threadIdx.x] + sW[32 + threadIdx.x] + sW[48 + threadIdx.x]);
+    // The workgroup's 336 parameter-gradient atomics (152 workgroups add to the same 336 addresses: they serialise at L2 and take
+    // microseconds to retire) are issued at the END of the kernel: vector-memory operations retire in order, so issued here every
+    // later wait for a load — the coupling's operands, the next weight fragments — waited for them too (10 k of the launch's 58 k
+    // cycles, tools/wn_boundary_phases.py).  The folded sums stay in their LDS region (nothing below reuses it).
     PH(4);
-    if (!TAILB) return;
+    if (a.pg_partial) param_grad_partials(a, sL, sB, sW, extra);     // plain stores: nothing later waits long for them
+    if (!TAILB) {
+      if (!a.pg_partial) param_grad_atomics(a, sL, sB, sW, wave, lane);
+      return;
+    }
   } else {
     // last block: the squeezed gradient of the decoder's output is d z
 #pragma unroll
@@ -634,13 +725,24 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     f32x16_t acc[3];
     acc_zero<3>(acc);
 #pragma unroll
-    for (int kk = 0; kk < KS2; ++kk) {
-      const int st = l * KS2 + kk, nx = st + RD;
-      const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + kk * 16);
+    for (int k0 = 0; k0 < KS2; k0 += 4) {
 #pragma unroll
-      for (int bn = 0; bn < 3; ++bn) {
-        acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring3[st % RD][bn]), bfm, acc[bn], 0, 0, 0);
-        if (nx < NS) ring3[st % RD][bn] = ldfrag(Wsd, (6 * (nx / KS2) + 3 * wn + bn) * a.ks_skip_d + nx % KS2, lane);
+      for (int kk = k0; kk < k0 + 4; ++kk) {
+        const int st = l * KS2 + kk;
+        const bf16x8_t bfm = *reinterpret_cast<const bf16x8_t*>(brow + kk * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn) acc[bn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring3[st % RD][bn]), bfm, acc[bn], 0, 0, 0);
+      }
+      if (l * KS2 + k0 + RD < NS) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = k0; kk < k0 + 4; ++kk) {
+          const int st = l * KS2 + kk, nx = st + RD;
+#pragma unroll
+          for (int bn = 0; bn < 3; ++bn)
+            if (nx < NS) ring3[st % RD][bn] = ldfrag(Wsd, (6 * (nx / KS2) + 3 * wn + bn) * a.ks_skip_d + nx % KS2, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // out through one of two dead tiles (the fp32 gradient tile / the d[m | logs] tile), alternating: one barrier per layer window
@@ -656,6 +758,24 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     coop_store_rows(via + l * H, a.ldvs, Vst, m0, R);
     PH(9 + l);
   }
+  if (HEADB && !a.pg_partial) {
+    const float* sL = reinterpret_cast<const float*>(smem + B_RED);
+    param_grad_atomics(a, sL, sL + 4 * 64 * 4, sL + 2 * 4 * 64 * 4, wave, lane);
+  }
+}
+
+// rows of per-workgroup partials [n_blocks][n_wg][PG] -> += into every block's d logs / d bias / d W (one writer per address)
+__global__ __launch_bounds__(384) void gt_boundary_param_reduce_kernel(const float* __restrict__ pg, int n_wg, float* const* __restrict__ dst)
+{
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t >= PG) return;
+  const float* p = pg + (size_t)b * n_wg * PG + t;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int w = 0;
+  for (; w + 4 <= n_wg; w += 4) { s0 += p[(size_t)w * PG]; s1 += p[(size_t)(w + 1) * PG]; s2 += p[(size_t)(w + 2) * PG]; s3 += p[(size_t)(w + 3) * PG]; }
+  for (; w < n_wg; ++w) s0 += p[(size_t)w * PG];
+  float* d = t < C ? dst[3 * b] + t : (t < 2 * C ? dst[3 * b + 1] + (t - C) : dst[3 * b + 2] + (t - 2 * C));
+  *d += (s0 + s1) + (s2 + s3);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -709,6 +829,16 @@ extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream
   if (tail && head) hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, true>), grid, block, FWD_LDS, st, a);
   else if (tail)    hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, false>), grid, block, FWD_LDS, st, a);
   else              hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<false, true>), grid, block, FWD_LDS, st, a);
+  return gt_launch_status(__func__);
+}
+
+extern "C" int gt_boundary_param_partials(void) { return PG; }
+
+extern "C" int gt_boundary_param_reduce(const float* partials, int n_wg, int n_blocks, float* const* dst, void* stream)
+{
+  if (!partials || !dst || n_wg <= 0 || n_blocks < 0) return GT_E_INVAL;
+  if (n_blocks == 0) return GT_OK;
+  hipLaunchKernelGGL(gt_boundary_param_reduce_kernel, dim3(n_blocks), dim3(384), 0, static_cast<hipStream_t>(stream), partials, n_wg, dst);
   return gt_launch_status(__func__);
 }
 

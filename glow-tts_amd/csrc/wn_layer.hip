@@ -66,13 +66,19 @@ struct WnArgs {
   unsigned long long* stamps; int stamp_slot; const int32_t* stamp_base;     // slot = stamp_slot + *stamp_base (a per-step device counter)
 };
 
-__device__ __forceinline__ void stamp_begin(const WnArgs& a)
+// workgroup 0's start (kept in a register, stored at the end) and an atomicMax of every workgroup's end, issued after its last wait:
+// an atomic at the kernel's start sits in front of every later wait for a load (vector-memory operations retire in order)
+__device__ __forceinline__ unsigned long long stamp_begin(const WnArgs& a)
 {
-  if (a.stamps && threadIdx.x == 0) atomicMin(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)), (unsigned long long)wall_clock64());
+  return (a.stamps && threadIdx.x == 0 && blockIdx.x == 0) ? (unsigned long long)wall_clock64() : 0ull;
 }
-__device__ __forceinline__ void stamp_end(const WnArgs& a)
+__device__ __forceinline__ void stamp_end(const WnArgs& a, unsigned long long t_begin)
 {
-  if (a.stamps && threadIdx.x == 0) atomicMax(a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0)) + 1, (unsigned long long)wall_clock64());
+  if (a.stamps && threadIdx.x == 0) {
+    unsigned long long* slot = a.stamps + 2 * (a.stamp_slot + (a.stamp_base ? *a.stamp_base : 0));
+    if (blockIdx.x == 0) slot[0] = t_begin;
+    atomicMax(slot + 1, (unsigned long long)wall_clock64());
+  }
 }
 
 __device__ __forceinline__ uint4 ldfrag(const bf16_t* __restrict__ W, int f, int lane)
@@ -145,7 +151,7 @@ template <bool RES>
 __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
 {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FWD_LDS];
-  stamp_begin(a);
+  const unsigned long long t_begin_ = stamp_begin(a);
   if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
       }
     }
   }
-  if (!RES) { stamp_end(a); return; }
+  if (!RES) { stamp_end(a, t_begin_); return; }
 
   f32x16_t acc2[3];
   s2_gemm(a.W2, At, wn2, wm2, lane, ring2, acc2);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void gt_wn_layer_fwd_kernel(WnArgs a)
         }
     }
   }
-  stamp_end(a);
+  stamp_end(a, t_begin_);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -309,7 +315,7 @@ template <bool S2>
 __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  stamp_begin(a);
+  const unsigned long long t_begin_ = stamp_begin(a);
   if (a.seed_dev) a.drop_seed ^= *a.seed_dev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
         if (S2) *reinterpret_cast<uint2*>(At + row * AP + n) = v;
       }
   }
-  if (!S2) { stamp_end(a); return; }                                 // bottom layer: only the data gradient (no gate below it)
+  if (!S2) { stamp_end(a, t_begin_); return; }                                 // bottom layer: only the data gradient (no gate below it)
   __syncthreads();
 
   f32x16_t acc2[3];
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(256) void gt_wn_layer_bwd_kernel(WnArgs a)
         *reinterpret_cast<uint2*>(yp + H) = pack4(gs[0], gs[1], gs[2], gs[3]);
       }
   }
-  stamp_end(a);
+  stamp_end(a, t_begin_);
 }
 
 int fill_drop(WnArgs& a, float drop_p, uint32_t seed, const uint32_t* seed_dev)

@@ -192,7 +192,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
             B=0 if (cond_per_row or cond is None) else rc.B, Tp=rc.Tp, rowmask=rc.rowmask, acts=acts_all, ldacts=acts_all.stride(0),
             gate_t=ts + pad, gate_s=ss + pad, x_out=xs[1:] + [None] + pad, R=R, H=H, taps=wn.kernel_size, n_layers=n,
             drop_p=float(p), drop_seed=int(seed), seed_dev=seed_word(dev) if p > 0 else None,
-            stamps=stamps.buf if stamps else None, stamp_slot=stamps.take() if stamps else 0, stamp_base=stamps.base if stamps else None)
+            stamps=stamps.buf if stamps else None, stamp_slot=stamps.take(f"stack{n}") if stamps else 0, stamp_base=stamps.base if stamps else None)
         _ev = KERNEL_TIMER.start("wn_stack_fwd")
         rcode = L.gt_wn_stack_fwd(ctypes.byref(args), _st(dev))
         KERNEL_TIMER.stop(_ev)
@@ -220,7 +220,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
                                       None if last else _lib.ptr(rs.pc_res.fwd),
                                       None if last else rs.bias.data_ptr(), _lib.ptr(xn), H,
                                       R, H, wn.kernel_size, float(p), int(seed + i), _lib.ptr(seed_word(dev)) if p > 0 else None,
-                                      _lib.ptr(stamps.buf) if stamps else None, stamps.take() if stamps else 0,
+                                      _lib.ptr(stamps.buf) if stamps else None, stamps.take("layer_last" if last else "layer") if stamps else 0,
                                       _lib.ptr(stamps.base) if stamps else None, _st(dev))
             KERNEL_TIMER.stop(_ev)
             _lib.check(rcode, "gt_wn_layer_fwd")
@@ -505,6 +505,18 @@ def _ptr_table(dec):
     return tab[1], tab[2]
 
 
+def _grad_ptr_table(dec, tensors):
+    """device array of the gradient accumulators' addresses (gt_boundary_param_reduce).  Under train.Trainer these are slices of the
+    flat gradient buffer: the table is built once, outside graph capture (the eager warm-up steps), and reused while they stay put."""
+    key = tuple(t.data_ptr() for t in tensors)
+    tab = getattr(dec, "_pg_table", None)
+    if tab is None or tab[0] != key:
+        assert not torch.cuda.is_current_stream_capturing(), "gradient pointer table is built outside graph capture"
+        tab = (key, torch.tensor(key, dtype=torch.int64).to(tensors[0].device))
+        object.__setattr__(dec, "_pg_table", tab)
+    return tab[1]
+
+
 def flow_scalars_all(dec):
     """scal [n_blocks, 18] = {sum logs, logdet W, W^-T} of every block in ONE launch, and the blocks' (contiguous) 4x4
     weights.  A weight that is a strided view (a hand-filled test module; trained parameters are slices of the flat
@@ -594,6 +606,11 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
     f32 = dict(dtype=torch.float32, device=dev)
     bf = dict(dtype=torch.bfloat16, device=dev)
     grads, dconds = {}, [None] * nb
+    # ActNorm / InvConvNear parameter gradients: one row of partial sums per workgroup and launch, added up by ONE launch after the
+    # pass (gt_boundary_param_reduce) — as atomics, 152 workgroups on the same 336 addresses cost ~10 us of every 33 us launch
+    n_wg, PG = (R + 63) // 64, L.gt_boundary_param_partials()
+    pg = torch.empty(nb, n_wg * PG, **f32)
+    pg_dst = []
     dx_prev = None                                         # [d z0 | d y1] of the block whose WaveNet backward runs next
     dh0 = None
     tail = None                                            # (dout, dwn_out, via_skip) of that block
@@ -607,7 +624,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
             dW = grad_accumulator(ic.weight, (16,))
             kw.update(dh=dh0, w_start_d=cb.start.pc_frag.dgrad, ks_start_d=cb.start.pc_frag.Kp_d // 16, dx_in=dx_prev, x=sv.x_in,
                       an_logs=an.logs, an_bias=an.bias, w_ic=sv.w_ic, scal=sv.scal, len=rc.lengths, B=rc.B,
-                      d_an_logs=dlogs, d_an_bias=dbias, d_w_ic=dW, dlogdet=dlogdet)
+                      d_an_logs=dlogs, d_an_bias=dbias, d_w_ic=dW, dlogdet=dlogdet, pg_partial=pg[b])
+            pg_dst.append((b, dlogs, dbias, dW))
             grads.update({an.logs: dlogs.view_as(an.logs), an.bias: dbias.view_as(an.bias), ic.weight: dW.view_as(ic.weight)})
         elif dz_bct is not None:
             kw.update(dz_bct=dz_bct, T=dz_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe, len=rc.lengths)
@@ -635,6 +653,9 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
         KERNEL_TIMER.stop(_ev)
         _lib.check(rcode, "gt_wn_boundary_bwd")
         if b == 0:
+            pg_dst.sort(key=lambda t: t[0])
+            tab = _grad_ptr_table(dec, [t for _, *ts in pg_dst for t in ts])
+            _lib.check(L.gt_boundary_param_reduce(_lib.ptr(pg), n_wg, nb, _lib.ptr(tab), _st(dev)), "gt_boundary_param_reduce")
             return dx_out, grads, dconds
         # block b-1: end conv's parameter gradients, the WaveNet's backward, then the start conv's
         cbp, svp = dec.flows[3 * (b - 1) + 2], blocks[b - 1]

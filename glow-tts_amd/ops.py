@@ -60,23 +60,31 @@ class KernelStamps:
         self.per_step, self.max_steps = per_step, max_steps
         n = per_step * max_steps
         init = torch.empty(2 * n, dtype=torch.int64)
-        init[0::2] = -1                                  # ~0 as uint64: atomicMin target
-        init[1::2] = 0
+        init[0::2] = 0                                   # start: workgroup 0's clock (plain store)
+        init[1::2] = 0                                   # end: atomicMax over the workgroups
         self.buf = init.to(device)
         self.base = torch.zeros(1, dtype=torch.int32, device=device)
         self._next = 0
+        self.kinds = {}                                  # slot within a step -> {kernel kinds that ever stamped it}
+        self.steps_done = 0                              # host-side count of end_step() calls (captured steps count once per capture)
 
     def begin_step(self):
         """inside the step (captured with it): the slots of this execution start at the counter's current value"""
         self._next = 0
 
     def end_step(self):
-        self.base.add_(self.per_step)
+        # the slot counter wraps inside the buffer: the kernels index stamps[2 * (slot + base)] unchecked (a run longer than
+        # max_steps then overwrites its oldest slots instead of writing past the allocation)
+        self.base.add_(self.per_step).remainder_(self.per_step * self.max_steps)
+        self.steps_done += 1
 
-    def take(self):
+    def take(self, kind=""):
+        """the next slot of the step; `kind` names the kernel that will stamp it (bench.py reads `kinds` to tell the WaveNet stack
+        launches from the per-layer ones a long batch falls back to)"""
         k = self._next
         self._next += 1
         assert k < self.per_step
+        self.kinds.setdefault(k, set()).add(kind)
         return k
 
     def durations_ticks(self):

@@ -598,6 +598,26 @@ class FlowGenerator(nn.Module):
         n = torch.log(torch.clamp(c, min=torch.finfo(c.dtype).tiny))
         return n.masked_fill(zero, 0.0).unsqueeze(1)
 
+    @torch.no_grad()
+    def voice_conversion(self, y, y_lengths, spk_embed_src, spk_embed_tgt, l=None):
+        """models.py:1233-1247: mel of the source speaker -> latent z through the decoder conditioned on the source speaker's vector
+        -> mel through the REVERSE decoder conditioned on the target's.  As in the reference, emb_g is applied to the raw embeddings
+        (no F.normalize here, unlike forward) and an optional language id is embedded, normalised and concatenated to both vectors
+        (which only a decoder built with gin_channels + lin_channels conditioning inputs accepts)."""
+        if not hasattr(self, "emb_g"):
+            raise ValueError("voice_conversion needs a model built with use_spk_embeds (emb_g, models.py:1234-1235)")
+        if self.decoder._inv_cache is None:
+            self.prepare()
+        g_src = self.emb_g(spk_embed_src).unsqueeze(-1)
+        g_tgt = self.emb_g(spk_embed_tgt).unsqueeze(-1)
+        if l is not None:
+            lv = torch.nn.functional.normalize(self.emb_l(l)).unsqueeze(-1)
+            g_src, g_tgt = torch.cat([g_src, lv], 1), torch.cat([g_tgt, lv], 1)
+        z_mask = ops.length_mask(y_lengths, y.shape[2]).to(y.dtype)
+        z, _ = self.decoder(y, z_mask, g=g_src, reverse=False, prepared=True)
+        y_conv, _ = self.decoder(z, z_mask, g=g_tgt, reverse=True, prepared=True)
+        return y_conv
+
     def preprocess(self, y, y_lengths, y_max_length):
         """reference models.py:1248-1253"""
         if y_max_length is not None:

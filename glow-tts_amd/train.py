@@ -77,7 +77,7 @@ class GradBuckets:
     `gather()` (one multi-tensor copy); the optimizer and the collectives only ever see the flat buffer."""
     ALIGN = 64          # floats: every parameter starts on a 256-byte boundary
 
-    def __init__(self, params, world, bucket_mb=64, accum=(), wire="fp32"):
+    def __init__(self, params, world, bucket_mb=64, accum=(), wire="fp32", force_collectives=False):
         """wire: "fp32" — all-reduce (mean) of the fp32 buffer, what the reference's DDP does; "bf16" — half the bytes on
         xGMI with fp32 accumulation: every rank sends bf16 copies of the other ranks' shards (all-to-all), sums the copies of
         its own shard in fp32, and the reduced shards travel back as bf16 (all-gather); all ranks end up with bit-identical
@@ -87,6 +87,9 @@ class GradBuckets:
         with one fill per step, so that their backward kernels add straight into the flat buffer
         (ops.grad_accumulator) — every other gradient is overwritten whole by the batched wgrad kernels."""
         self.world = world
+        # force_collectives: issue the step's collectives even with one rank (a world-1 process group) — how the RCCL path (ReduceOp.AVG,
+        # all-to-all / all-gather of the bf16 wire, the communication stream's hand-offs) is exercised on a one-GPU box
+        self.collect = world > 1 or bool(force_collectives)
         assert wire in ("fp32", "bf16")
         self.wire, self._wire_bufs = wire, {}
         ids = {id(p) for p in accum}
@@ -109,7 +112,7 @@ class GradBuckets:
             p._gt_prezeroed = i < self.n_accum
         self.accum_end = self.offsets[self.n_accum] if self.n_accum < len(self.params) else self.total
         self.on_gpu = dev.type == "cuda"
-        self.comm = torch.cuda.Stream(device=dev) if (world > 1 and self.on_gpu) else None
+        self.comm = torch.cuda.Stream(device=dev) if (self.collect and self.on_gpu) else None
         self.active = [True] * len(self.params)
 
     def zero_accum(self):
@@ -168,7 +171,7 @@ class GradBuckets:
         stream, after everything queued so far on the current stream; wait=False leaves the current stream free to run
         ahead (the caller overlaps the backward of the remaining parameters) until `wait_comm()`."""
         hi = self.total if hi is None else hi
-        if self.world == 1 or hi <= lo:
+        if not self.collect or hi <= lo:
             return
         pieces = [(max(s, lo), min(e, hi)) for s, e in self.buckets if min(e, hi) > max(s, lo)]
         if self.wire == "bf16":
@@ -317,7 +320,8 @@ class Trainer:
     WARMUPS = 2
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
-                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32"):
+                 split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32",
+                 force_collectives=False):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
         encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
@@ -339,7 +343,8 @@ class Trainer:
         # of the model's sub-modules; checkpoint.py maps the flat layout back to model.parameters() order by identity)
         named = list(model.named_parameters())
         plist = [p for n, p in named if not n.startswith("decoder.")] + [p for n, p in named if n.startswith("decoder.")]
-        self.buckets = GradBuckets(plist, world, accum=accum, wire=grad_wire)      # grad_wire="bf16": GradBuckets.__init__
+        self.buckets = GradBuckets(plist, world, accum=accum, wire=grad_wire,      # grad_wire="bf16": GradBuckets.__init__
+                                   force_collectives=force_collectives)
         # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
         # first backward call and travel over xGMI while the text encoder's backward runs
         name_of = {id(p): n for n, p in model.named_parameters()}
@@ -516,7 +521,7 @@ class Trainer:
         from . import wgrad
         tables = wgrad.table_arena_begin(ids.device) # the captured weight-gradient kernels' job tables: outside the graph's pool
         g1 = torch.cuda.CUDAGraph()
-        if not self.split and self.world == 1:
+        if not self.split and not self.buckets.collect:
             with torch.cuda.graph(g1, stream=side, capture_error_mode=CAPTURE_MODE):
                 out = self._step_impl(*static, lengths_host=lh, cond=cond, collectives=False)
             graphs = (g1,)

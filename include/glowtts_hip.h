@@ -478,9 +478,18 @@ typedef struct gt_boundary_bwd_args {
   /* optional, as in the forward: dz_bct (tail-only variant, instead of dz_in) and dx_bct (head-only variant, instead of dx_out;
    * pre-zeroed) are [B, C/2, T] fp32 */
   const float* dz_bct; float* dx_bct; int T; const int64_t* rowbatch; const int32_t* rowframe;
+  /* optional (head): one row of gt_boundary_param_partials() floats per workgroup of the launch (ceil(R / 64) rows) — the
+   * workgroup's sums for d_an_logs | d_an_bias | d_w_ic are STORED there instead of added to the three accumulators with atomics
+   * (152 workgroups on the same 336 addresses serialise at L2: ~10 us of a 33 us launch); gt_boundary_param_reduce adds the rows up */
+  float* pg_partial;
 } gt_boundary_bwd_args;
 int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream);
 int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream);
+/* floats per workgroup row of pg_partial, and the reduction over rows for n_blocks launches at once: partials
+ * [n_blocks][n_wg][gt_boundary_param_partials()], dst = DEVICE array of 3 * n_blocks pointers {d_an_logs, d_an_bias, d_w_ic} per block;
+ * every destination element gets += the sum over the block's n_wg rows (modules.py:584-599, 635-665 parameter gradients) */
+int gt_boundary_param_partials(void);
+int gt_boundary_param_reduce(const float* partials, int n_wg, int n_blocks, float* const* dst, void* stream);
 
 /* ---- One WaveNet layer as ONE kernel (modules.WN.forward, one loop iteration, modules.py:151-170; csrc/wn_layer.hip).
  * H = 192 hidden channels, k = 5, dilation 1; a workgroup owns 64 rows and all channels, so the 1x1 residual conv runs on the

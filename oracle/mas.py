@@ -36,6 +36,8 @@ def _lib():
         lib.mas_oracle_range.argtypes = [i32p, f32p, i32p, i32p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int]
         lib.mas_oracle_range.restype = None
+        lib.mas_oracle_batch_omp.argtypes = [i32p, f32p, i32p, i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.mas_oracle_batch_omp.restype = ctypes.c_int
         _LIB = lib
     return _LIB
 
@@ -53,6 +55,15 @@ def oracle_maximum_path_c(paths, values, t_xs, t_ys):
     b, T_x, T_y = values.shape
     _lib().mas_oracle_batch(_ptr(paths, ctypes.c_int32), _ptr(values, ctypes.c_float),
                             _ptr(t_xs, ctypes.c_int32), _ptr(t_ys, ctypes.c_int32), b, T_x, T_y)
+
+
+def oracle_maximum_path_omp(paths, values, t_xs, t_ys, n_threads=0):
+    """oracle_maximum_path_c with one utterance per OpenMP thread (n_threads = 0: all cores); returns the threads used."""
+    assert paths.dtype == np.int32 and values.dtype == np.float32 and t_xs.dtype == np.int32 and t_ys.dtype == np.int32
+    assert paths.flags.c_contiguous and values.flags.c_contiguous
+    b, T_x, T_y = values.shape
+    return _lib().mas_oracle_batch_omp(_ptr(paths, ctypes.c_int32), _ptr(values, ctypes.c_float), _ptr(t_xs, ctypes.c_int32),
+                                       _ptr(t_ys, ctypes.c_int32), b, T_x, T_y, int(n_threads))
 
 
 def oracle_maximum_path_range(paths, values, t_xs, t_ys, i0, i1):

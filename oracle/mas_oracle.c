@@ -70,8 +70,27 @@ void mas_oracle_batch(int32_t *paths, float *values, const int32_t *t_xs,
                         t_xs[i], t_ys[i], (int64_t)T_y, -1e9f);
 }
 
-/* Same as mas_oracle_batch but one utterance per thread-chunk [i0, i1): used by the
- * "all cores" CPU baseline variant in bench.py (the caller spawns the threads). */
+/* The batch loop with one utterance per OpenMP thread: what the reference's `prange` would be had monotonic_align/setup.py
+ * passed -fopenmp (it does not: core.pyx:38-45 runs serially).  bench.py's "all cores" CPU baseline; returns the threads used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int mas_oracle_batch_omp(int32_t *paths, float *values, const int32_t *t_xs,
+                         const int32_t *t_ys, int b, int T_x, int T_y, int n_threads)
+{
+    int i, used = 1;
+#ifdef _OPENMP
+    used = n_threads > 0 ? n_threads : omp_get_max_threads();     /* (num_threads clause only: the process-wide setting stays as it is) */
+    if (used > b) used = b;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(used)
+#endif
+    for (i = 0; i < b; ++i)
+        mas_oracle_each(paths + (int64_t)i * T_x * T_y, values + (int64_t)i * T_x * T_y,
+                        t_xs[i], t_ys[i], (int64_t)T_y, -1e9f);
+    return used;
+}
+
+/* Same as mas_oracle_batch for the utterances [i0, i1) (a caller that brings its own threads). */
 void mas_oracle_range(int32_t *paths, float *values, const int32_t *t_xs,
                       const int32_t *t_ys, int i0, int i1, int T_x, int T_y)
 {

@@ -341,3 +341,30 @@ def test_cfg5_infer_runs_the_predictors_in_reverse(built):
     assert ld is None and mel.shape[:2] == (2, 80) and pit.shape == (2, Ty) and ene.shape == (2, Ty)
     assert torch.isfinite(mel).all() and torch.isfinite(pit).all() and torch.isfinite(ene).all() and torch.isfinite(logw).all()
     assert torch.equal(attn.squeeze(1).sum(1), z_mask.squeeze(1))            # every valid frame belongs to exactly one token
+
+
+def test_voice_conversion_round_trip(built):
+    """FlowGenerator.voice_conversion (models.py:1233-1247): decoder forward under the source speaker's vector, reverse under the
+    target's.  Same speaker on both sides => the mel comes back (5e-3 of max|y|); another target => another mel.  The reference feeds
+    emb_g's output straight to the decoder (no emotion half), so the method only fits a model whose emb_g is gin_channels wide — the
+    fork's cfg 5 (emb_g: 512 -> gin / 2) raises a shape error there, and so does this class; the test widens emb_g by hand."""
+    from glow_tts_amd import models
+    cfg = dict(CFG5, n_blocks_dec=3, n_layers_enc=1, gin_channels=64, use_emo_embeds=False, use_spp=False, use_sep=False, use_sdp=False)
+    gen = models.FlowGenerator(n_vocab=187, out_channels=80, n_lang=10, **cfg)
+    gen.emb_g = torch.nn.Linear(512, 64)
+    gen = fill_module(gen, "").eval().to(dev())
+    for b in range(3):                                                    # a coupling that does something (end is zero-initialised)
+        torch.nn.init.normal_(gen.decoder.flows[3 * b + 2].end.weight, std=0.02)
+    gen.store_inverse()
+    g = torch.Generator().manual_seed(11)
+    yl = torch.tensor([40, 32])
+    y = (torch.randn(2, 80, 40, generator=g) * lens_mask(yl.tolist(), 40)).to(dev())
+    e_src, e_tgt = torch.randn(2, 512, generator=g).to(dev()), torch.randn(2, 512, generator=g).to(dev())
+    same = gen.voice_conversion(y, yl.to(dev()), e_src, e_src)
+    assert same.shape == y.shape and (same - y).abs().max().item() < 5e-3 * y.abs().max().item()
+    other = gen.voice_conversion(y, yl.to(dev()), e_src, e_tgt)
+    assert torch.isfinite(other).all() and (other - y).abs().max().item() > 1e-2
+    assert other[1, :, 32:].abs().max().item() == 0.0                     # padded frames stay zero
+    with pytest.raises(Exception):                                        # the fork's own cfg 5 shape: emb_g is gin / 2 wide
+        bad = fill_module(models.FlowGenerator(n_vocab=187, out_channels=80, n_lang=10, **dict(cfg, gin_channels=64)), "").eval().to(dev())
+        bad.voice_conversion(y, yl.to(dev()), e_src, e_tgt)

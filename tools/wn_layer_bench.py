@@ -103,6 +103,13 @@ timeit("WN forward, 4 layers: ONE stack launch", lambda k: stack(wns[k % 12]), l
 if not STACK_ONLY:
     timeit("WN forward, 4 layers: four layer launches", lambda k: layers(wns[k % 12]), launches=24)
 if len(sys.argv) > 1 and sys.argv[1] == 'stack':          # the stack kernels only (tools/stack_variants.sh)
+    if os.environ.get("WN_BENCH_COLD"):
+        # the same launches behind a 640 MB fill each (evicts L2 and the 256 MB Infinity Cache): in the training step a WaveNet's weights
+        # and saved-activation lines are cold; subtract the fill's own time
+        big = torch.empty(160 * 1024 * 1024, dtype=torch.float32, device=dev)
+        timeit("640 MB fill alone", lambda k: big.fill_(float(k)), launches=24)
+        timeit("fill + WN forward (stack)", lambda k: (big.fill_(float(k)), stack(wns[k % 12])), launches=24)
+        timeit("fill + WN backward (stack)", lambda k: (big.fill_(float(k)), bwd_wn(wns[k % 12], True)), launches=24)
     sys.exit(0)
 QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 for frac in ((1,) if QUICK else (1, 2, 4, 8)):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
