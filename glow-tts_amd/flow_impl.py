@@ -12,18 +12,20 @@ from . import _lib
 from .ops import KERNEL_TIMER, RowsCtx, conv_rows, grad_accumulator, seed_word, zeros_small  # noqa: F401
 
 _SCRATCH = {}
-_SCRATCH_RETIRED = []
+_SCRATCH_KEEP = []
 
 
 def _scratch(name, nbytes, device):
-    """Grow-only device scratch (wgrad partial slabs etc.), one per purpose and device."""
+    """Grow-only device scratch (wgrad partial slabs etc.), one per purpose and device.  A captured graph replays into the buffer it
+    was captured with: the capture holds a reference to it (wgrad.capture_keep), so an outgrown buffer lives as long as those graphs."""
+    from . import wgrad
     key = (name, str(device))
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _SCRATCH_RETIRED.append(buf)       # a captured graph may still replay into it (see wgrad._scratch)
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _SCRATCH[key] = buf
+    if buf.is_cuda and torch.cuda.is_current_stream_capturing() and not wgrad.capture_keep(buf):
+        _SCRATCH_KEEP.append(buf)              # a capture nobody owns: for the life of the process
     return buf
 
 
@@ -141,15 +143,13 @@ def _fused_ok(wn):
     return True
 
 
-_CUS = {}
+_CUS = {}                    # device -> compute units (a property of the hardware, read once)
 
 
 def _stack_pays(R, n, dev):
     """One launch per WaveNet (csrc/wn_stack.hip) owns 64 - 4 (n - 1) rows per workgroup where the per-layer kernels own 64: more
     workgroups for the same rows.  That is free while they fit the CUs at once (cfg 2: 188 instead of 152 of 256) and loses when it
     costs an extra round of workgroups (cfg 3's longest batches: 268 instead of 218)."""
-    if not WN_STACK:
-        return False
     key = str(dev)
     if key not in _CUS:
         _CUS[key] = torch.cuda.get_device_properties(dev).multi_processor_count
@@ -177,7 +177,7 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
     x = h0
     fused = _fused_ok(wn)
     stamps = getattr(rc, "stamps", None)              # bench.py: live in-graph timing of the dominant kernel (ops.KernelStamps)
-    if fused and n <= 4 and _stack_pays(R, n, dev):
+    if fused and getattr(wn, "stack_fwd", True) and n <= 4 and _stack_pays(R, n, dev):
         # all layers in ONE launch (csrc/wn_stack.hip: the 2-row halo between layers is recomputed, not exchanged)
         import ctypes
         ts = [torch.empty(R, H, dtype=torch.bfloat16, device=dev) for _ in range(n)]
@@ -277,7 +277,7 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     if dacts_skip is None:
         dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
-    if WN_STACK_BWD and n <= 4 and _stack_pays(R, n, dev):
+    if getattr(wn, "stack_bwd", True) and n <= 4 and _stack_pays(R, n, dev):
         # the whole data-gradient chain in ONE launch (csrc/wn_stack.hip), then the weight-gradient jobs on what it wrote
         import ctypes
         bf = dict(dtype=torch.bfloat16, device=dev)
@@ -478,9 +478,7 @@ def coupling_bwd(rc, cb, saved, dz, dlogdet, want_dcond=False, econd=False, pcon
 
 
 # ----------------------------------------------------------------------------- fused between-WaveNets kernels
-import os as _os
-WN_STACK_BWD = _os.environ.get('GT_WN_STACK_BWD', '1') != '0'   # dev
-WN_STACK = _os.environ.get('GT_WN_STACK', '1') != '0'              # all layers of a WaveNet forward in one launch (False: one launch per layer, the path it is tested against)
+# (whether a WaveNet runs as ONE launch per direction or one per layer is a property of the module: modules.WN.set_stack)
 BOUNDARY_TRACE = None        # dev (tools/wn_boundary_bench.py): a list collects the (entry name, args struct, keep-alive) of every launch
 
 

@@ -366,6 +366,12 @@ class WN(nn.Module):
         for rs in self.res_skip_layers:
             rs.frag, rs._pc, rs.pc_res = on, None, None
 
+    def set_stack(self, fwd=True, bwd=True):
+        """One launch per WaveNet and direction (csrc/wn_stack.hip) where that pays, or one launch per layer (csrc/wn_layer.hip: the
+        path the stack kernels are tested against, and what long batches fall back to) — a property of THIS module (round 2 kept it
+        in module-level switches that tests assigned)."""
+        self.stack_fwd, self.stack_bwd = bool(fwd), bool(bwd)
+
     def set_boundary_frag(self, on):
         """Also keep the skip-cat GEMM's images in MFMA-fragment order (the fused between-WaveNets kernels)."""
         H = self.hidden_channels

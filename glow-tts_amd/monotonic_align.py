@@ -80,6 +80,23 @@ def maximum_path_lengths(value, t_x, t_y, mask=None, out_dtype=None, want_durati
     return MASResult(path, dur, f2t, status, starts)
 
 
+def result_from_path(path, t_x, t_y):
+    """A MASResult for a GIVEN monotonic path [b, t_x_max, t_y_max] (entries {0, 1}, one 1 per valid frame): durations, the
+    frame -> token map (-1 on padded frames) and the per-row start columns, as gt_mas_f32 lays them out.  Test hook
+    (FlowGenerator.forward(path=...)): the reference's own alignment instead of the one searched on this model's lattice."""
+    B, T_x, T_y = path.shape
+    p = path.detach().to(torch.float32)
+    dur = p.sum(2)
+    yy = torch.arange(T_y, device=p.device)[None, :]
+    f2t = p.argmax(1).to(torch.int32)
+    f2t = torch.where(yy < t_y.to(p.device)[:, None], f2t, torch.full_like(f2t, -1))
+    starts = torch.zeros(B, T_x + 1, dtype=torch.int32, device=p.device)
+    starts[:, 1:] = torch.cumsum(dur, 1).to(torch.int32)
+    xx = torch.arange(T_x + 1, device=p.device)[None, :]
+    starts = torch.where(xx >= t_x.to(p.device)[:, None], t_y.to(p.device, torch.int32)[:, None].expand_as(starts), starts)
+    return MASResult(path, dur, f2t.contiguous(), None, starts.contiguous())
+
+
 def lengths_from_mask(mask):
     """t_x, t_y as reference monotonic_align/__init__.py:18-19 derives them, on the device."""
     _lib.require_cuda(mask)

@@ -226,6 +226,12 @@ class RowsConfig:
         self.host_lengths = {}      # "x" / "y" -> list of ints for the batch in flight (set by FlowGenerator.forward)
         self.prebuilt = {}          # "x" / "y" -> ragged RowsCtx the next forward must use (train.Trainer, around capture / replay)
         self.stamps = None          # KernelStamps for the decoder's fused WaveNet kernels (bench.py), attached to the "y" context
+        # how the step is laid out over streams (defaults from the process environment, read when the model is built; the owner of
+        # the model — a Trainer, a test — changes THIS object, not a module global):
+        import os
+        self.encoder_stream = os.environ.get("GT_ENC_STREAM", "1") != "0"      # text encoder + duration predictor as a parallel branch
+        self.predictor_branch = os.environ.get("GT_PRED_BRANCH", "1") != "0"   # cfg 5: stochastic predictors on the encoder's stream
+        self.energy_on_main = os.environ.get("GT_ENERGY_MAIN", "1") != "0"     # ... except the energy predictor (main stream)
 
 
 DEFAULT_ROWS = RowsConfig()

@@ -373,10 +373,9 @@ def mle_loss(z, m, logs, logdet, mask):
     return _MleLossFn.apply(z, m, logs, logdet, mask)
 
 
-ENCODER_STREAM = os.environ.get("GT_ENC_STREAM", "1") != "0"
-PREDICTOR_BRANCH = os.environ.get("GT_PRED_BRANCH", "1") != "0"     # stochastic predictors on the encoder's stream (cfg 5)
-ENERGY_ON_MAIN = os.environ.get("GT_ENERGY_MAIN", "1") != "0"       # ... except the energy predictor: on the main stream (dev switch)
-_ENC_STREAMS = {}
+# (whether the encoder / the predictors run as parallel branches is per-model state: ops.RowsConfig.encoder_stream / .predictor_branch /
+# .energy_on_main of model.rows_cfg)
+_ENC_STREAMS = {}            # device -> the branch's stream (one per device and process: streams are a device resource, not model state)
 
 
 def _encoder_stream(dev):
@@ -627,7 +626,7 @@ class FlowGenerator(nn.Module):
         return y, y_lengths, y_max_length
 
     def forward(self, x, x_lengths, y=None, y_lengths=None, g=None, emo=None, emo_cartesian=None, pitch=None, energy=None, l=None,
-                lengths_host=None, defer_encoder_backward=False, noise=None):
+                lengths_host=None, defer_encoder_backward=False, noise=None, path=None):
         """models.py:1007-1133.  Beyond the reference's arguments:
         lengths_host = (x_lengths, y_lengths) as Python ints: lets the ragged rows layout (self.rows_cfg.ragged) size its
         buffers without a device sync (the data loader has them); without it they are read back from the device.
@@ -659,7 +658,7 @@ class FlowGenerator(nn.Module):
         # lattice, and so are their backward passes: the encoder runs on its own stream (a parallel branch of the step's HIP
         # graph) — autograd replays each node's backward on the stream of its forward, so the encoder's backward overlaps
         # the decoder's too.  Both are chains of latency-bound kernels on a fraction of the CUs.
-        fork = ENCODER_STREAM and x.is_cuda
+        fork = self.rows_cfg.encoder_stream and x.is_cuda
         logw = None
         if fork:
             main = torch.cuda.current_stream(x.device)
@@ -694,13 +693,17 @@ class FlowGenerator(nn.Module):
                 t_.record_stream(main)
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
+            self._last_mas_path = mas.path                                    # (the searched alignment, whatever `path` says)
+            if path is not None:                                              # test hook: a given alignment [b, t_x, t_y] instead
+                mas = monotonic_align.result_from_path(path.reshape(mas.path.shape).to(mas.path.dtype), x_lengths.to(torch.int32),
+                                                       y_lengths.to(torch.int32))
             attn = mas.path.unsqueeze(1)
         ops.mark("mas done")
         w = mas.durations.unsqueeze(1)                                        # attn.sum(3): models.py:1085
         rcx, xb = self.encoder._last_rows
         # The stochastic predictors need the alignment, but nothing after them does except the loss: they go onto the
         # encoder's stream, so that autograd replays their (long, row-wise) backward there too, beside the decoder's.
-        pfork = fork and PREDICTOR_BRANCH and (self.use_sdp or self.use_spp or self.use_sep)
+        pfork = fork and self.rows_cfg.predictor_branch and (self.use_sdp or self.use_spp or self.use_sep)
         if pfork:
             enc_stream.wait_stream(main)
             for t_ in (w, mas.frame2token, mas.durations, pitch_norm, energy_norm, z_mask, x_mask, y_lengths):
@@ -709,7 +712,7 @@ class FlowGenerator(nn.Module):
         with (torch.cuda.stream(enc_stream) if pfork else contextlib.nullcontext()):
             l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths,
                                                                        y_max_length, pitch_norm, energy_norm,
-                                                                       energy_stream=main if (pfork and ENERGY_ON_MAIN) else None)
+                                                                       energy_stream=main if (pfork and self.rows_cfg.energy_on_main) else None)
         if pfork:
             main.wait_stream(enc_stream)
             for t_ in (l_length, l_pitch, l_energy):

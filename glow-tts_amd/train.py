@@ -292,6 +292,57 @@ def _copy_padded(dst, src):
     dst[..., T:].zero_()
 
 
+def graph_key(lh, ids_shape, y_shape, cond_names=(), ragged=True, row_round=512, pad_tx=16, pad_ty=32, ty_boundaries=None):
+    """-> (key, padded T_x, padded T_y) of a batch: which captured graph can run it.  Padded T_x is the next multiple of pad_tx; padded
+    T_y the next multiple of pad_ty, or — with ty_boundaries, the length boundaries of the bucketed sampler that builds the batches
+    (data.DistributedBucketSampler) — the smallest boundary that holds the batch; the ragged row counts (text rows, squeezed mel
+    rows, frame rows) are rounded up to row_round.  Coarser paddings mean fewer keys: SAMPLER_CAPTURE_CONFIG below."""
+    from . import ops
+    Tx = -(-int(ids_shape[-1]) // pad_tx) * pad_tx
+    Ty = -(-int(y_shape[-1]) // pad_ty) * pad_ty
+    if ty_boundaries:
+        import bisect
+        bs = sorted(-(-int(b) // 2) * 2 for b in ty_boundaries)
+        i = bisect.bisect_left(bs, int(y_shape[-1]))
+        if i < len(bs):
+            Ty = -(-bs[i] // pad_ty) * pad_ty
+    rows = (0, 0)
+    if ragged:
+        _, rx = ops.RowsCtx.row_starts(lh[0], Tx, row_round)
+        _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], Ty // 2, row_round)
+        _, rf = ops.RowsCtx.row_starts([int(v) // 2 * 2 for v in lh[1]], Ty // 2 * 2, row_round)
+        rows = (rx, ry, rf)
+    return rows + (tuple(ids_shape[:-1]) + (Tx,), tuple(y_shape[:-1]) + (Ty,), tuple(sorted(cond_names))), Tx, Ty
+
+
+def sampler_capture_config(boundaries):
+    """Trainer keyword arguments for batches built by a length-bucketed sampler with these boundaries (the reference trains with
+    [32, 300, ..., 1000], train_ms_emo_lang_pitch.py:101-109): T_y padded to the bucket's boundary, T_x to 64, rows to 1024 (~3 % more
+    masked rows than 512), a key captured the second time it is seen, 16 resident graphs.  On an LJSpeech-shaped length distribution
+    that is 27 distinct keys, 29 captures in three epochs (1 233 steps) and a 97 % replay rate; the round-2 defaults (16 / 32 / 512,
+    capture at first sight, 8 graphs) re-captured on 59 % of the steps (tests/test_capture_policy.py)."""
+    return dict(ty_boundaries=list(boundaries), pad_tx=64, row_round=1024, capture_after=2, max_graphs=16)
+
+
+class CapturePolicy:
+    """Which graph keys are worth a capture: a key is admitted the `capture_after`-th time it is seen while not captured (host-side
+    bookkeeping only; `seen` is bounded)."""
+
+    def __init__(self, capture_after=2, max_tracked=4096):
+        self.capture_after, self.max_tracked = max(1, int(capture_after)), int(max_tracked)
+        self.seen = {}
+
+    def admit(self, key):
+        n = self.seen.get(key, 0) + 1
+        if n < self.capture_after:
+            if len(self.seen) >= self.max_tracked:
+                self.seen.clear()
+            self.seen[key] = n
+            return False
+        self.seen.pop(key, None)
+        return True
+
+
 class Trainer:
     """zero_grad -> forward -> loss -> backward -> all-reduce -> grad-norm -> AdamW step.
 
@@ -321,7 +372,7 @@ class Trainer:
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32",
-                 force_collectives=False):
+                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
         encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
@@ -358,12 +409,21 @@ class Trainer:
         self._grad_norm_buf = None
         self._captured = OrderedDict()            # key -> (graphs, static inputs, outputs, row contexts); LRU, <= max_graphs
         self.max_graphs = int(max_graphs)
+        # Capture policy.  A first-seen graph key costs two eager warm-up passes + the capture (~3 steps of work) and ~2 GiB of graph
+        # memory, and a length-bucketed sampler produces many more (padded T_x, padded T_y, rounded row counts) combinations than
+        # max_graphs slots: a key is captured only once it has been seen `capture_after` times (until then its steps run eagerly,
+        # with exactly one step's collectives), so that one-off shapes do not evict the graphs of the frequent ones.
+        # `capture_stats()` reports the hit rate.
+        self.policy = CapturePolicy(capture_after)
+        self.n_replays = self.n_eager = 0
         self.pad_tx, self.pad_ty = int(pad_tx), int(pad_ty)
         assert self.pad_ty % 2 == 0
         self.n_captures = 0
         self.cfg = model.rows_cfg                 # this model's rows-layout state (ops.RowsConfig): nothing process-global
         self.cfg.ragged = (os.environ.get("GT_RAGGED", "1") != "0") if ragged is None else bool(ragged)
-        self.cfg.row_round = 512 if self.graph_mode else 128     # ragged row count granularity (one graph per rounded size)
+        # ragged row count granularity (one graph per rounded size)
+        self.cfg.row_round = int(row_round) if row_round else (512 if self.graph_mode else 128)
+        self.ty_boundaries = list(ty_boundaries) if ty_boundaries else None
         # bench.py: device-side begin / end stamps of every fused WaveNet-layer forward launch, valid inside replayed graphs
         self.stamps = None
         if kernel_stamps:
@@ -401,7 +461,7 @@ class Trainer:
         # either branch can start.  Only the packing is long (~100 us): the rest runs beside it on the encoder's stream.
         from . import text_models
         side = None
-        if device.type == "cuda" and text_models.ENCODER_STREAM and hasattr(self.model, "prepare"):
+        if device.type == "cuda" and self.cfg.encoder_stream and hasattr(self.model, "prepare"):
             side = text_models._encoder_stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
@@ -545,17 +605,12 @@ class Trainer:
         self.n_captures += 1
         wgrad.sync_uploads(ids.device)               # fill the tables the captured kernels read (once, not per replay)
         wgrad.table_arena_end(ids.device)
-        ctxs = dict(ctxs or {}, _wgrad_tables=tables)  # lives (and is evicted) with this key's graphs
+        ctxs = dict(ctxs or {}, _keep=tables)        # wgrad.CaptureKeep: lives (and is released) with this key's graphs
         return graphs, static + [cond], out, ctxs
 
     def _rows_key(self, Tx, Ty, lh):
-        from . import ops
-        if not self.cfg.ragged:
-            return (0, 0)
-        _, rx = ops.RowsCtx.row_starts(lh[0], Tx, self.cfg.row_round)
-        _, ry = ops.RowsCtx.row_starts([int(v) // 2 for v in lh[1]], Ty // 2, self.cfg.row_round)
-        _, rf = ops.RowsCtx.row_starts([int(v) // 2 * 2 for v in lh[1]], Ty // 2 * 2, self.cfg.row_round)
-        return (rx, ry, rf)
+        """the rounded ragged row counts (text, squeezed mel, frame rows) of a batch padded to (Tx, Ty): the head of its graph key"""
+        return graph_key(lh, (len(lh[0]), Tx), (len(lh[1]), 1, Ty), (), self.cfg.ragged, self.cfg.row_round, 1, 2)[0][:3]
 
     @staticmethod
     def _pad_time(t, T):
@@ -572,14 +627,30 @@ class Trainer:
         if not self.graph_mode:
             return
         for ids, t_x, y, t_y, lh, cond in batches:
-            self._graph_for(ids, t_x, y, t_y, lh, dict(cond or {}))
+            self._graph_for(ids, t_x, y, t_y, lh, dict(cond or {}), force=True)
 
-    def _graph_for(self, ids, t_x, y, t_y, lh, cond):
-        """-> (captured entry or None if capture is impossible, padded inputs)"""
-        Tx = -(-ids.shape[1] // self.pad_tx) * self.pad_tx
-        Ty = -(-y.shape[2] // self.pad_ty) * self.pad_ty
-        key = self._rows_key(Tx, Ty, lh) + (tuple(ids.shape[:-1]) + (Tx,), tuple(y.shape[:-1]) + (Ty,), tuple(sorted(cond)))
+    def capture_stats(self):
+        """{captures, replays, eager steps, hit rate = replays / steps taken in graph mode, graphs resident}"""
+        n = self.n_replays + self.n_eager
+        return {"captures": self.n_captures, "replays": self.n_replays, "eager": self.n_eager,
+                "hit_rate": (self.n_replays / n) if n else None, "resident": len(self._captured)}
+
+    def _evict(self):
+        """least recently used key goes: its graphs free their pool, its CaptureKeep returns the pinned staging buffers to the pool
+        and drops the tables / scratch buffers only those graphs read"""
+        _, (graphs, static, out, ctxs) = self._captured.popitem(last=False)
+        keep = ctxs.pop("_keep", None) if isinstance(ctxs, dict) else None
+        del graphs, static, out, ctxs
+        if keep is not None:
+            keep.release()
+
+    def _graph_for(self, ids, t_x, y, t_y, lh, cond, force=False):
+        """-> (captured entry or None if this step runs eagerly (a cold key, or capture is impossible), padded inputs)"""
+        key, Tx, Ty = graph_key(lh, ids.shape, y.shape, cond, self.cfg.ragged, self.cfg.row_round, self.pad_tx, self.pad_ty,
+                                self.ty_boundaries)
         cap = self._captured.get(key)
+        if cap is None and not force and not self.policy.admit(key):
+            return None, (ids, y, cond)              # a cold key: this step runs eagerly
         if cap is None:
             # a new key: the capture clones PADDED inputs (a known key's batch goes straight into the padded static buffers)
             ids, y = self._pad_time(ids, Tx), self._pad_time(y, Ty)
@@ -596,11 +667,27 @@ class Trainer:
                 self.cfg.prebuilt.clear()
                 return None, (ids, y, cond)
             self._captured[key] = cap
-            while len(self._captured) > self.max_graphs:      # least recently used key goes (its graphs free their pool)
-                self._captured.popitem(last=False)
+            while len(self._captured) > self.max_graphs:
+                self._evict()
         else:
             self._captured.move_to_end(key)
         return cap, (ids, y, cond)
+
+    def _ddi_pass(self, ids, t_x, y, t_y, lh, cond):
+        """ActNorm's data-dependent init (ActNorm.set_ddi(True); modules.py:604-619, the reference's init.py:17-23 runs it as ONE
+        forward pass and saves the result): if any ActNorm is still uninitialised, this batch initialises them all, block after
+        block, in a forward-only pass — no gradient, no optimizer update, outside any capture and outside the capture's
+        snapshot / restore (inside it, the restored parameter buffer silently undid the initialisation while `initialized`
+        stayed True).  The regular step on the same batch follows."""
+        dec = getattr(self.model, "decoder", None)
+        if dec is None or all(dec.flows[3 * b].initialized for b in range(dec.n_blocks)):
+            return
+        assert not torch.cuda.is_current_stream_capturing()
+        was = self.model.training
+        with torch.no_grad():
+            self.model(ids, t_x, y, t_y, lengths_host=lh, **(cond or {}))
+        self.model.train(was)
+        assert all(dec.flows[3 * b].initialized for b in range(dec.n_blocks))
 
     def step(self, ids, t_x, y, t_y, lengths_host=None, g=None, pitch=None, energy=None, l=None, emo=None, emo_cartesian=None):
         """One optimizer step.  g: speaker input ([b, gin_channels, 1] at the encoder boundary, or the raw [b, 512]
@@ -614,11 +701,31 @@ class Trainer:
         lh = lengths_host
         if self.cfg.ragged and lh is None:
             lh = (t_x.tolist(), t_y.tolist())        # device sync: pass lengths_host to avoid it
+        self._ddi_pass(ids, t_x, y, t_y, lh, cond)
         if not self.graph_mode:
             return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
         cap, (ids_p, y_p, cond_p) = self._graph_for(ids, t_x, y, t_y, lh, cond)
         if cap is None:
-            return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
+            self.n_eager += 1
+            if not self.graph_mode or not ids.is_cuda:           # (a failed capture switched graph mode off)
+                return self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
+            # A cold key's eager step runs on the CAPTURE stream: autograd's AccumulateGrad nodes remember the stream of the first
+            # backward they saw, and a later capture whose backward has to synchronise with a stream outside the capture (the
+            # default stream an eager step would have bound them to) is an invalid capture — hipStreamEndCapture answered that with
+            # a segmentation fault (cfg 5, round 3; the round-2 "four capture streams" crash was the same class: a stream the
+            # capture had to wait for without it ever having joined the capture).
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_cap_stream", None) is None:
+                self._cap_stream = torch.cuda.Stream()
+            side = self._cap_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out = self._step_impl(ids, t_x, y, t_y, lh, cond=cond)
+            cur.wait_stream(side)
+            for t_ in (ids, t_x, y, t_y) + tuple((cond or {}).values()):
+                t_.record_stream(side)
+            return out
+        self.n_replays += 1
         graphs, static, out, ctxs = cap
         for dst, src in list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]:
             if dst.data_ptr() != src.data_ptr():

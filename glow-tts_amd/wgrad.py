@@ -52,21 +52,48 @@ def _fill_pool():
 
 
 _PENDING_UPLOADS = []        # (device table, pinned host copy) of the flushes recorded by the graph capture in progress
-_SCRATCH_RETIRED = []
 _TABLE_ARENA = {}            # device -> {"buf", "off"}: where a capture's tables live (see _flush)
+_CAPTURE_KEEP = None         # while a trainer captures a step: what that capture's graphs read (pinned staging buffers, tables, scratch)
+
+
+class CaptureKeep(list):
+    """Everything ONE captured step reads besides its own memory pool: it lives in the trainer's entry for that graph key and goes
+    with it — evicting the key (train.Trainer's LRU) returns the pinned staging buffers to the pool and drops the last reference
+    to tables and outgrown scratch buffers.  (Hung on the module or on a module-level list, as before, every capture leaked its
+    8 MB table arena and its pinned buffers for the life of the model.)"""
+
+    def release(self):
+        for obj in self:
+            if isinstance(obj, torch.Tensor) and not obj.is_cuda and obj.numel() == _POOL_BYTES and obj.is_pinned() and len(_POOL) < 4 * _POOL_N:
+                _POOL.append(obj)
+        self.clear()
 
 
 def table_arena_begin(dev, nbytes=8 << 20):
-    """Before a graph capture (outside it): a buffer for the capture's weight-gradient tables; the caller keeps the returned tensor
-    alive as long as the graph."""
+    """Before a graph capture (outside it): a buffer for the capture's weight-gradient tables.  Returns the CaptureKeep of this
+    capture (the arena is its first element): the caller keeps it exactly as long as the graph and calls .release() on eviction."""
+    global _CAPTURE_KEEP
     buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     _TABLE_ARENA[str(dev)] = {"buf": buf, "off": 0}
     _PENDING_UPLOADS.clear()                          # nothing left over from a capture that failed half-way
-    return buf
+    _CAPTURE_KEEP = CaptureKeep([buf])
+    return _CAPTURE_KEEP
 
 
 def table_arena_end(dev):
+    global _CAPTURE_KEEP
     _TABLE_ARENA.pop(str(dev), None)
+    _CAPTURE_KEEP = None
+
+
+def capture_keep(obj):
+    """Tie obj's lifetime to the graph capture in progress (a scratch buffer the captured kernels write into, say); False if no
+    trainer-owned capture is open."""
+    if _CAPTURE_KEEP is not None:
+        if not any(o is obj for o in _CAPTURE_KEEP):
+            _CAPTURE_KEEP.append(obj)
+        return True
+    return False
 
 
 
@@ -101,18 +128,19 @@ def active():
 
 def _scratch(dev, nbytes):
     """Partial-sum workspace of a flush, one per (device, stream the flush runs on): flushes on different streams (the
-    decoder's and the text encoder's backward run concurrently, text_models.ENCODER_STREAM) must not share it."""
+    decoder's and the text encoder's backward run concurrently, ops.RowsConfig.encoder_stream) must not share it."""
     key = (str(dev), torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None and buf.is_cuda:
-            # A captured step has the address of the buffer it was captured with baked into its kernel arguments, and a later
-            # capture (another row bucket, more slabs) may need a bigger one: the outgrown buffer must stay allocated for as long as
-            # any graph can replay into it — freed, its pages go back to the allocator and the next replay of the older graph
-            # writes its partial sums over whoever owns them then.  They are few (one growth per bucket shape at most).
-            _SCRATCH_RETIRED.append(buf)
+        # A captured step has the address of the buffer it was captured with baked into its kernel arguments, and a later capture
+        # (another row bucket, more slabs) may need a bigger one: the outgrown buffer must stay allocated for as long as any graph
+        # can replay into it — freed, its pages go back to the allocator and the next replay of the older graph writes its partial
+        # sums over whoever owns them then.  Every capture therefore holds a reference to the buffer it used (capture_keep below):
+        # an outgrown buffer lives exactly as long as the graphs that replay into it, and no longer.
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
         _SCRATCH[key] = buf
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing() and not capture_keep(buf):
+        _KEEP.append(buf)                             # a capture nobody owns (no trainer): keep it for the life of the process
     return buf
 
 
@@ -223,8 +251,11 @@ class WgradQueue:
 
     def _keep(self, obj):
         """Whatever a captured graph reads (pinned staging, device tables from the graph's private pool) must outlive
-        the graph — but not the interpreter: hang it on the module that owns the queue, so it dies with the model
-        instead of at interpreter shutdown (device memory of a graph pool freed after the allocator is gone aborts)."""
+        the graph — and go with it: under a trainer's capture it joins that capture's CaptureKeep; a capture nobody owns hangs it
+        on the module that owns the queue, so that it dies with the model instead of at interpreter shutdown (device memory of a
+        graph pool freed after the allocator is gone aborts)."""
+        if capture_keep(obj):
+            return
         if self.site is not None:
             lst = getattr(self.site, "_wgrad_keep", None)
             if lst is None:
@@ -250,9 +281,10 @@ class WgradQueue:
                 if not _POOL or raw.size > _POOL_BYTES:
                     raise RuntimeError("wgrad tables: no pinned staging buffer available inside graph capture "
                                        "(run one eager step first)")
-                host = _POOL.pop()[: raw.size]
+                full = _POOL.pop()
+                host = full[: raw.size]
                 host.numpy()[:] = raw
-                self._keep(host)
+                self._keep(full)                         # the whole buffer: it returns to the pool when the capture is evicted
                 # The tables of a captured step never change (the graph's buffers are static).  With a table arena open (the
                 # trainer allocates it BEFORE the capture, outside the graph's memory pool — a pool block would be reused by other
                 # tensors of the step and clobbered at every replay) they are copied ONCE, right after the capture

@@ -418,6 +418,59 @@ def test_decoder_full_size_cfg2_batch(built):
     assert rows > 8000
 
 
+def _full_size_conditioned_case(B, T_y, seed, gin, prosody, check):
+    """As _full_size_case with the speaker vector (cfg 4) and, for cfg 5, the three WaveNets per block with per-frame pitch / energy
+    conditioning: forward, log-det, input / speaker / contour-independent parameter gradients of a few utterances against the
+    oracle run on just those utterances (the per-utterance loss weights make one utterance's parameter-gradient contribution
+    separable: all other utterances get weight 0 in a second device pass)."""
+    from glow_tts_amd import models, ops
+    dec = fill_module(models.FlowSpecDecoder(80, 192, 5, 1, 12, 4, p_dropout=0.05, gin_channels=gin, with_prosody_wn=prosody), "decoder.").eval()
+    P = cpu_state(dec, "decoder.")
+    g = torch.Generator().manual_seed(seed)
+    lens = (torch.randint(T_y * 3 // 16, T_y // 2 + 1, (B,), generator=g) * 2).tolist()
+    lens[0] = T_y
+    m = lens_mask(lens, T_y)
+    y = torch.randn(B, 80, T_y, generator=g) * m
+    spk = torch.randn(B, gin, 1, generator=g)
+    pit = torch.randn(B, 1, T_y, generator=g) * m if prosody else None
+    ene = torch.randn(B, 1, T_y, generator=g).abs() * m if prosody else None
+    rz = torch.randn(B, 80, T_y, generator=g) * m
+    rl = torch.randn(B, generator=g) * 0.1
+    dec = dec.to(dev())
+    dec.rows_cfg = ops.RowsConfig(ragged=True, row_round=512)
+    dec.rows_cfg.host_lengths["y"] = list(lens)
+    dkw = dict(pitch=pit.to(dev()), energy=ene.to(dev())) if prosody else {}
+    yd, gd = y.to(dev()).requires_grad_(True), spk.to(dev()).requires_grad_(True)
+    zd, ldd = dec(yd, m.to(dev()), g=gd, **dkw)
+    ((zd * rz.to(dev())).sum() + (ldd * rl.to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    for u in check:
+        T = lens[u]
+        yy, gg = y[u:u + 1, :, :T].clone().requires_grad_(True), spk[u:u + 1].clone().requires_grad_(True)
+        okw = dict(pitch=pit[u:u + 1, :, :T], energy=ene[u:u + 1, :, :T]) if prosody else {}
+        z, ld = R.decoder_fwd(P, "decoder.", yy, m[u:u + 1, :, :T], gg, n_blocks=12, **okw)
+        ((z * rz[u:u + 1, :, :T]).sum() + (ld * rl[u:u + 1]).sum()).backward()
+        assert relerr(zd[u:u + 1, :, :T].detach().cpu(), z.detach()) < 3e-2, u
+        assert abs(ldd[u].item() - ld.item()) < 2e-3 * (T // 2) * 160 + 1e-2, (u, ldd[u].item(), ld.item())
+        assert relerr(yd.grad[u:u + 1, :, :T].cpu(), yy.grad) < 4e-2, (u, relerr(yd.grad[u:u + 1, :, :T].cpu(), yy.grad))
+        assert relerr(gd.grad[u:u + 1].cpu(), gg.grad) < 6e-2, (u, relerr(gd.grad[u:u + 1].cpu(), gg.grad))
+    return sum(v // 2 + 4 for v in lens)
+
+
+def test_decoder_full_size_cfg4_batch(built):
+    """cfg 4 (configs/base_blank_ms.json shapes): B = 20, T_y <= 500, speaker vector gin = 256 — parity at the bench's size
+    (cfg 4 / cfg 5 were parity-tested at toy size only)."""
+    rows = _full_size_conditioned_case(20, 500, seed=41, gin=256, prosody=False, check=(0, 19))
+    assert rows > 2500
+
+
+def test_decoder_full_size_cfg5_batch(built):
+    """cfg 5 (configs/base_blank_emo_lang_pitch.json shapes): B = 32, T_y <= 400, gin = 512, three WaveNets per block with per-frame
+    pitch / energy conditioning (the stack kernel's per-row cond at R ~ 5 k rows)."""
+    rows = _full_size_conditioned_case(32, 400, seed=43, gin=512, prosody=True, check=(0, 17))
+    assert rows > 4000
+
+
 def test_decoder_full_size_cfg3_batch(built):
     """cfg 3 (configs/base_blank.json shapes): B = 32, T_y <= 872."""
     rows = _full_size_case(32, 872, seed=77, n_check=2)
@@ -543,11 +596,11 @@ def test_wn_stack_kernel_is_bit_identical_to_the_per_layer_kernels(built, mode):
         cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
     res = []
     for stack in (True, False):
-        flow_impl.WN_STACK = stack
+        wn.set_stack(stack, stack)
         try:
             out, (xs, ts, ss, acts_all, p, seed) = flow_impl.wn_fwd(rc, wn, h0, cond, True, 123, cond_per_row=mode == "per_row")
         finally:
-            flow_impl.WN_STACK = True
+            wn.set_stack(True, True)
         torch.cuda.synchronize()
         res.append((out, xs, ts, ss, acts_all))
     valid = rc.rowmask.bool()
@@ -582,13 +635,13 @@ def test_wn_stack_backward_is_bit_identical_to_the_per_layer_kernels(built, mode
         cond = (torch.randn(rc.R, 2 * H * n, generator=g) * 0.3).to(dev())
     res = []
     for stack in (True, False):
-        flow_impl.WN_STACK = stack
+        wn.set_stack(stack, stack)
         try:
             out, saved = flow_impl.wn_fwd(rc, wn, h0, cond, True, 55, cond_per_row=mode == "per_row")
             with wgrad.WgradQueue(dev(), site=wn):
                 dh0, grads, dcond = flow_impl.wn_bwd(rc, wn, saved, dskip, want_dcond=cond is not None, cond_per_row=mode == "per_row")
         finally:
-            flow_impl.WN_STACK = True
+            wn.set_stack(True, True)
         torch.cuda.synchronize()
         res.append((dh0.clone(), None if dcond is None else dcond.clone(), {id(k): v.clone() for k, v in grads.items()}))
     (d1, c1, g1), (d2, c2, g2) = res
@@ -615,13 +668,13 @@ def test_wn_stack_kernels_other_depths_and_tiny_batches(built, n, lens):
     dskip = ((torch.randn(rc.R, H, generator=g)).to(dev()) * rc.rowmask[:, None]).to(torch.bfloat16)
     res = []
     for stack in (True, False):
-        flow_impl.WN_STACK = stack
+        wn.set_stack(stack, stack)
         try:
             out, saved = flow_impl.wn_fwd(rc, wn, h0, None, True, 9)
             with wgrad.WgradQueue(dev(), site=wn):
                 dh0, grads, _ = flow_impl.wn_bwd(rc, wn, saved, dskip)
         finally:
-            flow_impl.WN_STACK = True
+            wn.set_stack(True, True)
         torch.cuda.synchronize()
         res.append((saved[3].clone(), [t.clone() for t in saved[1] + saved[2] + saved[0]], dh0.clone(), {id(k): v.clone() for k, v in grads.items()}))
     (a1, l1, d1, g1), (a2, l2, d2, g2) = res

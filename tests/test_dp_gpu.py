@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
         for name, graph, w, split in (("eager", False, world, None), ("graph", True, world, None), ("graph3", True, world, True),
                                       ("solo", False, 1, None)):
             m = make()
-            tr = train.Trainer(m, world=w, graph=graph, split_graph=split)
+            tr = train.Trainer(m, world=w, graph=graph, split_graph=split, capture_after=1)     # capture at first sight: new keys mid-stream
             tr.cfg.row_round = 32
             for b in stream:
                 loss, _ = tr.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))

@@ -53,7 +53,7 @@ def _worker(port, q):
         info = {}
         for name, kw in runs:
             m = make()
-            tr = train.Trainer(m, world=1, **kw)
+            tr = train.Trainer(m, world=1, capture_after=1, **kw)
             tr.cfg.row_round = 32
             for b in stream:
                 loss, _ = tr.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))

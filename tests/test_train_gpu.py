@@ -368,16 +368,97 @@ def test_two_trainers_in_one_process_do_not_interfere(built):
         assert worst < 1e-5, worst
 
 
-def test_wgrad_workspace_outgrown_by_a_later_capture_stays_allocated(built):
+def test_wgrad_workspace_outgrown_by_a_later_capture_lives_as_long_as_its_graphs(built):
     """The partial-sum workspace of the batched weight-gradient launches is shared by every captured step of a stream, and a
     captured step has its address baked in.  When a later row bucket needs a bigger one, the outgrown buffer must not go back to
-    the allocator: the older graphs still replay into it (cfg 3 faulted with 'write access to a read-only page' when it did)."""
+    the allocator while an older graph can still replay into it (cfg 3 faulted with 'write access to a read-only page' when it
+    did) — and must go once those graphs are gone (round 2 kept every outgrown buffer for ever).  The capture that used
+    a buffer holds the reference (wgrad.CaptureKeep)."""
+    import gc
+    import weakref
     from glow_tts_amd import wgrad
-    with torch.cuda.stream(torch.cuda.Stream()):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
         a = wgrad._scratch(dev(), 1 << 20)
-        pa = a.data_ptr()
+        pa, wa = a.data_ptr(), weakref.ref(a)
         assert wgrad._scratch(dev(), 1 << 19).data_ptr() == pa           # big enough: reused
-        b = wgrad._scratch(dev(), 8 << 20)
+        keep = wgrad.table_arena_begin(dev())                            # "a capture is open": whoever asks for scratch now registers it
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                assert wgrad._scratch(dev(), 1 << 19).data_ptr() == pa
+                _ = torch.ones(4, device=dev()) * 2.0                    # (a graph with a node in it)
+        finally:
+            wgrad.table_arena_end(dev())
+        assert any(t.data_ptr() == pa for t in keep if isinstance(t, torch.Tensor))
+        b = wgrad._scratch(dev(), 8 << 20)                               # a later bucket outgrows it
         assert b.numel() >= (8 << 20) and b.data_ptr() != pa
         del a
-        assert any(t.data_ptr() == pa for t in wgrad._SCRATCH_RETIRED)
+        gc.collect()
+        assert wa() is not None                                          # the first capture still owns the old buffer
+        keep.release(); del keep, g
+        gc.collect()
+        assert wa() is None                                              # ... and it is gone with that capture
+
+
+def test_evicting_captured_graphs_releases_what_they_pinned(built):
+    """More graph keys than max_graphs: the trainer's memory stays bounded — evicted keys give back their pinned staging buffers
+    (wgrad._POOL) and drop their table arenas (every capture used to leak 8 MB of device memory + its pinned buffers)."""
+    import gc
+    from glow_tts_amd import train, wgrad
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=1, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m = train.build_model(cfg, device=dev())
+    tr = train.Trainer(m, graph=True, max_graphs=2, capture_after=1)
+    tr.cfg.row_round = 32
+    shapes = [(40, 120), (37, 100), (44, 140), (33, 90), (48, 150), (29, 80)]
+    mem, pool = [], []
+    for rnd in range(2):
+        for i, (tx, ty) in enumerate(shapes):
+            b = train.synth_batch(4, tx, ty, i, dev())
+            tr.step(*b, lengths_host=(b[1].tolist(), b[3].tolist()))
+            torch.cuda.synchronize(); gc.collect()
+            mem.append(torch.cuda.memory_allocated()); pool.append(len(wgrad._POOL))
+    assert tr.n_captures >= 10 and len(tr._captured) == 2
+    assert not getattr(m, "_wgrad_keep", None) and not getattr(m.decoder, "_wgrad_keep", None)     # nothing hangs on the modules any more
+    # the second pass over the shapes re-captures everything: allocated memory and the pinned pool must not keep growing
+    first, second = mem[len(shapes) - 1], mem[-1]
+    assert second <= first + (32 << 20), (first, second)
+    assert min(pool[len(shapes):]) >= min(pool[:len(shapes)]) - 8, pool
+    st = tr.capture_stats()
+    assert st["captures"] == tr.n_captures and st["replays"] == len(mem) and st["resident"] == 2
+
+
+def test_actnorm_ddi_survives_the_first_graph_step(built):
+    """ActNorm.set_ddi(True) + a graph trainer: the data-dependent init runs as a forward-only pass BEFORE the first
+    step (the reference's init.py:17-23), outside the capture's snapshot / restore — the parameters it writes must still be there
+    after the step, equal (up to that step's own update) to what a plain no-grad forward of the same batch computes."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+
+    def make():
+        torch.manual_seed(0)
+        m = train.build_model(cfg, device=dev())
+        m.encoder.pre.p_dropout = 0.0
+        for b in range(2):
+            m.decoder.flows[3 * b].set_ddi(True)
+        return m
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    lh = (batch[1].tolist(), batch[3].tolist())
+    ref = make()
+    with torch.no_grad():
+        ref(*batch, lengths_host=lh)
+    want = [(ref.decoder.flows[3 * b].logs.detach().clone(), ref.decoder.flows[3 * b].bias.detach().clone()) for b in range(2)]
+    assert all(w[0].abs().max().item() > 1e-3 for w in want) and want[0][1].abs().max().item() > 1e-3    # the init moved them off zero
+    for graph in (False, True):
+        m = make()
+        tr = train.Trainer(m, graph=graph, capture_after=1)
+        for _ in range(2):
+            tr.step(*batch, lengths_host=lh)
+        torch.cuda.synchronize()
+        assert tr.adam_steps == 2
+        for b in range(2):
+            an = m.decoder.flows[3 * b]
+            assert an.initialized
+            assert (an.logs.detach() - want[b][0]).abs().max().item() < 5e-3, (graph, b)        # two AdamW updates at lr 2e-4 away
+            assert (an.bias.detach() - want[b][1]).abs().max().item() < 5e-3, (graph, b)

@@ -67,11 +67,11 @@ def stack(wn):
 
 
 def layers(wn):
-    flow_impl.WN_STACK = False
+    wn.set_stack(False, False)
     try:
         flow_impl.wn_fwd(rc, wn, x, None, True, 7, layers_only=True)
     finally:
-        flow_impl.WN_STACK = True
+        wn.set_stack(True, True)
 
 
 from glow_tts_amd import wgrad
@@ -83,14 +83,14 @@ via_all = (torch.randn(R, n * H, device=dev) * rc.rowmask[:, None] * 0.1).to(tor
 def bwd_wn(wn, stack_on):
     if id(wn) not in _saved:
         _saved[id(wn)] = flow_impl.wn_fwd(rc, wn, x, None, True, 7, layers_only=True)[1]
-    flow_impl.WN_STACK = stack_on
+    wn.set_stack(stack_on, stack_on)
     try:
         q = wgrad.WgradQueue(dev, site=wn)
         q.__enter__()
         flow_impl.wn_bwd(rc, wn, _saved[id(wn)], dsk, dacts_skip=via_all)
         wgrad._ACTIVE.pop(); q.items = []                      # data-gradient chain only: drop the recorded weight-gradient jobs
     finally:
-        flow_impl.WN_STACK = True
+        wn.set_stack(True, True)
 
 
 for w in wns:
