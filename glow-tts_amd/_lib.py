@@ -89,6 +89,7 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gt_wn_stack_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_stack_rows_per_workgroup": (c_int, [c_int]),
+    "gt_cond_affine_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_wn_stack_bwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_fwd": (c_int, [c_void_p, c_void_p]),
     "gt_wn_boundary_bwd": (c_int, [c_void_p, c_void_p]),
@@ -135,7 +136,8 @@ class WnStackFwdArgs(ctypes.Structure):
                 ("cond", c_void_p), ("ldc", c_int), ("row0", c_void_p), ("B", c_int), ("Tp", c_int), ("rowmask", c_void_p),
                 ("acts", c_void_p), ("ldacts", c_int), ("gate_t", c_void_p * 4), ("gate_s", c_void_p * 4), ("x_out", c_void_p * 4),
                 ("R", c_int), ("H", c_int), ("taps", c_int), ("n_layers", c_int), ("drop_p", c_float), ("drop_seed", c_u32),
-                ("seed_dev", c_void_p), ("stamps", c_void_p), ("stamp_slot", c_int), ("stamp_base", c_void_p)]
+                ("seed_dev", c_void_p), ("stamps", c_void_p), ("stamp_slot", c_int), ("stamp_base", c_void_p),
+                ("aff_w", c_void_p), ("aff_b", c_void_p), ("aff_sig", c_void_p)]
 
 
 class WnStackBwdArgs(ctypes.Structure):

@@ -59,9 +59,13 @@ class CouplingBlock(nn.Module):
         """Keep fragment-ordered twins of the start / end / skip-cat images for the fused between-WaveNets kernels
         (csrc/wn_boundary.hip; the owning FlowSpecDecoder decides).  Returns whether the block's shape qualifies."""
         ok = bool(on) and self.in_channels == 160 and self.hidden_channels == 192 and self.n_layers == 4 and \
-            getattr(self.wn, "fused", False) and not hasattr(self, "wn_pitch")
+            getattr(self.wn, "fused", False)
         self.start.also_frag = self.end.also_frag = ok
-        self.wn.set_boundary_frag(ok)
+        # whichever WaveNet runs last in the block (wn, or wn_energy / wn_pitch when their contours are given) feeds the boundary
+        # kernel's skip GEMM: all of them keep the fragment-ordered twin of their skip-cat image
+        for w in (self.wn, getattr(self, "wn_energy", None), getattr(self, "wn_pitch", None)):
+            if w is not None:
+                w.set_boundary_frag(ok and getattr(w, "fused", False))
         return ok
 
     def store_inverse(self):

@@ -467,7 +467,35 @@ __global__ __launch_bounds__(256) void gt_bct_from_rows_kernel(const void* __res
   }
 }
 
+// Gradient of modules.WNP's affine per-frame conditioning (cond_layer1 has ONE input channel: cond = b + contour * w, squeezed in time,
+// see gt_wn_stack_fwd): from the gate backward's d pre rows of the WaveNet's layers (before the dropout mask where dropout is on),
+//   d w[off_i + c] += sum_m dpre_i[m, c] * sig[m, par_i],   d b[off_i + c] += sum_m dpre_i[m, c],   c < 2H, layer i.
+// grid (row slab, layer); 192 threads, 2 consecutive channels each (one 4-byte load per row), fp32 sums, one atomic pair per thread.
+__global__ __launch_bounds__(192) void gt_cond_affine_grads_kernel(const bf16_t* __restrict__ d0, const bf16_t* __restrict__ d1, const bf16_t* __restrict__ d2,
+                                                                   const bf16_t* __restrict__ d3, int lddp, const float* __restrict__ sig,
+                                                                   float* __restrict__ dw, float* __restrict__ db, int R, int H, int n_layers,
+                                                                   int rows_per_block)
+{
+  const int layer = blockIdx.y, O = H * n_layers;
+  const bf16_t* d = layer == 0 ? d0 : (layer == 1 ? d1 : (layer == 2 ? d2 : d3));
+  const int par = (2 * H * layer) / O, off = 2 * H * layer - par * O;
+  const int c = 2 * threadIdx.x;
+  const int m0 = blockIdx.x * rows_per_block, m1 = min(R, m0 + rows_per_block);
+  float w0 = 0.f, w1 = 0.f, b0 = 0.f, b1 = 0.f;
+  if (c < 2 * H) {
+#pragma unroll 4
+    for (int m = m0; m < m1; ++m) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(d + (size_t)m * lddp + c);
+      const float x0 = bf2f(v & 0xffff), x1 = bf2f(v >> 16), p = sig[2 * (size_t)m + par];
+      b0 += x0; b1 += x1; w0 += x0 * p; w1 += x1 * p;
+    }
+    atomicAdd(dw + off + c, w0); atomicAdd(dw + off + c + 1, w1);
+    atomicAdd(db + off + c, b0); atomicAdd(db + off + c + 1, b1);
+  }
+}
+
 }  // namespace
+
 
 #define GT_ST(s) static_cast<hipStream_t>(s)
 #define GT_RET() return gt_launch_status(__func__)
@@ -615,5 +643,18 @@ extern "C" int gt_bct_from_rows(const void* rows, int rows_f32, void* x, int x_f
   if (!x || !rows || !lengths || B <= 0 || C <= 0 || T <= 0 || Tp <= 0 || R <= 0) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_bct_from_rows_kernel, dim3((T + 63) / 64, (C + 63) / 64, B), dim3(256), 0, GT_ST(stream), rows, rows_f32, x, x_f32,
                      lengths, row0, B, C, T, Tp, R);
+  GT_RET();
+}
+
+extern "C" int gt_cond_affine_grads(const void* dpre0, const void* dpre1, const void* dpre2, const void* dpre3, int lddp, const float* sig,
+                                    float* dw, float* db, int R, int H, int n_layers, void* stream)
+{
+  if (!dpre0 || !sig || !dw || !db || R < 0 || H != 192 || n_layers < 1 || n_layers > 4 || ((H * n_layers) % (2 * H)) || (lddp & 1)) return GT_E_INVAL;
+  if ((n_layers > 1 && !dpre1) || (n_layers > 2 && !dpre2) || (n_layers > 3 && !dpre3)) return GT_E_INVAL;
+  if (R == 0) return GT_OK;
+  const int rows_per_block = 256;
+  hipLaunchKernelGGL(gt_cond_affine_grads_kernel, dim3((R + rows_per_block - 1) / rows_per_block, n_layers), dim3(192), 0, GT_ST(stream),
+                     static_cast<const bf16_t*>(dpre0), static_cast<const bf16_t*>(dpre1), static_cast<const bf16_t*>(dpre2),
+                     static_cast<const bf16_t*>(dpre3), lddp, sig, dw, db, R, H, n_layers, rows_per_block);
   GT_RET();
 }

@@ -48,7 +48,9 @@ __device__ unsigned long long g_wns_ph[1024 * 48];
 constexpr int KK2 = H / 16;
 constexpr int STACK_LDS = (2 * XR + BM) * AP * 2;                       // Xa, Xb [68][200] + At [64][200] = 80 000 B
 constexpr int FWD_BIAS_FLOATS = NLMAX * 2 * H + (NLMAX - 1) * H;        // every layer's biases, staged once (see the forward kernel)
+constexpr int FWD_AFF_FLOATS = 2 * NLMAX * H;                            // affine conditioning (COND == 2): w | b of cond_layer1, H * n each
 constexpr int STACK_FWD_LDS = STACK_LDS + 2 * BM * AP * 2 + FWD_BIAS_FLOATS * 4;   // forward: + the saved tanh / sigmoid tiles [64][200] each + biases = 139 648 B
+constexpr int STACK_FWD_LDS_AFF = STACK_FWD_LDS + FWD_AFF_FLOATS * 4;              // + 6 144 B
 constexpr int CPR = H / 8;                                              // 16-byte chunks per row
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -91,7 +93,12 @@ __device__ __forceinline__ T pick(T const (&arr)[NLMAX], int i)        // scalar
 // the backward kernel needs (its register budget has no room for them).
 // COND / DROP are compile-time: as run-time (uniform) branches around the conditioning loads and the dropout hashes they cost a
 // branch per element and a conservative `s_waitcnt vmcnt(0)` at every join.
-template <bool COND, bool DROP>
+// COND: 0 none; 1 rows of a cond tensor (per utterance: the speaker vector through cond_layer; or per row); 2 AFFINE per-frame
+// conditioning formed here: modules.WNP (modules.py:316-343) conditions on cond_layer1(contour), a conv with ONE input channel —
+// w[c] * contour[t] + b[c] — squeezed in time (modules.py:353-362): squeezed row m, column parity * O + c (O = H n) holds
+// w[c] * contour[2 m + parity] + b[c], and layer i reads columns [2H i, 2H (i+1)).  Materialised, that is 6 KB of fp32 per row written
+// by a host-side op and read back here; formed from the row's two contour values and the 2 x O parameters it is 8 bytes per row.
+template <int COND, bool DROP>
 __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_args a, uint32_t drop_thresh, float drop_scale)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -149,6 +156,17 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     constexpr int NX = (XR * CPR + 255) / 256, NB = (FWD_BIAS_FLOATS / 4 + 255) / 256;   // 7 and 3 per thread
     uint4 xin[NX];
     float4 bin[NB];
+    float4 ain[(FWD_AFF_FLOATS / 4 + 255) / 256];
+    if (COND == 2) {
+      const int O = H * n_layers;
+#pragma unroll
+      for (int i = 0; i < (FWD_AFF_FLOATS / 4 + 255) / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;                       // [w (O) | b (O)] as float4
+        ain[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < O / 4) ain[i] = reinterpret_cast<const float4*>(a.aff_w)[idx];
+        else if (idx < 2 * O / 4) ain[i] = reinterpret_cast<const float4*>(a.aff_b)[idx - O / 4];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int chunk = threadIdx.x + 256 * i, u = chunk / CPR, c8 = chunk - u * CPR, gm = s0 - 2 + u;
@@ -188,6 +206,13 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       const int idx = threadIdx.x + 256 * i;
       if (idx < FWD_BIAS_FLOATS / 4) reinterpret_cast<float4*>(Bs)[idx] = bin[i];
     }
+    if (COND == 2) {
+#pragma unroll
+      for (int i = 0; i < (FWD_AFF_FLOATS / 4 + 255) / 256; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < 2 * H * n_layers / 4) reinterpret_cast<float4*>(Bs + FWD_BIAS_FLOATS)[idx] = ain[i];
+      }
+    }
     if (threadIdx.x < 4 * 24) {                                       // the next tile's rows 0, 1, 66, 67 are never produced
       const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
@@ -198,11 +223,19 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 
   // per-utterance conditioning: the utterance of this lane's two rows (one binary search each, once per launch)
   int cb[2] = {0, 0};
-  if (COND) {
+  float sg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                          // COND == 2: the two contour values (even / odd frame) of this lane's two rows
+  if (COND == 1) {
 #pragma unroll
     for (int bm = 0; bm < 2; ++bm) {
       const int m = s0 + 32 * bm + r, mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
       cb[bm] = a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc;
+    }
+  }
+  if (COND == 2) {
+#pragma unroll
+    for (int bm = 0; bm < 2; ++bm) {
+      const int m = s0 + 32 * bm + r;
+      if (m >= 0 && m < R) { const float2 v = *reinterpret_cast<const float2*>(a.aff_sig + 2 * (size_t)m); sg[bm][0] = v.x; sg[bm][1] = v.y; }
     }
   }
 
@@ -268,7 +301,11 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
 
     // gate epilogue in registers (see wn_layer.hip): block 3*wave + bn holds [16 tanh | 16 sigmoid] of channels 16*(3*wave+bn)..+15
     bf16_t* acts = static_cast<bf16_t*>(a.acts) + layer * H;
-    const float* cond = COND ? a.cond + (size_t)layer * 2 * H : nullptr;
+    const float* cond = COND == 1 ? a.cond + (size_t)layer * 2 * H : nullptr;
+    // affine conditioning of this layer: column 2H * layer of the squeezed cond_layer1 output = parity par, parameters off ..
+    const int aff_O = H * n_layers, aff_par = (2 * H * layer) / aff_O, aff_off = (2 * H * layer) - aff_par * aff_O;
+    const float* Aw = Bs + FWD_BIAS_FLOATS + aff_off;
+    const float* Ab = Aw + aff_O;
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -280,10 +317,18 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
         for (int bm = 0; bm < 2; ++bm) {
           const int t = 32 * bm + r_e, m = s0 + t;
           float ctv[4] = {}, csv[4] = {};
-          if (COND) {
+          if (COND == 1) {
             const float* cp = cond + (size_t)cb[bm] * a.ldc + c;
             const float4 ct = *reinterpret_cast<const float4*>(cp), cs = *reinterpret_cast<const float4*>(cp + H);
             ctv[0] = ct.x; ctv[1] = ct.y; ctv[2] = ct.z; ctv[3] = ct.w; csv[0] = cs.x; csv[1] = cs.y; csv[2] = cs.z; csv[3] = cs.w;
+          }
+          if (COND == 2) {
+            const float pv = aff_par ? sg[bm][1] : sg[bm][0];
+            const float4 wt = *reinterpret_cast<const float4*>(Aw + c), ws = *reinterpret_cast<const float4*>(Aw + H + c);
+            const float4 bt2 = *reinterpret_cast<const float4*>(Ab + c), bs2 = *reinterpret_cast<const float4*>(Ab + H + c);
+            // torch.addcmul(b, contour, w) of the host-side form: b + contour * w, one rounding each way it is written
+            ctv[0] = bt2.x + pv * wt.x; ctv[1] = bt2.y + pv * wt.y; ctv[2] = bt2.z + pv * wt.z; ctv[3] = bt2.w + pv * wt.w;
+            csv[0] = bs2.x + pv * ws.x; csv[1] = bs2.y + pv * ws.y; csv[2] = bs2.z + pv * ws.z; csv[3] = bs2.w + pv * ws.w;
           }
           float tt[4], ss[4], aa[4];
 #pragma unroll
@@ -796,24 +841,32 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
         !al16(a.x_out[i])) return GT_E_ALIGN;
   }
   if (a.cond && (a.Tp <= 0 || (a.row0 && a.B <= 0))) return GT_E_INVAL;
+  const bool affine = a.aff_w || a.aff_b || a.aff_sig;
+  if (affine) {
+    if (a.cond || !a.aff_w || !a.aff_b || !a.aff_sig || ((H * a.n_layers) % (2 * H))) return GT_E_INVAL;   // (O must hold whole layers: n even)
+    if (!al16(a.aff_w) || !al16(a.aff_b) || ((uintptr_t)a.aff_sig & 7)) return GT_E_ALIGN;
+  }
   uint32_t thresh = 0; float scale = 1.0f;
   if (a.drop_p > 0.0f) {
     if (a.drop_p >= 1.0f) return GT_E_UNSUPPORTED;
     thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
   }
   typedef void (*kern_t)(gt_wn_stack_fwd_args, uint32_t, float);
-  static const kern_t kerns[4] = {gt_wn_stack_fwd_kernel<false, false>, gt_wn_stack_fwd_kernel<false, true>,
-                                  gt_wn_stack_fwd_kernel<true, false>, gt_wn_stack_fwd_kernel<true, true>};
+  static const kern_t kerns[6] = {gt_wn_stack_fwd_kernel<0, false>, gt_wn_stack_fwd_kernel<0, true>, gt_wn_stack_fwd_kernel<1, false>,
+                                  gt_wn_stack_fwd_kernel<1, true>, gt_wn_stack_fwd_kernel<2, false>, gt_wn_stack_fwd_kernel<2, true>};
   static bool attr = false;                    // > 64 KB of LDS: opt in once per process
   if (!attr) {
-    for (kern_t k : kerns)
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, STACK_FWD_LDS) != hipSuccess)
+    for (int i = 0; i < 6; ++i)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              i >= 4 ? STACK_FWD_LDS_AFF : STACK_FWD_LDS) != hipSuccess)
         return GT_E_LAUNCH;
     attr = true;
   }
   const int own = BM - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
-  hipLaunchKernelGGL(kerns[(a.cond ? 2 : 0) + (thresh ? 1 : 0)], grid, block, STACK_FWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  const int mode = affine ? 2 : (a.cond ? 1 : 0);
+  hipLaunchKernelGGL(kerns[2 * mode + (thresh ? 1 : 0)], grid, block, affine ? STACK_FWD_LDS_AFF : STACK_FWD_LDS,
+                     static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }
 

@@ -159,19 +159,25 @@ def _stack_pays(R, n, dev):
     return rounds(own) <= rounds(64)
 
 
-def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False):
+def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False, affine=None):
     """modules.WN.forward on rows.  h0: [R,H] bf16 (masked).  cond: [B, 2*H*n_layers] fp32 or None; with cond_per_row
     it is [R, 2*H*n_layers] — the per-frame conditioning of modules.WNP.forward (modules.py:316-343), whose loop is WN's.
     Returns out [R,H] bf16 (= skip sum * mask) and saved activations.
 
     One kernel per layer (gt_wn_layer_fwd: k=5 conv + gate + residual 1x1 on the gated tile).  The gated activations of
     all layers live side by side in ONE [R, n*H] buffer, and output = sum_i skip_i(acts_i) (modules.py:168-170) is a
-    single K = n*H GEMM at the end instead of n read-modify-write passes over an fp32 accumulator."""
+    single K = n*H GEMM at the end instead of n read-modify-write passes over an fp32 accumulator.
+    affine = (sig [R, 2], w [O], b [O]): modules.WNP's per-frame conditioning in its affine form (cond_layer1 has one input channel):
+    the whole-WaveNet kernel forms it from the row's two contour values (no [R, 2*H*n] fp32 rows); the per-layer path
+    materialises it (cond_rows) as before."""
     L = _lib.lib()
     R, H = h0.shape
     dev = h0.device
     n = wn.n_layers
     p = wn.p_dropout if train else 0.0
+    if affine is not None:
+        assert cond is None
+        aff_sig, aff_w, aff_b = affine[0], affine[1].detach().float().contiguous(), affine[2].detach().float().contiguous()
     xs, ts, ss = [h0], [], []
     acts_all = torch.empty(R, n * H, dtype=torch.bfloat16, device=dev)
     x = h0
@@ -192,7 +198,8 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
             B=0 if (cond_per_row or cond is None) else rc.B, Tp=rc.Tp, rowmask=rc.rowmask, acts=acts_all, ldacts=acts_all.stride(0),
             gate_t=ts + pad, gate_s=ss + pad, x_out=xs[1:] + [None] + pad, R=R, H=H, taps=wn.kernel_size, n_layers=n,
             drop_p=float(p), drop_seed=int(seed), seed_dev=seed_word(dev) if p > 0 else None,
-            stamps=stamps.buf if stamps else None, stamp_slot=stamps.take(f"stack{n}") if stamps else 0, stamp_base=stamps.base if stamps else None)
+            stamps=stamps.buf if stamps else None, stamp_slot=stamps.take(f"stack{n}") if stamps else 0, stamp_base=stamps.base if stamps else None,
+            **(dict(aff_w=aff_w, aff_b=aff_b, aff_sig=aff_sig) if affine is not None else {}))
         _ev = KERNEL_TIMER.start("wn_stack_fwd")
         rcode = L.gt_wn_stack_fwd(ctypes.byref(args), _st(dev))
         KERNEL_TIMER.stop(_ev)
@@ -201,6 +208,8 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
         if layers_only:
             return None, saved
         return conv_rows(acts_all, wn.pc_skipcat, rc, bias=wn.skip_bias, mask=True), saved
+    if affine is not None:                            # the per-layer kernels read materialised rows
+        cond, cond_per_row = cond_rows(aff_sig, (aff_w, aff_b)), True
     for i in range(n):
         ci = None if cond is None else cond[:, 2 * H * i:2 * H * (i + 1)]
         acts = acts_all[:, i * H:(i + 1) * H]
@@ -244,15 +253,26 @@ def wn_fwd(rc, wn, h0, cond, train, seed, cond_per_row=False, layers_only=False)
     return out, saved
 
 
-def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False, dacts_skip=None):
+def wn_bwd(rc, wn, saved, dskip, want_dcond=False, cond_per_row=False, dacts_skip=None, affine_grads=None):
     """dskip: [R,H] bf16, the MASKED gradient of the wn output (= d skip of every layer, since out = skip*mask).
     dacts_skip (fused layers only): dskip @ [W_skip_0 | ..] [R, n*H] when the caller already has it (boundary kernel).
     Returns (dh0 [R,H] bf16 masked, {param: grad}, dcond); dcond is [B, 2*H*n] (per-utterance sums) or, with
-    cond_per_row, the per-frame gradient [R, 2*H*n] fp32."""
+    cond_per_row, the per-frame gradient [R, 2*H*n] fp32.
+    affine_grads = (sig [R, 2], dw [O], db [O]): the conditioning was modules.WNP's affine map (wn_fwd(affine=...)); the gradients of
+    its two parameter vectors are ACCUMULATED into dw / db (gt_cond_affine_grads, straight from the gate backward's rows) and
+    dcond comes back None — no [R, 2*H*n] fp32 gradient rows, no reductions on the host side."""
+    if affine_grads is not None:
+        want_dcond, cond_per_row = True, True
     if _fused_ok(wn):
-        return _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip)
-    assert dacts_skip is None
-    return _wn_bwd_unfused(rc, wn, saved, dskip, want_dcond, cond_per_row)
+        dh0, grads, dcond = _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip, affine_grads)
+    else:
+        assert dacts_skip is None
+        dh0, grads, dcond = _wn_bwd_unfused(rc, wn, saved, dskip, want_dcond, cond_per_row)
+    if affine_grads is not None and dcond is not None:       # a path that produced gradient rows: reduce them the old way
+        g = cond_affine_grads(dcond, affine_grads[0])
+        affine_grads[1].add_(g[0]); affine_grads[2].add_(g[1])
+        dcond = None
+    return dh0, grads, dcond
 
 
 def _dcond_store(rc, dcond, i, H, src, cond_per_row):
@@ -262,7 +282,7 @@ def _dcond_store(rc, dcond, i, H, src, cond_per_row):
         rc.utt_sum(src, dcond[:, 2 * H * i:2 * H * (i + 1)])
 
 
-def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=None):
+def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=None, affine_grads=None):
     """One kernel per layer boundary (gt_wn_layer_bwd): the k=5 data gradient of layer i+1's in_layer gives dX_{i+1} (the
     gradient at x_{i+1}); on that tile the residual 1x1's data gradient + the skip-path gradient + the gate backward of
     layer i follow, and d pre_i leaves for the next launch and for the weight gradients."""
@@ -272,12 +292,14 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
     dev = dskip.device
     n = wn.n_layers
     grads = {}
-    dcond = None if not want_dcond else torch.empty(R if cond_per_row else rc.B, 2 * H * n, dtype=torch.float32, device=dev)
+    use_stack = getattr(wn, "stack_bwd", True) and n <= 4 and _stack_pays(R, n, dev)
+    dcond = None if (not want_dcond or (use_stack and affine_grads is not None)) else \
+        torch.empty(R if cond_per_row else rc.B, 2 * H * n, dtype=torch.float32, device=dev)
     need_c = want_dcond and p > 0                     # cond is added after the dropout: its gradient is d pre BEFORE the mask
     # skip path of every layer at once: dskip @ [W_skip_0 | ... | W_skip_{n-1}]  ->  [R, n*H]
     if dacts_skip is None:
         dacts_skip = conv_rows(dskip, wn.pc_skipcat, rc, dgrad=True)
-    if getattr(wn, "stack_bwd", True) and n <= 4 and _stack_pays(R, n, dev):
+    if use_stack:
         # the whole data-gradient chain in ONE launch (csrc/wn_stack.hip), then the weight-gradient jobs on what it wrote
         import ctypes
         bf = dict(dtype=torch.bfloat16, device=dev)
@@ -301,8 +323,13 @@ def _wn_bwd_fused(rc, wn, saved, dskip, want_dcond, cond_per_row, dacts_skip=Non
             else:
                 grads.update(conv_param_grads(wn.res_skip_layers[i], acts, None, R, parts=[(dxs[i + 1], 0, H), (dskip, H, H)]))
             grads.update(conv_param_grads(wn.in_layers[i], xs[i], dpre[i], R))
-            if want_dcond:
+            if want_dcond and affine_grads is None:
                 _dcond_store(rc, dcond, i, H, dpre_c[i] if need_c else dpre[i], cond_per_row)
+        if affine_grads is not None:
+            src = (dpre_c if need_c else dpre) + [None] * (4 - n)
+            _lib.check(L.gt_cond_affine_grads(_lib.ptr(src[0]), _lib.ptr(src[1]), _lib.ptr(src[2]), _lib.ptr(src[3]), 2 * H,
+                                              _lib.ptr(affine_grads[0]), _lib.ptr(affine_grads[1]), _lib.ptr(affine_grads[2]), R, H, n, _st(dev)),
+                       "gt_cond_affine_grads")
         return dxs[0], grads, dcond
     # top layer: no residual output, d acts = skip path only
     i = n - 1
@@ -484,7 +511,7 @@ BOUNDARY_TRACE = None        # dev (tools/wn_boundary_bench.py): a list collects
 
 class _BlockState:
     """what one flow block keeps for the backward on the fused path"""
-    __slots__ = ("x_in", "y", "x0", "h0", "wn_saved", "wn_out", "logs_raw", "z", "scal", "w_ic")
+    __slots__ = ("x_in", "y", "x0", "h0", "wn_saved", "wn_out", "logs_raw", "z", "scal", "w_ic", "chain")
 
 
 def _ptr_table(dec):
@@ -533,7 +560,17 @@ def flow_scalars_all(dec):
     return torch.stack([flow_scalars(l, w) for l, w in zip(lgs, Ws)]), Ws
 
 
-def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_bct=None):
+def block_chain(cb, cond, esig=None, eaff_b=None, psig=None, paff_b=None):
+    """The WaveNets of one coupling block in the reference's order (attentions.py:152-154: wn, wn_energy, wn_pitch; the latter two
+    are the identity when their contour is None, modules.py:323-324) with what conditions each: [(module, cond, affine)]."""
+    chain = [(cb.wn, cond, None)]
+    for w, sig, aff in ((getattr(cb, "wn_energy", None), esig, eaff_b), (getattr(cb, "wn_pitch", None), psig, paff_b)):
+        if w is not None and sig is not None:
+            chain.append((w, None, (sig, aff[0], aff[1])))
+    return chain
+
+
+def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_bct=None, esig=None, eaff=None, psig=None, paff=None):
     """The decoder's flow chain with ONE kernel between consecutive WaveNets (gt_wn_boundary_fwd: tail of block b-1 + head
     of block b) and one kernel per WaveNet layer: n_blocks * (n_layers + 1) + 1 launches.  rows [R, C] fp32 (squeezed mel),
     conds[b]: [B, 2*H*n] or None.  Returns (z rows, per-block saved state).
@@ -549,14 +586,15 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_b
     blocks = []
     for b in range(nb + 1):
         kw = dict(rowmask=rc.rowmask, R=R, H=H, C=C, n_layers=n, logdet=logdet)
-        if b > 0:                                          # tail of block b-1
+        if b > 0:                                          # tail of block b-1: on the LAST WaveNet of its chain
             sv, cbp = blocks[b - 1], dec.flows[3 * (b - 1) + 2]
+            last_wn = sv.chain[-1][0]
             acts_all = sv.wn_saved[3]
             sv.wn_out = torch.empty(R, H, **bf)
             sv.logs_raw = torch.empty(R, C // 2, **f32)
             last_out = b == nb and z_bct is not None
             sv.z = None if last_out else torch.empty(R, C, **f32)
-            kw.update(acts=acts_all, ldacts=acts_all.stride(0), w_skip=cbp.wn.pc_skipcat_frag.fwd, b_skip=cbp.wn.skip_bias,
+            kw.update(acts=acts_all, ldacts=acts_all.stride(0), w_skip=last_wn.pc_skipcat_frag.fwd, b_skip=last_wn.skip_bias,
                       w_end=cbp.end.pc_frag.fwd, b_end=cbp.end.bias, ks_end=cbp.end.pc_frag.Kp_f // 16, y=sv.y, wn_out=sv.wn_out,
                       logs_raw=sv.logs_raw, z=sv.z, rowutt=rc.rowutt, sigmoid_scale=int(cbp.sigmoid_scale))
             if last_out:
@@ -586,12 +624,21 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_b
         KERNEL_TIMER.stop(_ev)
         _lib.check(rcode, "gt_wn_boundary_fwd")
         if b < nb:
+            # the block's WaveNets: wn (speaker vector) [-> wn_energy -> wn_pitch (affine per-frame conditioning)]; between two of them
+            # only the skip GEMM + mask (one launch); the last one's gated activations go straight into the next boundary launch
             st = blocks[b]
-            _, st.wn_saved = wn_fwd(rc, dec.flows[3 * b + 2].wn, st.h0, conds[b], train, seed + 16 * b, layers_only=True)
+            chain = block_chain(dec.flows[3 * b + 2], conds[b], esig, None if eaff is None else eaff[b], psig, None if paff is None else paff[b])
+            h, st.chain = st.h0, []
+            for k, (w, c, aff) in enumerate(chain):
+                last = k == len(chain) - 1
+                out, sv_k = wn_fwd(rc, w, h, c, train, seed + 16 * b + 4 * k, layers_only=last, affine=aff)
+                st.chain.append((w, sv_k, aff))
+                h = out
+            st.wn_saved = st.chain[-1][1]
     return blocks[-1].z, blocks
 
 
-def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx_bct=None):
+def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx_bct=None, deaff=None, dpaff=None):
     """Backward of decoder_fwd_fused: gt_wn_boundary_bwd between the WaveNets' layer kernels.  drows [R, C] fp32 = gradient
     of the decoder's output rows; returns (d input rows [R, C], {param: grad}, [dcond per block]).
     dz_bct / dx_bct ([B, C/2, T] fp32, T even, dx_bct pre-zeroed): the gradients at the public boundary — the first launch then
@@ -637,7 +684,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
             via = torch.empty(R, n * H, **bf)
             kw.update(logs_raw=svp.logs_raw, y=svp.y, dlogdet=dlogdet, rowutt=rc.rowutt, sigmoid_scale=int(cbp.sigmoid_scale),
                       dout=dout, w_end_d=cbp.end.pc_frag.dgrad, ks_end_d=cbp.end.pc_frag.Kp_d // 16, dwn_out=dwn,
-                      w_skip_d=cbp.wn.pc_skipcat_frag.dgrad, ks_skip_d=cbp.wn.pc_skipcat_frag.Kp_d // 16, via_skip=via, ldvs=via.stride(0))
+                      w_skip_d=svp.chain[-1][0].pc_skipcat_frag.dgrad, ks_skip_d=svp.chain[-1][0].pc_skipcat_frag.Kp_d // 16, via_skip=via,
+                      ldvs=via.stride(0))
             new_tail = (dout, dwn, via)
         if dx_out is None:
             kw.update(dx_bct=dx_bct, T=dx_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe)
@@ -659,8 +707,21 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
         cbp, svp = dec.flows[3 * (b - 1) + 2], blocks[b - 1]
         dout, dwn, via = new_tail
         grads.update(conv_param_grads(cbp.end, svp.wn_out, dout, R))
-        dh0, g2, dconds[b - 1] = wn_bwd(rc, cbp.wn, svp.wn_saved, dwn, has_cond, dacts_skip=via)
-        grads.update(g2)
+        # the chain backwards: the masked input gradient of a WaveNet is the d skip of the one before it; the last one's skip-path
+        # gradient came out of the boundary launch (via), the others compute theirs (one launch)
+        dskip = dwn
+        for k in reversed(range(len(svp.chain))):
+            w, sv_k, aff = svp.chain[k]
+            ag = None
+            if aff is not None:
+                dst = deaff if w is getattr(cbp, "wn_energy", None) else dpaff
+                ag = (aff[0], dst[b - 1, 0], dst[b - 1, 1])
+            dskip, g2, dc = wn_bwd(rc, w, sv_k, dskip, has_cond if k == 0 else False, dacts_skip=via if k == len(svp.chain) - 1 else None,
+                                   affine_grads=ag)
+            grads.update(g2)
+            if k == 0:
+                dconds[b - 1] = dc
+        dh0 = dskip
         grads.update(conv_param_grads(cbp.start, svp.x0, dh0, R))
         dx_prev = dx_out
 

@@ -141,19 +141,21 @@ class _DecoderRunner:
         esig, psig = self._contour_rows(rc, self.energy, B, T2 * 2), self._contour_rows(rc, self.pitch, B, T2 * 2)
         saved = []
         # one kernel between consecutive WaveNets (csrc/wn_boundary.hip) unless a block still waits for its data-dependent
-        # init (that forward runs round 1's launch sequence once) or per-frame prosody conditioning is on
-        fused = dec.fused_boundary and esig is None and psig is None and all(dec.flows[3 * b].initialized for b in range(nb))
+        # init (that forward runs round 1's launch sequence once).  With per-frame prosody conditioning (cfg 5) a block is a chain
+        # of up to three WaveNets: the boundary kernel sits behind the last one, a skip GEMM between two of them
+        fused = dec.fused_boundary and all(dec.flows[3 * b].initialized for b in range(nb))
+        pros = dict(esig=esig, eaff=eaff, psig=psig, paff=paff)
         # ... and then commons.squeeze / unsqueeze ride in its first / last launch (ragged rows, even T)
         folded = fused and T == T2 * 2 and getattr(rc, "rowbatch", None) is not None
         if folded:
             z = ops.zeros_big((B, C, T), torch.float32, dev)
-            _, blocks = flow_impl.decoder_fwd_fused(rc, dec, None, conds, logdet, self.train, self.seed, y_bct=xin, z_bct=z)
+            _, blocks = flow_impl.decoder_fwd_fused(rc, dec, None, conds, logdet, self.train, self.seed, y_bct=xin, z_bct=z, **pros)
             return (z.to(x.dtype), logdet), (rc, ("fused", blocks), (B, C, T), esig, psig)
         rows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(xin), _lib.ptr(rows), _lib.ptr(rc.lengths), B, C, T, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         cur = rows
         if fused:
-            cur, blocks = flow_impl.decoder_fwd_fused(rc, dec, rows, conds, logdet, self.train, self.seed)
+            cur, blocks = flow_impl.decoder_fwd_fused(rc, dec, rows, conds, logdet, self.train, self.seed, **pros)
             saved = ("fused", blocks)
         for b in range(0 if not fused else nb, nb):
             an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
@@ -206,16 +208,20 @@ class _DecoderRunner:
         dlogdet = ops.zeros_small(B, torch.float32, dev) if dlogdet is None else dlogdet.contiguous().float()
         grads = {}
         fused = isinstance(saved, tuple) and len(saved) == 2 and saved[0] == "fused"
+        O = 2 * dec.hidden_channels * dec.n_layers // 2
+        deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None     # (w, b) gradients of the
+        dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None     # affine conditioning, per block
         if fused and dz is not None and T == T2 * 2 and getattr(rc, "rowbatch", None) is not None:
             # squeeze of d z / unsqueeze of the input gradient inside the first / last launch of the backward chain
             dzc = dz.float().contiguous()
             dx = ops.zeros_big((B, C, T), torch.float32, dev)
             ops.mark("dec bwd begin")
             with wgrad.WgradQueue(dev, site=dec):
-                _, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], None, dlogdet, self.has_cond, dz_bct=dzc, dx_bct=dx)
+                _, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], None, dlogdet, self.has_cond, dz_bct=dzc, dx_bct=dx,
+                                                               deaff=deaff, dpaff=dpaff)
                 ops.mark("dec dgrad end")
             ops.mark("dec wgrad end")
-            return [dx] + (dconds if self.has_cond else []) + [grads.get(p) for p in self.params]
+            return [dx] + (dconds if self.has_cond else []) + [d for d in (deaff, dpaff) if d is not None] + [grads.get(p) for p in self.params]
         drows = torch.empty(rc.R, 2 * C, dtype=torch.float32, device=dev)
         if dz is None:
             drows.zero_()
@@ -223,14 +229,11 @@ class _DecoderRunner:
             dzc = dz.float().contiguous()
             _lib.check(L.gt_squeeze_rows_f32(_lib.ptr(dzc), _lib.ptr(drows), _lib.ptr(rc.lengths), B, C, T2 * 2, rc.Tp, _lib.ptr(rc.row0), st), "gt_squeeze_rows_f32")
         dconds = [None] * nb
-        O = 2 * dec.hidden_channels * dec.n_layers // 2
-        deaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if esig is not None else None
-        dpaff = torch.zeros(nb, 2, O, dtype=torch.float32, device=dev) if psig is not None else None
         cur = drows
         # data-gradient chain now; ALL weight gradients of the decoder go out as one batch when the block ends
         with wgrad.WgradQueue(dev, site=dec):
             if fused:
-                cur, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], drows, dlogdet, self.has_cond)
+                cur, grads, dconds = flow_impl.decoder_bwd_fused(rc, dec, saved[1], drows, dlogdet, self.has_cond, deaff=deaff, dpaff=dpaff)
             for b in (() if fused else reversed(range(nb))):
                 an, ic, cb = dec.flows[3 * b], dec.flows[3 * b + 1], dec.flows[3 * b + 2]
                 s1, s2 = saved[b]

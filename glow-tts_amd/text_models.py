@@ -754,8 +754,13 @@ class FlowGenerator(nn.Module):
                 es = energy_stream if ready is not None else None
                 if es is not None:
                     es.wait_event(ready)                                    # not the pitch chain queued behind it
+                    xf.record_stream(es); zsum.record_stream(es)            # produced on this stream, read on that one
                 with (torch.cuda.stream(es) if es is not None else contextlib.nullcontext()):
                     pe = self.proj_energy
                     nez = None if noise is None else rcf.to_rows(noise[2].float())[:, 0].contiguous()
                     l_energy = torch.sum(pe.nll_rows(rcf, xf, rcf.to_rows(energy_norm.float())[:, 0].contiguous(), pe.cond_vec(g), nez) / zsum)
+            # (A stream each for the pitch and the energy chain — forked from the encoder's stream, re-joined to it — was tried again in
+            # round 3 with the capture-stream fix of train.Trainer in place: eager steps run, the capture still dies in
+            # hipStreamEndCapture (host segmentation fault, 8 s into the run, before any replay).  Three streams in a capture work, a
+            # fourth forked from a FORKED stream does not on this ROCm; not pursued further.)
         return l_length, l_pitch, l_energy, logw

@@ -394,7 +394,17 @@ typedef struct gt_wn_stack_fwd_args {
   int R, H, taps, n_layers;
   float drop_p; uint32_t drop_seed; const uint32_t* seed_dev;
   unsigned long long* stamps; int stamp_slot; const int32_t* stamp_base;   /* as gt_wn_layer_fwd */
+  /* optional, instead of cond: AFFINE per-frame conditioning of modules.WNP (modules.py:316-343, 353-362) formed in the kernel:
+   * cond[m, 2H i + c] = aff_b[off + c] + aff_sig[m, par] * aff_w[off + c] with O = H n_layers, par = (2H i) / O, off = (2H i) % O
+   * (n_layers even) — aff_w / aff_b: fp32 [O] (cond_layer1's weight-normed weight and bias), aff_sig: fp32 [R, 2] = the contour
+   * at frames 2 m and 2 m + 1 of squeezed row m */
+  const float* aff_w; const float* aff_b; const float* aff_sig;
 } gt_wn_stack_fwd_args;
+/* gradient of the affine conditioning's parameters from the d pre rows of the WaveNet's layers (dpre_c of gt_wn_stack_bwd, or dpre
+ * where no dropout is applied): dw[off_i + c] += sum_m dpre_i[m, c] aff_sig[m, par_i], db[off_i + c] += sum_m dpre_i[m, c]
+ * (par_i, off_i as above; fp32 [H n_layers] accumulators the caller zeroes; dpre_i: bf16 [R, lddp >= 2H]) */
+int gt_cond_affine_grads(const void* dpre0, const void* dpre1, const void* dpre2, const void* dpre3, int lddp, const float* sig,
+                         float* dw, float* db, int R, int H, int n_layers, void* stream);
 int gt_wn_stack_rows_per_workgroup(int n_layers);
 int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream);
 /* gt_wn_stack_bwd: the data-gradient chain of the same WaveNet in one launch (what n_layers - 1 calls of gt_wn_layer_bwd, the
