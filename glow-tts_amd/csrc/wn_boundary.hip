@@ -183,6 +183,33 @@ __device__ __forceinline__ void coop_store_rows(bf16_t* __restrict__ dst, int ld
   }
 }
 
+// Prefetch workgroups.  The launch that FOLLOWS a boundary launch on the decoder's chain is a whole WaveNet, and every one of its
+// workgroups streams all 3.2 MB of that WaveNet's weight images — first touched there, they come from HBM (the step's 2 GB of saved
+// activations have pushed everything else out of the 256 MB Infinity Cache) and every workgroup waits on the same misses: + 13 us
+// on a forward launch, + 9 us on a backward one, all of it gone once the images are back in the cache (tools/wn_layer_bench.py,
+// WN_BENCH_COLD).  A boundary launch runs 152 workgroups on 256 CUs: PF_WGS extra workgroups (blockIdx >= the row tiles) read
+// those images once, on CUs that were idle, and retire within a few microseconds.
+constexpr int PF_WGS = 64;
+__device__ __forceinline__ void prefetch_images(const void* const (&ptr)[8], const uint32_t (&bytes)[8], int wg, uint32_t* sink)
+{
+  uint32_t acc = 0;
+  const int gid = wg * 256 + threadIdx.x, nthr = PF_WGS * 256;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (!ptr[i]) break;
+    const uint4* src = static_cast<const uint4*>(ptr[i]);
+    const int n16 = (int)(bytes[i] >> 4);
+    for (int c = gid; c < n16; c += 4 * nthr) {                       // four independent loads in flight per thread
+      const uint4 v0 = src[c];
+      const uint4 v1 = c + nthr < n16 ? src[c + nthr] : make_uint4(0, 0, 0, 0);
+      const uint4 v2 = c + 2 * nthr < n16 ? src[c + 2 * nthr] : make_uint4(0, 0, 0, 0);
+      const uint4 v3 = c + 3 * nthr < n16 ? src[c + 3 * nthr] : make_uint4(0, 0, 0, 0);
+      acc ^= v0.x ^ v1.y ^ v2.z ^ v3.w;
+    }
+  }
+  if (acc == 0x9E3779B9u && sink) *sink = acc;                          // (keeps the loads alive; bf16 weight bits never form this word on every lane)
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 constexpr int F_AS = 0;                                    // acts slices [4][64][AP] bf16; later At [64][AP] (slice 0) / y0 tile
 constexpr int F_O = BM * AP * 2;                           // m | logs tile [64][ZP] fp32 (over slices 1, 2 once they are dead)
@@ -196,6 +223,8 @@ template <bool TAIL, bool HEAD>
 __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd_args a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_tiles = (a.R + BM - 1) / BM;
+  if ((int)blockIdx.x >= n_tiles) { prefetch_images(a.pf_ptr, a.pf_bytes, blockIdx.x - n_tiles, reinterpret_cast<uint32_t*>(a.logdet)); return; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, R = a.R;
@@ -487,6 +516,8 @@ template <bool HEADB, bool TAILB>
 __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd_args a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_tiles = (a.R + BM - 1) / BM;
+  if ((int)blockIdx.x >= n_tiles) { prefetch_images(a.pf_ptr, a.pf_bytes, blockIdx.x - n_tiles, nullptr); return; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, R = a.R;
@@ -824,7 +855,8 @@ extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream
         opt_in_lds(&gt_wn_boundary_fwd_kernel<false, true>, FWD_LDS)) return GT_E_LAUNCH;
     attr = true;
   }
-  const dim3 grid((a.R + BM - 1) / BM), block(256);
+  for (int i = 0; i < 8; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
+  const dim3 grid((a.R + BM - 1) / BM + (a.pf_ptr[0] ? PF_WGS : 0)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tail && head) hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, true>), grid, block, FWD_LDS, st, a);
   else if (tail)    hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, false>), grid, block, FWD_LDS, st, a);
@@ -872,7 +904,8 @@ extern "C" int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream
         opt_in_lds(&gt_wn_boundary_bwd_kernel<false, true>, BWD_LDS)) return GT_E_LAUNCH;
     attr = true;
   }
-  const dim3 grid((a.R + BM - 1) / BM), block(256);
+  for (int i = 0; i < 8; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
+  const dim3 grid((a.R + BM - 1) / BM + (a.pf_ptr[0] ? PF_WGS : 0)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (headb && tailb) hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<true, true>), grid, block, BWD_LDS, st, a);
   else if (headb)     hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<true, false>), grid, block, BWD_LDS, st, a);

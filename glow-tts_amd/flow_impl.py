@@ -560,6 +560,15 @@ def flow_scalars_all(dec):
     return torch.stack([flow_scalars(l, w) for l, w in zip(lgs, Ws)]), Ws
 
 
+def _prefetch_list(wn, attr):
+    """(pointers, byte counts) of a WaveNet's weight images for the boundary launches' prefetch workgroups (attr: "fwd" — the forward
+    images — or "dgrad"): the four in_layers and the residual 1x1s, what the whole-WaveNet launch that follows streams."""
+    n = wn.n_layers
+    imgs = [getattr(il.pc, attr) for il in wn.in_layers] + [getattr(rs.pc_res, attr) for rs in wn.res_skip_layers[:n - 1]]
+    imgs = [t for t in imgs if t is not None][:8]
+    return imgs + [None] * (8 - len(imgs)), [t.numel() * t.element_size() // 16 * 16 for t in imgs] + [0] * (8 - len(imgs))
+
+
 def block_chain(cb, cond, esig=None, eaff_b=None, psig=None, paff_b=None):
     """The WaveNets of one coupling block in the reference's order (attentions.py:152-154: wn, wn_energy, wn_pitch; the latter two
     are the identity when their contour is None, modules.py:323-324) with what conditions each: [(module, cond, affine)]."""
@@ -614,6 +623,8 @@ def decoder_fwd_fused(rc, dec, rows, conds, logdet, train, seed, y_bct=None, z_b
             st.scal, st.w_ic = scal[b], Ws[b]
             kw.update(an_logs=an.logs, an_bias=an.bias, w_ic=st.w_ic, scal=st.scal, len=rc.lengths, B=rc.B, y_next=st.y, y0_bf16=st.x0,
                       w_start=cb.start.pc_frag.fwd, b_start=cb.start.bias, ks_start=cb.start.pc_frag.Kp_f // 16, h_next=st.h0)
+            if _fused_ok(cb.wn):                       # the WaveNet launch that follows: its images are read once by this launch's spare CUs
+                kw["pf_ptr"], kw["pf_bytes"] = _prefetch_list(cb.wn, "fwd")
             blocks.append(st)
         args = _lib.fill_args(_lib.BoundaryFwdArgs, **kw)
         import ctypes
@@ -686,6 +697,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
                       dout=dout, w_end_d=cbp.end.pc_frag.dgrad, ks_end_d=cbp.end.pc_frag.Kp_d // 16, dwn_out=dwn,
                       w_skip_d=svp.chain[-1][0].pc_skipcat_frag.dgrad, ks_skip_d=svp.chain[-1][0].pc_skipcat_frag.Kp_d // 16, via_skip=via,
                       ldvs=via.stride(0))
+            if _fused_ok(svp.chain[-1][0]):
+                kw["pf_ptr"], kw["pf_bytes"] = _prefetch_list(svp.chain[-1][0], "dgrad")
             new_tail = (dout, dwn, via)
         if dx_out is None:
             kw.update(dx_bct=dx_bct, T=dx_bct.shape[2], rowbatch=rc.rowbatch, rowframe=rc.rowframe)

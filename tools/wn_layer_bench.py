@@ -110,6 +110,18 @@ if len(sys.argv) > 1 and sys.argv[1] == 'stack':          # the stack kernels on
         timeit("640 MB fill alone", lambda k: big.fill_(float(k)), launches=24)
         timeit("fill + WN forward (stack)", lambda k: (big.fill_(float(k)), stack(wns[k % 12])), launches=24)
         timeit("fill + WN backward (stack)", lambda k: (big.fill_(float(k)), bwd_wn(wns[k % 12], True)), launches=24)
+        # ... with the WaveNet's weight images touched again behind the fill (they come back into the Infinity Cache / one XCD's L2): how much
+        # of the cold launch's extra time is the weights' first touch, and how much the activations' (inputs from HBM, stores to cold lines)
+        def touch(wn, attr):
+            acc = None
+            for il in wn.in_layers:
+                acc = getattr(il.pc, attr).view(torch.int32).sum() if acc is None else acc + getattr(il.pc, attr).view(torch.int32).sum()
+            for rs in wn.res_skip_layers[:-1]:
+                acc = acc + getattr(rs.pc_res, attr).view(torch.int32).sum()
+            return acc
+        timeit("fill + weight touch alone", lambda k: (big.fill_(float(k)), touch(wns[k % 12], "fwd")), launches=24)
+        timeit("fill + weight touch + WN forward (stack)", lambda k: (big.fill_(float(k)), touch(wns[k % 12], "fwd"), stack(wns[k % 12])), launches=24)
+        timeit("fill + weight touch + WN backward (stack)", lambda k: (big.fill_(float(k)), touch(wns[k % 12], "dgrad"), bwd_wn(wns[k % 12], True)), launches=24)
     sys.exit(0)
 QUICK = len(sys.argv) > 1 and sys.argv[1] == 'quick'
 for frac in ((1,) if QUICK else (1, 2, 4, 8)):          # fewer workgroups, same weights per workgroup: per-CU streaming limit or chip-level L2 limit?
