@@ -158,7 +158,7 @@ class BoundaryFwdArgs(ctypes.Structure):
                 ("b_start", c_void_p), ("ks_start", c_int), ("h_next", c_void_p), ("rowmask", c_void_p),
                 ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int),
                 ("y_bct", c_void_p), ("z_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p),
-                ("pf_ptr", c_void_p * 8), ("pf_bytes", c_u32 * 8)]
+                ("pf_ptr", c_void_p * 16), ("pf_bytes", c_u32 * 16)]
 
 
 class BoundaryBwdArgs(ctypes.Structure):
@@ -171,7 +171,7 @@ class BoundaryBwdArgs(ctypes.Structure):
                 ("dwn_out", c_void_p), ("w_skip_d", c_void_p), ("ks_skip_d", c_int), ("via_skip", c_void_p), ("ldvs", c_int),
                 ("rowmask", c_void_p), ("R", c_int), ("H", c_int), ("C", c_int), ("n_layers", c_int),
                 ("dz_bct", c_void_p), ("dx_bct", c_void_p), ("T", c_int), ("rowbatch", c_void_p), ("rowframe", c_void_p),
-                ("pg_partial", c_void_p), ("pf_ptr", c_void_p * 8), ("pf_bytes", c_u32 * 8)]
+                ("pg_partial", c_void_p), ("pf_ptr", c_void_p * 16), ("pf_bytes", c_u32 * 16)]
 
 
 def fill_args(cls, **kw):

@@ -190,12 +190,12 @@ __device__ __forceinline__ void coop_store_rows(bf16_t* __restrict__ dst, int ld
 // WN_BENCH_COLD).  A boundary launch runs 152 workgroups on 256 CUs: PF_WGS extra workgroups (blockIdx >= the row tiles) read
 // those images once, on CUs that were idle, and retire within a few microseconds.
 constexpr int PF_WGS = 64;
-__device__ __forceinline__ void prefetch_images(const void* const (&ptr)[8], const uint32_t (&bytes)[8], int wg, uint32_t* sink)
+__device__ __forceinline__ void prefetch_images(const void* const (&ptr)[16], const uint32_t (&bytes)[16], int wg, uint32_t* sink)
 {
   uint32_t acc = 0;
   const int gid = wg * 256 + threadIdx.x, nthr = PF_WGS * 256;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 16; ++i) {
     if (!ptr[i]) break;
     const uint4* src = static_cast<const uint4*>(ptr[i]);
     const int n16 = (int)(bytes[i] >> 4);
@@ -855,7 +855,7 @@ extern "C" int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream
         opt_in_lds(&gt_wn_boundary_fwd_kernel<false, true>, FWD_LDS)) return GT_E_LAUNCH;
     attr = true;
   }
-  for (int i = 0; i < 8; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
+  for (int i = 0; i < 16; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
   const dim3 grid((a.R + BM - 1) / BM + (a.pf_ptr[0] ? PF_WGS : 0)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tail && head) hipLaunchKernelGGL((gt_wn_boundary_fwd_kernel<true, true>), grid, block, FWD_LDS, st, a);
@@ -904,7 +904,7 @@ extern "C" int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream
         opt_in_lds(&gt_wn_boundary_bwd_kernel<false, true>, BWD_LDS)) return GT_E_LAUNCH;
     attr = true;
   }
-  for (int i = 0; i < 8; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
+  for (int i = 0; i < 16; ++i) if (a.pf_ptr[i] && (!al16(a.pf_ptr[i]) || (a.pf_bytes[i] & 15))) return GT_E_ALIGN;
   const dim3 grid((a.R + BM - 1) / BM + (a.pf_ptr[0] ? PF_WGS : 0)), block(256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (headb && tailb) hipLaunchKernelGGL((gt_wn_boundary_bwd_kernel<true, true>), grid, block, BWD_LDS, st, a);

@@ -560,13 +560,14 @@ def flow_scalars_all(dec):
     return torch.stack([flow_scalars(l, w) for l, w in zip(lgs, Ws)]), Ws
 
 
-def _prefetch_list(wn, attr):
+def _prefetch_list(wn, attr, extra=()):
     """(pointers, byte counts) of a WaveNet's weight images for the boundary launches' prefetch workgroups (attr: "fwd" — the forward
-    images — or "dgrad"): the four in_layers and the residual 1x1s, what the whole-WaveNet launch that follows streams."""
+    images — or "dgrad"): the four in_layers and the residual 1x1s, what the whole-WaveNet launch that follows streams.  extra:
+    activations that launch reads and that were written long ago (the backward's saved tanh / sigmoid halves)."""
     n = wn.n_layers
-    imgs = [getattr(il.pc, attr) for il in wn.in_layers] + [getattr(rs.pc_res, attr) for rs in wn.res_skip_layers[:n - 1]]
-    imgs = [t for t in imgs if t is not None][:8]
-    return imgs + [None] * (8 - len(imgs)), [t.numel() * t.element_size() // 16 * 16 for t in imgs] + [0] * (8 - len(imgs))
+    imgs = [getattr(il.pc, attr) for il in wn.in_layers] + [getattr(rs.pc_res, attr) for rs in wn.res_skip_layers[:n - 1]] + list(extra)
+    imgs = [t for t in imgs if t is not None][:16]
+    return imgs + [None] * (16 - len(imgs)), [t.numel() * t.element_size() // 16 * 16 for t in imgs] + [0] * (16 - len(imgs))
 
 
 def block_chain(cb, cond, esig=None, eaff_b=None, psig=None, paff_b=None):
@@ -698,6 +699,8 @@ def decoder_bwd_fused(rc, dec, blocks, drows, dlogdet, has_cond, dz_bct=None, dx
                       w_skip_d=svp.chain[-1][0].pc_skipcat_frag.dgrad, ks_skip_d=svp.chain[-1][0].pc_skipcat_frag.Kp_d // 16, via_skip=via,
                       ldvs=via.stride(0))
             if _fused_ok(svp.chain[-1][0]):
+                # (the saved tanh / sigmoid halves the same launch reads — 30 MB written in the forward pass — were tried as `extra`: no
+                # change in the step; the backward launch's cold cost is not where its 64 spare workgroups can reach in 28 us)
                 kw["pf_ptr"], kw["pf_bytes"] = _prefetch_list(svp.chain[-1][0], "dgrad")
             new_tail = (dout, dwn, via)
         if dx_out is None:

@@ -465,10 +465,10 @@ typedef struct gt_boundary_fwd_args {
    * y_bct (head-only variant, instead of x_in): the decoder's input [B, C/2, T] fp32 (z, if given, then receives the squeezed rows); z_bct (tail-only variant, instead of z): its
    * output [B, C/2, T] fp32, pre-zeroed by the caller; rowbatch (int64) / rowframe (int32): gt_rows_ctx_fill's tables; len as above */
   const float* y_bct; float* z_bct; int T; const int64_t* rowbatch; const int32_t* rowframe;
-  /* optional: up to 8 buffers (16-byte aligned, pf_bytes[i] % 16 == 0, pf_ptr[i] == NULL ends the list) that 64 EXTRA workgroups of
+  /* optional: up to 16 buffers (16-byte aligned, pf_bytes[i] % 16 == 0, pf_ptr[i] == NULL ends the list) that 64 EXTRA workgroups of
    * the launch read once, on CUs the 64-row tiles leave idle — the weight images of the WaveNet launch that follows on the chain,
    * which would otherwise take their first touch (HBM) inside it */
-  const void* pf_ptr[8]; uint32_t pf_bytes[8];
+  const void* pf_ptr[16]; uint32_t pf_bytes[16];
 } gt_boundary_fwd_args;
 typedef struct gt_boundary_bwd_args {
   /* head */
@@ -496,7 +496,7 @@ typedef struct gt_boundary_bwd_args {
    * workgroup's sums for d_an_logs | d_an_bias | d_w_ic are STORED there instead of added to the three accumulators with atomics
    * (152 workgroups on the same 336 addresses serialise at L2: ~10 us of a 33 us launch); gt_boundary_param_reduce adds the rows up */
   float* pg_partial;
-  const void* pf_ptr[8]; uint32_t pf_bytes[8];  /* optional prefetch list, as in the forward */
+  const void* pf_ptr[16]; uint32_t pf_bytes[16];  /* optional prefetch list, as in the forward */
 } gt_boundary_bwd_args;
 int gt_wn_boundary_fwd(const gt_boundary_fwd_args* args, void* stream);
 int gt_wn_boundary_bwd(const gt_boundary_bwd_args* args, void* stream);

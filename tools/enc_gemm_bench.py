@@ -36,3 +36,19 @@ for (Cin, Cout, k, name) in [(192, 192, 1, "attn q/k/v/o"), (192, 576, 1, "qkv f
         d = timeit(lambda: ops.conv_rows(dy, pc, rc, dgrad=True, tile=tile))
         out.append(f"{tn} fwd {f:5.1f} dgrad {d:5.1f}")
     print(f"{name:14s} " + " | ".join(out), flush=True)
+
+if len(sys.argv) > 1 and sys.argv[1] == "cold":
+    # the same launches behind a 640 MB fill (L2 and the Infinity Cache evicted: the state of the text encoder's backward inside the step),
+    # with and without the weight image touched again behind the fill: what the first touch of the weights costs a short GEMM launch
+    big = torch.empty(160 * 1024 * 1024, dtype=torch.float32, device=dev)
+    fill = timeit(lambda: big.fill_(1.0), n=10, reps=5)
+    print(f"640 MB fill alone {fill:6.1f} us")
+    for (Cin, Cout, k, name) in [(192, 576, 1, "qkv fused"), (192, 768, 3, "ffn conv1"), (768, 192, 3, "ffn conv2")]:
+        x = torch.randn(R, Cin, device=dev).to(torch.bfloat16)
+        dy = torch.randn(R, Cout, device=dev).to(torch.bfloat16)
+        pc = ops.PackedConv(Cout, Cin, k).pack(torch.randn(Cout, Cin, k, device=dev) * 0.05)
+        warm = timeit(lambda: ops.conv_rows(dy, pc, rc, dgrad=True))
+        cold = timeit(lambda: (big.fill_(1.0), ops.conv_rows(dy, pc, rc, dgrad=True)), n=10, reps=5) - fill
+        touch = timeit(lambda: (big.fill_(1.0), pc.dgrad.view(torch.int32).sum()), n=10, reps=5) - fill
+        both = timeit(lambda: (big.fill_(1.0), pc.dgrad.view(torch.int32).sum(), ops.conv_rows(dy, pc, rc, dgrad=True)), n=10, reps=5) - fill - touch
+        print(f"{name:14s} dgrad: warm {warm:5.1f} us, cold {cold:5.1f} us, cold with the weights touched first {both:5.1f} us", flush=True)
