@@ -286,6 +286,8 @@ def main():
         from importlib import import_module
         _ops = import_module(train.__name__.rsplit(".", 1)[0] + ".ops")
         _ops.MARKS = _ops.Marks(dev)
+    if tr.stamps is not None:                       # every step (eager warm-ups of the captures included) takes a row of stamp slots
+        assert args.steps + args.warmup + 3 * len(batches) + 8 <= tr.stamps.max_steps, "raise KernelStamps(max_steps=) for this many steps"
     t_cap = time.perf_counter()
     tr.precapture([(b["ids"], b["t_x"], b["y"], b["t_y"], b["lh"], b["cond"]) for b in batches])
     torch.cuda.synchronize(dev)
