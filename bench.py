@@ -374,7 +374,7 @@ def main():
                 name = (f"gt_wn_stack_fwd_kernel (a whole WaveNet forward in one launch: {nl} x (k=5 conv 192->384 + gate) + {nl - 1} x "
                         f"residual 1x1, halo recomputed per 52-row tile; {used.numel() / args.steps:.1f} launches per step)")
                 extra, n_l = {}, used.numel()
-                pmc_name = "r03_wn_stack_pmc.json"
+                pmc_name = "r03_decoder_pmc.json"
             else:
                 used = d[:, fam["layer"]]
                 used = used[used > 0]
@@ -399,8 +399,14 @@ def main():
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     pj = json.load(f)
-                roof["traffic"] = pj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = pj.get("source")
+                if "kernels" in pj:                                   # tools/decoder_pmc.py: the decoder's four fused kernels
+                    kj = pj["kernels"].get("wn_stack_fwd", {})
+                    roof["traffic"] = kj.get("hbm_bytes_per_launch")
+                    roof["mfma_busy_fraction"] = kj.get("mfma_busy_fraction_of_wave_lifetime")   # SQ_VALU_MFMA_BUSY_CYCLES / wave lifetime
+                    roof["traffic_source"] = pj.get("source")
+                else:
+                    roof["traffic"] = pj.get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = pj.get("source")
         roof["step"] = {"algorithmic_flops_per_step": flops_step, "achieved": flops_step / (wall / args.steps) / 1e12,
                         "frac": flops_step / (wall / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                         "how": "SURVEY §8d: 3 x forward FLOPs over the valid frames / tokens of the rotated batches, / wall time per step"}
