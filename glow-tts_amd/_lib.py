@@ -26,6 +26,7 @@ PROTOTYPES = {
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_float, c_u32, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gt_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_void_p]),
+    "gt_conv_wgrad_ci_tile": (c_int, [c_int]),
     "gt_conv_wgrad_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "gt_weightnorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_void_p]),
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "gt_rows_add_cond": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_rows_ctx_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gt_step_inputs": (c_int, [c_void_p, c_void_p]),
     "gt_rows_utt_sum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_logp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_prior_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -128,6 +130,26 @@ class PackDesc(ctypes.Structure):
                 ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32), ("taps", ctypes.c_int32), ("Np_fwd", ctypes.c_int32),
                 ("Kp_fwd", ctypes.c_int32), ("Np_dgrad", ctypes.c_int32), ("Kp_dgrad", ctypes.c_int32), ("gate", ctypes.c_int32),
                 ("row_start", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class StepCopy(ctypes.Structure):
+    """struct gt_step_copy (include/glowtts_hip.h)"""
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", ctypes.c_int32), ("src_words", ctypes.c_int32),
+                ("dst_words", ctypes.c_int32), ("blk0", ctypes.c_int32)]
+
+
+class StepCtx(ctypes.Structure):
+    """struct gt_step_ctx (include/glowtts_hip.h)"""
+    _fields_ = [("geo_src", c_void_p), ("geo_dst", c_void_p), ("rowbatch", c_void_p), ("rowframe", c_void_p), ("rowmask", c_void_p),
+                ("rowutt", c_void_p), ("B", ctypes.c_int32), ("R", ctypes.c_int32), ("blk0", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+STEP_MAX_COPIES, STEP_MAX_CTX, STEP_MAX_B = 10, 3, 1024
+
+
+class StepInputsArgs(ctypes.Structure):
+    """struct gt_step_inputs_args (include/glowtts_hip.h)"""
+    _fields_ = [("copy", StepCopy * STEP_MAX_COPIES), ("ctx", StepCtx * STEP_MAX_CTX), ("n_copy", ctypes.c_int32), ("n_ctx", ctypes.c_int32)]
 
 
 class WnStackFwdArgs(ctypes.Structure):

@@ -492,6 +492,55 @@ __global__ __launch_bounds__(256) void gt_rows_ctx_fill_kernel(const int32_t* __
   rowmask[m] = (t >= 0 && t < lens[b]) ? 1.f : 0.f;
 }
 
+// One launch for everything a replayed step needs from its batch: the inputs copied into the graph's padded static buffers (rows of
+// src_words 4-byte words into rows of dst_words >= src_words, the rest zeroed) and the row tables of up to three ragged contexts rebuilt
+// from the row offsets / lengths the host left in pinned memory (read once per workgroup, over PCIe, into LDS).  Was ten launches of
+// 4-6 us each between two graph replays: serial time of every step.
+__global__ __launch_bounds__(256) void gt_step_inputs_kernel(gt_step_inputs_args a)
+{
+  __shared__ int32_t geo[2 * GT_STEP_MAX_B + 1];
+  const int blk = blockIdx.x;
+  for (int j = 0; j < a.n_copy; ++j) {
+    const gt_step_copy c = a.copy[j];
+    const int nb = (int)(((size_t)c.rows * c.dst_words + 1023) / 1024);
+    if (blk >= c.blk0 && blk < c.blk0 + nb) {
+      const uint32_t* __restrict__ src = static_cast<const uint32_t*>(c.src);
+      uint32_t* __restrict__ dst = static_cast<uint32_t*>(c.dst);
+      const size_t total = (size_t)c.rows * c.dst_words;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t w = (size_t)(blk - c.blk0) * 1024 + i * 256 + threadIdx.x;
+        if (w < total) {
+          const int row = (int)(w / c.dst_words), col = (int)(w - (size_t)row * c.dst_words);
+          dst[w] = col < c.src_words ? src[(size_t)row * c.src_words + col] : 0u;
+        }
+      }
+      return;
+    }
+  }
+  for (int j = 0; j < a.n_ctx; ++j) {
+    const gt_step_ctx c = a.ctx[j];
+    const int nb = (c.R + 255) / 256;
+    if (blk >= c.blk0 && blk < c.blk0 + nb) {
+      for (int i = threadIdx.x; i < 2 * c.B + 1; i += 256) {
+        const int32_t v = c.geo_src[i];
+        geo[i] = v;
+        if (blk == c.blk0) c.geo_dst[i] = v;            // the device copy later kernels read (row0[B+1] | lengths[B])
+      }
+      __syncthreads();
+      const int m = (blk - c.blk0) * 256 + threadIdx.x;
+      if (m >= c.R) return;
+      const int b = gt_row_batch(geo, c.B, m, 0);
+      const int t = m - geo[b] - HALO;
+      c.rowbatch[m] = b;
+      if (c.rowutt) c.rowutt[m] = b;
+      c.rowframe[m] = t;
+      c.rowmask[m] = (t >= 0 && t < geo[c.B + 1 + b]) ? 1.f : 0.f;
+      return;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
 // logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
 //               + sum_d -0.5 m_id^2 e^{-2 s_id}
@@ -887,6 +936,28 @@ extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_
 {
   if (!row0 || !lens || !rowbatch || !rowframe || !rowmask || B <= 0 || R <= 0) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_rows_ctx_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, GT_ST(stream), row0, lens, rowbatch, rowframe, rowmask, rowutt, B, R);
+  GT_RET();
+}
+extern "C" int gt_step_inputs(const gt_step_inputs_args* args, void* stream)
+{
+  if (!args || args->n_copy < 0 || args->n_copy > GT_STEP_MAX_COPIES || args->n_ctx < 0 || args->n_ctx > GT_STEP_MAX_CTX) return GT_E_INVAL;
+  gt_step_inputs_args a = *args;
+  int blocks = 0;
+  for (int j = 0; j < a.n_copy; ++j) {
+    gt_step_copy& c = a.copy[j];
+    if (!c.src || !c.dst || c.rows <= 0 || c.src_words < 0 || c.dst_words < c.src_words || c.dst_words <= 0) return GT_E_INVAL;
+    if (((uintptr_t)c.src | (uintptr_t)c.dst) & 3) return GT_E_ALIGN;
+    c.blk0 = blocks;
+    blocks += (int)(((size_t)c.rows * c.dst_words + 1023) / 1024);
+  }
+  for (int j = 0; j < a.n_ctx; ++j) {
+    gt_step_ctx& c = a.ctx[j];
+    if (!c.geo_src || !c.geo_dst || !c.rowbatch || !c.rowframe || !c.rowmask || c.B <= 0 || c.B > GT_STEP_MAX_B || c.R <= 0) return GT_E_INVAL;
+    c.blk0 = blocks;
+    blocks += (c.R + 255) / 256;
+  }
+  if (!blocks) return GT_OK;
+  hipLaunchKernelGGL(gt_step_inputs_kernel, dim3(blocks), dim3(256), 0, GT_ST(stream), a);
   GT_RET();
 }
 extern "C" int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, float* demb,

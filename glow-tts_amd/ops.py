@@ -330,19 +330,36 @@ class RowsCtx:
 
     RING = 8
 
-    def _fill(self, starts, lengths_host):
-        """row0 / lengths (host lists) -> device (ONE non-blocking copy from pinned memory), then row -> utterance, row ->
-        frame, rowmask in ONE launch; all in place, stream-ordered."""
+    def _stage(self, starts, lengths_host):
+        """row0 / lengths (host lists) into the next pinned staging buffer of the ring -> (buffer, its event: to be recorded behind
+        the launch that reads the buffer)."""
         if len(self._ring) < self.RING:
             self._ring.append((torch.empty(2 * self.B + 1, dtype=torch.int32).pin_memory(), torch.cuda.Event()))
             host, ev = self._ring[-1]
         else:
             host, ev = self._ring[self._ring_i % self.RING]
-            ev.synchronize()                                         # the copy that last read this buffer (8 refreshes ago) is done
+            ev.synchronize()                                         # the launch that last read this buffer (8 refreshes ago) is done
         self._ring_i += 1
         hv = host.numpy()
         hv[:self.B + 1] = starts
         hv[self.B + 1:] = [int(v) for v in lengths_host]
+        return host, ev
+
+    def stage_refresh(self, lengths_host):
+        """refresh() in two halves, for a caller that launches gt_step_inputs itself (train.Trainer: the batch's copies and every
+        context in one launch): -> None if the rounded size differs, else (job fields for _lib.StepCtx, pinned buffer, event)."""
+        starts, R = self.row_starts(lengths_host, self.T, self.rnd)
+        if R != self.R or self.B > _lib.STEP_MAX_B:
+            return None
+        host, ev = self._stage(starts, lengths_host)
+        job = dict(geo_src=host.data_ptr(), geo_dst=self._geo.data_ptr(), rowbatch=self.rowbatch.data_ptr(), rowframe=self.rowframe.data_ptr(),
+                   rowmask=self.rowmask.data_ptr(), rowutt=self.rowutt.data_ptr(), B=self.B, R=self.R)
+        return job, host, ev
+
+    def _fill(self, starts, lengths_host):
+        """row0 / lengths (host lists) -> device (ONE non-blocking copy from pinned memory), then row -> utterance, row ->
+        frame, rowmask in ONE launch; all in place, stream-ordered."""
+        host, ev = self._stage(starts, lengths_host)
         self._geo.copy_(host, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.device))
         _lib.check(_lib.lib().gt_rows_ctx_fill(_lib.ptr(self.row0), _lib.ptr(self.lengths), _lib.ptr(self.rowbatch),

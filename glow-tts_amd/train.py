@@ -15,7 +15,7 @@ import contextlib
 import torch
 import torch.distributed as dist
 
-from . import models
+from . import _lib, models
 
 BASE_MODEL = dict(hidden_channels=192, filter_channels=768, filter_channels_dp=256, kernel_size=3, p_dropout=0.1,
                   n_blocks_dec=12, n_layers_enc=6, n_heads=2, p_dropout_dec=0.05, dilation_rate=1, kernel_size_dec=5,
@@ -290,6 +290,48 @@ def _copy_padded(dst, src):
     assert dst.shape[:-1] == src.shape[:-1] and dst.shape[-1] >= T
     dst[..., :T].copy_(src)
     dst[..., T:].zero_()
+
+
+def _upload_step_inputs(pairs, ctx_lens):
+    """The batch into a captured step's static buffers — (dst, src) pairs, dst padded along the last dimension — and its ragged row
+    contexts rebuilt for the batch's lengths: ONE launch (gt_step_inputs) where every tensor took a copy + a fill and every context a
+    host-to-device copy + a launch; whatever does not fit the kernel's form (non-contiguous, odd sizes) goes the old way."""
+    args = _lib.StepInputsArgs()
+    n = 0
+    for dst, src in pairs:
+        if dst.data_ptr() == src.data_ptr():
+            continue
+        ok = (n < _lib.STEP_MAX_COPIES and src.is_cuda and dst.is_cuda and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous()
+              and src.dim() >= 1 and dst.shape[:-1] == src.shape[:-1] and dst.shape[-1] >= src.shape[-1] and src.numel() > 0
+              and (src.shape[-1] * src.element_size()) % 4 == 0 and (dst.shape[-1] * dst.element_size()) % 4 == 0
+              and src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0)
+        if not ok:
+            _copy_padded(dst, src)
+            continue
+        c = args.copy[n]
+        c.src, c.dst = src.data_ptr(), dst.data_ptr()
+        c.rows = src.numel() // src.shape[-1]
+        c.src_words, c.dst_words = src.shape[-1] * src.element_size() // 4, dst.shape[-1] * dst.element_size() // 4
+        n += 1
+    args.n_copy = n
+    staged = []
+    for ctx, lens in ctx_lens:
+        st = ctx.stage_refresh(lens) if len(staged) < _lib.STEP_MAX_CTX else None
+        if st is None:
+            assert ctx.refresh(None, lens), "row count of the batch does not match the captured graph"
+            continue
+        job, host, ev = st
+        c = args.ctx[len(staged)]
+        for k, v in job.items():
+            setattr(c, k, v)
+        staged.append((host, ev))
+    args.n_ctx = len(staged)
+    if n or staged:
+        import ctypes
+        dev = pairs[0][0].device if pairs else ctx_lens[0][0].device
+        _lib.check(_lib.lib().gt_step_inputs(ctypes.byref(args), _lib.current_stream(dev)), "gt_step_inputs")
+        for host, ev in staged:
+            ev.record(torch.cuda.current_stream(dev))
 
 
 def graph_key(lh, ids_shape, y_shape, cond_names=(), ragged=True, row_round=512, pad_tx=16, pad_ty=32, ty_boundaries=None):
@@ -727,14 +769,13 @@ class Trainer:
             return out
         self.n_replays += 1
         graphs, static, out, ctxs = cap
-        for dst, src in list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]:
-            if dst.data_ptr() != src.data_ptr():
-                _copy_padded(dst, src)
+        pairs = list(zip(static[:4], (ids_p, t_x, y_p, t_y))) + [(static[4][k], v) for k, v in cond_p.items()]
+        ctx_lens = []
         if ctxs and "x" in ctxs:                        # per-utterance row offsets / masks of THIS batch (same rounded size)
-            ok = ctxs["x"].refresh(None, lh[0]) and ctxs["y"].refresh(None, [int(v) // 2 for v in lh[1]])
+            ctx_lens = [(ctxs["x"], lh[0]), (ctxs["y"], [int(v) // 2 for v in lh[1]])]
             if "f" in ctxs:
-                ok = ok and ctxs["f"].refresh(None, [int(v) // 2 * 2 for v in lh[1]])
-            assert ok, "row count of the batch does not match the captured graph"
+                ctx_lens.append((ctxs["f"], [int(v) // 2 * 2 for v in lh[1]]))
+        _upload_step_inputs(pairs, ctx_lens)
         graphs[0].replay()                           # collectives sit BETWEEN the graphs, never inside one
         if len(graphs) == 2:
             self.buckets.allreduce()

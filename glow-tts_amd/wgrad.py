@@ -23,12 +23,19 @@ WNB = np.dtype([("part", "u8"), ("part_bias", "u8"), ("v", "u8"), ("g", "u8"), (
                 ("accumulate", "i4"), ("pad0_", "i4"), ("pad1_", "i4")])
 assert JOB.itemsize == 64 and TILE.itemsize == 16 and WNB.itemsize == 96
 
-# rows x taps one workgroup reduces over: bigger = fewer slab partials (HBM traffic), smaller = more workgroups
-ROWTAPS = int(os.environ.get("GT_WGRAD_ROWTAPS", "24576"))
-MAX_SLABS = 8
-FILL_TILES = int(os.environ.get("GT_WGRAD_FILL_TILES", "512"))      # dev knob
-FILL_MAX_SLABS = 32
+# Row slabs per job.  A launch's workgroups (tiles x slabs) run two per CU — SLOTS at a time —, each walks its slab's rows at about
+# ROW_US per row whatever the tap count (operand latency, not MFMA, sets it; measured 0.033 us with both slots of a CU busy), and every
+# slab costs one more copy of dW written here and re-read by the weight-norm backward (PART_BPS).  choose_slabs() takes the cheapest
+# count under that model; it reproduces the measured optima of round 3 (`profiles/r03_wgrad_variants.txt`): 1 slab for the decoder's 432
+# k = 5 tiles (2 slabs: same kernel time, 35 us more partial traffic), 2 for its 180 k = 1 tiles (1: 186 us, 2: 147 us, 3: 160 us).
+SLOTS = 512
+ROW_US = float(os.environ.get("GT_WGRAD_ROW_US", "0.033"))         # dev knobs
+WG_US = 3.0                            # prologue + partial stores of one workgroup
+PART_BPS = 2.0e6                       # bytes of slab partials per microsecond, write + re-read
+MAX_SLABS = 32
 XCDS = 8
+CI_TILE = {5: 64, 3: 64, 1: 192}      # input channels per workgroup tile (conv_wgrad.hip WgSel; checked against the library at flush time)
+FORCE_SLABS = int(os.environ.get("GT_WGRAD_SLABS", "0"))           # dev knob: the same slab count for every job
 
 # ASYNC (process-level dev knob GT_WGRAD_ASYNC=1, read once at import; off by default): flush() launches on a side stream, so the batched weight-gradient kernels of the
 # decoder overlap with whatever the backward does next (the rest of the data-gradient chain, the text encoder's
@@ -105,6 +112,21 @@ def sync_uploads(dev):
             dst.copy_(host, non_blocking=True)
         _PENDING_UPLOADS.clear()
         torch.cuda.current_stream(dev).synchronize()
+
+
+def choose_slabs(base_tiles, R, part_bytes):
+    """Slabs per job for a launch of base_tiles workgroup tiles (at one slab) over jobs of ~R rows whose weight gradients are
+    part_bytes of fp32 in total: the smallest count within 5 % of the cheapest under the cost model above; slabs stay >= 128 rows."""
+    if FORCE_SLABS:
+        return FORCE_SLABS
+    best, costs = None, []
+    for S in range(1, max(1, min(MAX_SLABS, R // 128)) + 1):
+        rounds = -(-base_tiles * S // SLOTS)
+        rows = -(-(-(-R // S)) // 64) * 64
+        cost = rounds * (rows * ROW_US + WG_US) + S * part_bytes / PART_BPS
+        costs.append((cost, S))
+        best = cost if best is None else min(best, cost)
+    return min(S for cost, S in costs if cost <= 1.05 * best)
 
 
 def _side_stream(dev):
@@ -199,17 +221,19 @@ class WgradQueue:
         off = 0
         row = 0
         max_n = 1
-        # slabs: the long jobs (the decoder's) are cut by rows x taps per tile; a launch whose jobs are few and short (the text
-        # encoder's 3 pre-net convs, the duration predictor's 2) would run a dozen workgroups that each walk all the rows — cut those
-        # finer (down to 128-row slabs) until the launch has FILL_TILES tiles
-        base = {5: 0, 3: 0, 1: 0}
+        # slabs: one count per launch (tap count) from choose_slabs() — a launch whose jobs are few and short (the text encoder's 3
+        # pre-net convs, the duration predictor's 2) would otherwise run a dozen workgroups that each walk all the rows
+        base, pbytes, rmax = {5: 0, 3: 0, 1: 0}, {5: 0, 3: 0, 1: 0}, {5: 1, 3: 1, 1: 1}
         for conv, R, parts, dv, dg, db in self.items:
-            base[conv.pc.taps] += sum(-(-cc // 128) * -(-conv.pc.Cin // 64) for _, _, _, cc in parts)
+            t = conv.pc.taps
+            base[t] += sum(-(-cc // 128) * -(-conv.pc.Cin // CI_TILE[t]) for _, _, _, cc in parts)
+            pbytes[t] += t * conv.pc.Cout * conv.pc.Cin * 4
+            rmax[t] = max(rmax[t], R)
+        slabs = {t: choose_slabs(base[t], rmax[t], pbytes[t]) if base[t] else 1 for t in (5, 3, 1)}
         for conv, R, parts, dv, dg, db in self.items:
             pc = conv.pc
             taps, Cin, Cout = pc.taps, pc.Cin, pc.Cout
-            S = min(MAX_SLABS, max(1, round(R * taps / ROWTAPS)))
-            S = max(S, min(FILL_MAX_SLABS, -(-FILL_TILES // max(1, base[taps])), max(1, R // 128)))
+            S = max(1, min(slabs[taps], R // 128 if not FORCE_SLABS else slabs[taps]))
             slab_rows = -(-(-(-R // S)) // 64) * 64
             S = -(-R // slab_rows)
             part_off, off = off, off + S * taps * Cout * Cin * 4
@@ -221,7 +245,7 @@ class WgradQueue:
                 jid = len(jobs)
                 jobs.append((x.data_ptr(), dy.data_ptr(), part_off, pb_off if db is not None else -1, x.stride(0), dy.stride(0),
                              R, Cin, Cout, co_begin, co_count, slab_rows))
-                tiles[taps].append((R * taps, jid, -(-co_count // 128), -(-Cin // 64), S))
+                tiles[taps].append((R * taps, jid, -(-co_count // 128), -(-Cin // CI_TILE[taps]), S))
             v = conv.weight_v if conv.weight_norm else conv.weight
             wnbs.append((part_off, pb_off, v.data_ptr(), conv.weight_g.data_ptr() if dg is not None else 0,
                          pc.inv_norm.data_ptr() if dg is not None else 0, dv.data_ptr(), dg.data_ptr() if dg is not None else 0,
@@ -325,7 +349,7 @@ class WgradQueue:
                     _, jid, nco, nci, S = tiles[taps][i]
                     for sl in range(S):
                         q = min(queues, key=len)
-                        q += [(jid, co * 128, ci * 64, sl) for co in range(nco) for ci in range(nci)]
+                        q += [(jid, co * 128, ci * CI_TILE[taps], sl) for co in range(nco) for ci in range(nci)]
                 flat = [q[pos] for pos in range(max(map(len, queues), default=0)) for q in queues if pos < len(q)]
                 if flat:
                     t = np.zeros(len(flat), dtype=TILE)
@@ -344,6 +368,7 @@ class WgradQueue:
             cache["pkey"], cache["jobs"], cache["wnb"] = pkey, upload(ja), upload(wa)
         counts = cache["counts"]
         st = _lib.current_stream(dev)
+        assert all(L.gt_conv_wgrad_ci_tile(t) == w for t, w in CI_TILE.items()), "wgrad.CI_TILE does not match the library's tile widths"
         _lib.check(L.gt_conv_wgrad_batched(_lib.ptr(cache["jobs"]), _lib.ptr(cache["tiles"]), counts[0], counts[1], counts[2], st),
                    "gt_conv_wgrad_batched")
         _lib.check(L.gt_weightnorm_bwd_batched(_lib.ptr(cache["wnb"]), len(wnbs), rows, max_n, st), "gt_weightnorm_bwd_batched")

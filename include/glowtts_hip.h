@@ -174,6 +174,9 @@ int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_
  * transposing LDS reads.  dW[tap][co][ci] = sum_m dY[m,co] * X[m + tap - k/2, ci].
  * (ATen conv backward-weight in the reference, reached through autograd.) */
 size_t gt_conv_wgrad_workspace_bytes(int R, int Cin, int Cout, int taps, int* slabs_out);
+/* input channels one workgroup tile of the weight-gradient kernel spans at this tap count (64 at k = 3 and 5, 192 at k = 1): the ci0
+ * granularity of gt_wgrad_tile below; 0 for an unsupported tap count. */
+int gt_conv_wgrad_ci_tile(int taps);
 int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, int Cin, int Cout,
                        int taps, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -181,7 +184,7 @@ int gt_conv_wgrad_bf16(const void* X, int ldx, const void* dY, int ldy, int R, i
  * [Cout, Cin, taps] layout: plain conv (g == NULL): dv (+)= dW; weight-normed conv
  * (torch weight_norm dim 0): dg = <dW,v>/||v||, dv = g/||v|| (dW - v <dW,v>/||v||^2).
  * dbias (optional) receives the bias gradient: the wgrad kernel also leaves the column sums of dY
- * per slab in the workspace (one extra MFMA against a ones operand). */
+ * per slab in the workspace (summed from the MFMA A fragments it reads anyway). */
 int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float* g, const float* inv_norm,
                       float* dv, float* dg, float* dbias, int Cout, int Cin, int taps, int accumulate, void* stream);
 
@@ -190,7 +193,7 @@ int gt_weightnorm_bwd(const void* workspace, int R, const float* v, const float*
  * weight-norm backward over all of them.  Tables live in device memory.
  *   job:  dY column c is output channel co_begin + c (co_count columns) of a conv with Cout channels whose
  *         partials are part[S][taps][Cout][Cin] (+ part_bias[S][Cout], may be NULL); slab_rows % 64 == 0.
- *   tile: one workgroup = 128 dY columns from co0 x 64 input channels from ci0 x all taps x rows of `slab`;
+ *   tile: one workgroup = 128 dY columns from co0 x gt_conv_wgrad_ci_tile(taps) input channels from ci0 x all taps x rows of `slab`;
  *         tiles are ordered taps 5, then 3, then 1.
  *   wnb job: as gt_weightnorm_bwd, rows [row_start, row_start + Cout) of the launch. */
 typedef struct gt_wgrad_job {
@@ -307,6 +310,24 @@ int gt_embedding_bwd(const int64_t* ids, const float* dx, const int32_t* lens, f
  * are refreshed per batch). */
 int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_t* rowbatch, int32_t* rowframe, float* rowmask, int32_t* rowutt,
                      int B, int R, void* stream);
+
+/* Everything a replayed training step takes from its batch, in ONE launch (train.Trainer's graph replay; the reference's loop does
+ * `x.cuda(rank, non_blocking=True)` per tensor, train_ms_emo_lang_pitch.py:286-300): up to GT_STEP_MAX_COPIES padded copies — rows of
+ * src_words 4-byte words into rows of dst_words >= src_words words, the tail of every row zeroed — and up to GT_STEP_MAX_CTX ragged row
+ * contexts: geo_src = row0[B+1] | lengths[B] as int32 (device or PINNED HOST memory: read directly by the kernel), copied to geo_dst
+ * and expanded into gt_rows_ctx_fill's tables.  blk0 is filled in by the call. */
+#define GT_STEP_MAX_COPIES 10
+#define GT_STEP_MAX_CTX 3
+#define GT_STEP_MAX_B 1024
+typedef struct gt_step_copy { const void* src; void* dst; int32_t rows, src_words, dst_words, blk0; } gt_step_copy;
+typedef struct gt_step_ctx {
+  const int32_t* geo_src; int32_t* geo_dst; int64_t* rowbatch; int32_t* rowframe; float* rowmask; int32_t* rowutt;
+  int32_t B, R, blk0, pad_;
+} gt_step_ctx;
+typedef struct gt_step_inputs_args {
+  gt_step_copy copy[GT_STEP_MAX_COPIES]; gt_step_ctx ctx[GT_STEP_MAX_CTX]; int32_t n_copy, n_ctx;
+} gt_step_inputs_args;
+int gt_step_inputs(const gt_step_inputs_args* args, void* stream);
 
 /* out[m,:] = (x[m,:] + cond[utterance(m),:]) * rowmask[m]: a per-utterance vector added to every valid row — the
  * speaker conditioning the reference broadcasts over time in attentions.py:66-67 (Encoder.cond_g, before layer index 2)

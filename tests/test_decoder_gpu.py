@@ -63,6 +63,42 @@ def test_wgrad_kernel_vs_torch(built):
         assert relerr(grads[conv.bias], b.grad) < 1e-3
 
 
+def test_wgrad_ring_long_rows_and_ragged_ends(built):
+    """The weight-gradient kernel's operand ring (LDS-DMA stages of 32 rows, conv_wgrad.hip) on inputs long enough to run its steady state:
+    several slabs per job, a row count that is no multiple of the stage (the last stage is the zero-filled register path), channel counts
+    that are no multiple of the 128 x 64 tile (clamped chunks), every tap count; immediate mode and the batched queue (two dY pieces)."""
+    from glow_tts_amd import ops, flow_impl, wgrad
+    from glow_tts_amd.modules import ConvP, WNConvP
+    B, T = 5, 777
+    lens = [777, 640, 333, 100, 9]
+    for (Cin, Cout, k, wn) in [(192, 384, 5, True), (80, 192, 1, True), (192, 160, 1, False), (192, 768, 3, False), (192, 384, 1, True)]:
+        g = torch.Generator().manual_seed(Cin + 7 * k)
+        ctx = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev()), T)
+        m = ctx.rowmask2d[:, ops.HALO:ops.HALO + T].unsqueeze(1)
+        x = (torch.randn(B, Cin, T, generator=g).to(dev()) * m).to(torch.bfloat16)
+        dy = (torch.randn(B, Cout, T, generator=g).to(dev()) * m).to(torch.bfloat16)
+        conv = (WNConvP if wn else ConvP)(Cin, Cout, k).to(dev())
+        conv.prepare()
+        xr, dyr = ctx.to_rows(x), ctx.to_rows(dy)
+        got = [flow_impl.conv_param_grads(conv, xr, dyr, ctx.R)]
+        with wgrad.WgradQueue(dev()):                                          # batched, dY in two column pieces
+            h = Cout // 2
+            got.append(flow_impl.conv_param_grads(conv, xr, None, ctx.R, parts=[(dyr[:, :h], 0, h), (dyr[:, h:], h, Cout - h)]))
+        if wn:
+            v = conv.weight_v.detach().clone().requires_grad_(True); gg = conv.weight_g.detach().clone().requires_grad_(True)
+            w = gg * v / v.reshape(Cout, -1).norm(dim=1).reshape(Cout, 1, 1)
+        else:
+            v = conv.weight.detach().clone().requires_grad_(True); w = v
+        b = conv.bias.detach().clone().requires_grad_(True)
+        F.conv1d(x.float(), w, b, padding=k // 2).backward(dy.float())
+        for grads in got:
+            if wn:
+                assert relerr(grads[conv.weight_v], v.grad) < 1e-2 and relerr(grads[conv.weight_g], gg.grad) < 1e-2, (Cin, Cout, k)
+            else:
+                assert relerr(grads[conv.weight], v.grad) < 1e-2, (Cin, Cout, k)
+            assert relerr(grads[conv.bias], b.grad) < 1e-3, (Cin, Cout, k)
+
+
 def test_actnorm_invconv_fwd_bwd(built):
     from glow_tts_amd import ops, flow_impl
     B, T, C = 2, 40, 160

@@ -462,3 +462,37 @@ def test_actnorm_ddi_survives_the_first_graph_step(built):
             assert an.initialized
             assert (an.logs.detach() - want[b][0]).abs().max().item() < 5e-3, (graph, b)        # two AdamW updates at lr 2e-4 away
             assert (an.bias.detach() - want[b][1]).abs().max().item() < 5e-3, (graph, b)
+
+
+def test_step_inputs_one_launch_matches_copies_and_refreshes(built):
+    """train._upload_step_inputs (gt_step_inputs: the batch into a captured step's padded static buffers + its ragged row contexts, one
+    launch) against the launches it replaces (train._copy_padded per tensor, ops.RowsCtx.refresh per context)."""
+    from glow_tts_amd import ops, train
+    g = torch.Generator().manual_seed(3)
+    B = 7
+    lens_a = [33, 17, 40, 5, 29, 40, 12]
+    lens_b = [31, 23, 38, 9, 25, 36, 14]                 # same rounded row count, different offsets
+    srcs = [torch.randint(0, 99, (B, 37), generator=g).to(dev()), torch.tensor(lens_b).to(dev()),
+            torch.randn(B, 80, 123, generator=g).to(dev()), torch.randn(B, 3, generator=g).to(dev()).to(torch.bfloat16).reshape(B, 3)[:, :2].contiguous()]
+    shapes = [(B, 48), (B,), (B, 80, 160), (B, 4)]
+    want = [torch.full(sh, 7, dtype=t.dtype, device=dev()) for sh, t in zip(shapes, srcs)]
+    got = [w.clone() for w in want]
+    for w, t in zip(want, srcs):
+        train._copy_padded(w, t)
+    ctx_w = [ops.RowsCtx(torch.tensor(lens_a, dtype=torch.int32, device=dev()), 40, lengths_host=lens_a, round_to=64) for _ in range(2)]
+    ctx_g = [ops.RowsCtx(torch.tensor(lens_a, dtype=torch.int32, device=dev()), 40, lengths_host=lens_a, round_to=64) for _ in range(2)]
+    lens2 = [lens_b, [v // 2 * 2 for v in lens_b]]
+    if ops.RowsCtx.row_starts(lens2[1], 40, 64)[1] != ctx_w[1].R:
+        lens2[1] = lens_b
+    for c, l in zip(ctx_w, lens2):
+        assert c.refresh(None, l)
+    train._upload_step_inputs(list(zip(got, srcs)), list(zip(ctx_g, lens2)))
+    torch.cuda.synchronize()
+    for w, o in zip(want, got):
+        assert torch.equal(w, o)
+    for cw, cg in zip(ctx_w, ctx_g):
+        for name in ("row0", "lengths", "rowbatch", "rowframe", "rowmask", "rowutt"):
+            assert torch.equal(getattr(cw, name), getattr(cg, name)), name
+    # a context whose rounded size does not match is refused, as refresh() refuses it
+    with pytest.raises(AssertionError):
+        train._upload_step_inputs([], [(ctx_g[0], [40] * B)])

@@ -54,7 +54,7 @@ for sid, lst in sorted(by_stream.items(), key=lambda kv: -len(kv[1])):
     agg = {}
     for r in lst:
         a = agg.setdefault(r[0][:70], [0, 0]); a[0] += 1; a[1] += r[2] - r[1]
-    for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:10]:
+    for name, (cnt, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"      {tot / 1e6:7.3f} ms {cnt:4d} x {tot / cnt / 1e3:7.1f} us  {name}")
 
 if "--list" in sys.argv:                               # chronological listing of the step: start (us from the step's start), duration, name
