@@ -41,6 +41,12 @@ __device__ __forceinline__ void drop_keep_gate(uint32_t seed, uint32_t row, uint
   keep_t = (hsh & 0xffffu) >= thresh16; keep_s = (hsh >> 16) >= thresh16;
 }
 
+// Workgroup barrier for LDS hazards only.  hipcc's __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: every global
+// load AND store the wave has in flight is drained first — at one wave per SIMD that exposes a full HBM round trip per barrier
+// (weights prefetched for the next phase, saved activations on their way out).  This one waits for the wave's LDS traffic only; the
+// "memory" clobber keeps the compiler from moving LDS accesses across it.  Not for data handed over through global memory.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -32,6 +32,17 @@ constexpr int XR = BM + TAPS - 1;             // 68 input rows
 #ifndef WNS_RING
 #define WNS_RING 3
 #endif
+#ifndef WNS_LDSBAR
+#define WNS_LDSBAR 0                          // 1: barriers wait for LDS traffic only (common.h lds_barrier) instead of __syncthreads()'s
+                                              // vmcnt(0).  Measured (round 3, back to back): backward 86.6 us either way, forward 71.2 vs
+                                              // 67.9 us — the activation stores then sit in front of the next layer's weight loads on
+                                              // the in-order vmcnt counter and stall the conv loop instead of the barrier
+#endif
+#if WNS_LDSBAR
+#define WNS_BARRIER() lds_barrier()
+#else
+#define WNS_BARRIER() __syncthreads()
+#endif
 #ifndef WNS_FIXA
 #define WNS_FIXA 1                            // loads ahead of stores (see the forward kernel)
 #endif
@@ -218,7 +229,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
     }
   }
-  __syncthreads();
+  WNS_BARRIER();
   PH(1);
 
   // per-utterance conditioning: the utterance of this lane's two rows (one binary search each, once per launch)
@@ -351,7 +362,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
         }
       }
     PH(3 + 6 * layer);
-    __syncthreads();                                                   // At, Tl, Sl complete
+    WNS_BARRIER();                                                   // At, Tl, Sl complete
     PH(4 + 6 * layer);
     auto store_gate_tiles = [&]() {
       if (WNS_EXP & 1) return;
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
           *reinterpret_cast<uint2*>(Xn + (t + 2) * AP + n) = v;
         }
     }
-    __syncthreads();                                                   // the next layer's input is complete; Xc and At are free
+    WNS_BARRIER();                                                   // the next layer's input is complete; Xc and At are free
     PH(6 + 6 * layer);
     bf16_t* tmp = Xc; Xc = Xn; Xn = tmp;
     if (!(WNS_EXP & 1)) {                                              // x_next of the owned rows, whole rows from the finished tile
@@ -588,7 +599,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       }
     }
   }
-  __syncthreads();                            // every wave is done with the d pre tile: the exchange buffer may overwrite it
+  WNS_BARRIER();                            // every wave is done with the d pre tile: the exchange buffer may overwrite it
 
   // K halves meet: a wave keeps row block bm == wk and hands the other one to its partner (same columns, other K half)
   {
@@ -598,7 +609,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
 #pragma unroll
       for (int e = 0; e < 16; ++e) mine[(bn * 16 + e) * 64 + lane] = wk ? acc[bn][0][e] : acc[bn][1][e];
   }
-  __syncthreads();
+  WNS_BARRIER();
   f32x16_t sum[3];
   {
     const float* theirs = Ex + (wave ^ 2) * (3 * 16 * 64);
@@ -624,7 +635,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
         *reinterpret_cast<uint2*>(At + t * AP + n) = v;
       }
   }
-  __syncthreads();
+  WNS_BARRIER();
   PH(4 + 8 * (3 - J));
   auto store_dx = [&]() {
     // dX_j of the owned rows leaves as whole rows from the finished tile (the MFMA layout gives a store 16 bytes in each of 32 rows)
@@ -674,7 +685,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
     *reinterpret_cast<uint4*>(Tl + row * AP + c8 * 8) = pre[1][i];
     *reinterpret_cast<uint4*>(Sl + row * AP + c8 * 8) = pre[2][i];
   }
-  __syncthreads();
+  WNS_BARRIER();
   PH(6 + 8 * (3 - J));
   {
     bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
@@ -704,7 +715,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
       }
   }
   PH(7 + 8 * (3 - J));
-  __syncthreads();                                                   // the next conv's input tile is complete
+  WNS_BARRIER();                                                   // the next conv's input tile is complete
   PH(8 + 8 * (3 - J));
   {
     // d pre_{j-1} of the owned rows: whole 768-byte rows from the tile (read-only until the next step's exchange, which follows a barrier)
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
       *reinterpret_cast<uint4*>(Dt + u * DP + H + n) = make_uint4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
     }
   }
-  __syncthreads();
+  WNS_BARRIER();
   PH(1);
   // the chain, top to bottom (workgroup-uniform branches; each step is its own straight-line code)
   if (n_layers > 3) bwd_step<3, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
