@@ -58,6 +58,11 @@ PROTOTYPES = {
     "gt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "gt_layernorm_bwd_partial_rows": (c_int, [c_int]),
+    "gt_layernorm_bwd_partials": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                          c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gt_layernorm_param_reduce": (c_int, [c_void_p, c_void_p]),
     "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -150,6 +155,19 @@ STEP_MAX_COPIES, STEP_MAX_CTX, STEP_MAX_B = 10, 3, 1024
 class StepInputsArgs(ctypes.Structure):
     """struct gt_step_inputs_args (include/glowtts_hip.h)"""
     _fields_ = [("copy", StepCopy * STEP_MAX_COPIES), ("ctx", StepCtx * STEP_MAX_CTX), ("n_copy", ctypes.c_int32), ("n_ctx", ctypes.c_int32)]
+
+
+class LnReduceJob(ctypes.Structure):
+    """struct gt_ln_reduce_job (include/glowtts_hip.h)"""
+    _fields_ = [("partials", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("n_rows", ctypes.c_int32), ("C", ctypes.c_int32)]
+
+
+LN_REDUCE_MAX = 32
+
+
+class LnReduceArgs(ctypes.Structure):
+    """struct gt_ln_reduce_args (include/glowtts_hip.h)"""
+    _fields_ = [("job", LnReduceJob * LN_REDUCE_MAX), ("n_jobs", ctypes.c_int32)]
 
 
 class WnStackFwdArgs(ctypes.Structure):

@@ -77,6 +77,7 @@ struct LnBwdArgs {
   const float* dout_f32; const bf16_t* dout_bf16; int lddo;
   float* da; bf16_t* dy; int lddy;             // gradients wrt a (fp32) and y (bf16, dropout replayed)
   float* dgamma; float* dbeta;                 // accumulated (atomics)
+  float* partials;                             // or: row blockIdx.x of [gridDim.x][2 C] receives this workgroup's sums (no atomics)
   int rows_per_block;
 };
 
@@ -144,8 +145,42 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
 #ifdef LNB_EXP
     if (LNB_EXP & 1) { if (tg == 1.2345f) q.dgamma[c] = tb; return; }
 #endif
-    atomicAdd(q.dgamma + c, tg);
-    atomicAdd(q.dbeta + c, tb);
+    if (q.partials) {
+      q.partials[(size_t)blockIdx.x * 2 * p.C + c] = tg;
+      q.partials[(size_t)blockIdx.x * 2 * p.C + p.C + c] = tb;
+    } else {
+      atomicAdd(q.dgamma + c, tg);
+      atomicAdd(q.dbeta + c, tb);
+    }
+  }
+}
+
+// dgamma / dbeta of up to GT_LN_REDUCE_MAX LayerNorms from the partial rows their backward launches left (gt_layernorm_bwd_partials):
+// one launch at the end of a module's backward instead of 2 C same-address atomics per workgroup in every one of them.
+// block (x: 64-column group of the 2 C columns, y: job); thread = (column, row phase)
+__global__ __launch_bounds__(256) void gt_layernorm_param_reduce_kernel(gt_ln_reduce_args a)
+{
+  __shared__ float red[4][64];
+  const gt_ln_reduce_job j = a.job[blockIdx.y];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  if (blockIdx.x * 64 >= 2 * j.C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * j.C) {
+    const float* pp = j.partials + c;
+    const size_t st = (size_t)2 * j.C;
+    int r = ph;
+    for (; r + 12 < j.n_rows; r += 16) {
+      const float v0 = pp[(size_t)r * st], v1 = pp[(size_t)(r + 4) * st], v2 = pp[(size_t)(r + 8) * st], v3 = pp[(size_t)(r + 12) * st];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; r < j.n_rows; r += 4) s0 += pp[(size_t)r * st];
+  }
+  red[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && c < 2 * j.C) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float* d = c < j.C ? j.dgamma + c : j.dbeta + (c - j.C);
+    *d += t;
   }
 }
 
@@ -807,7 +842,7 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
   if (rc) return rc;
   if ((!dout_f32 && !dout_bf16) || !dgamma || !dbeta) return GT_E_INVAL;
   q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
-  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta;
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = dgamma; q.dbeta = dbeta; q.partials = nullptr;
   // geometry: 16 waves x 32 rows per workgroup (the gamma / beta partials are folded in LDS before the atomics) while
   // that still gives >= 64 workgroups; short inputs fall back to 4 waves x 16 rows so the chip is not left idle
 #ifdef LNB_EXP
@@ -823,6 +858,42 @@ extern "C" int gt_layernorm_bwd(const float* a, const void* y, int ldy, const fl
     q.rows_per_block = 16;
     hipLaunchKernelGGL(gt_layernorm_bwd_kernel<4>, dim3((R + 15) / 16), dim3(256), 0, GT_ST(stream), q);
   }
+  GT_RET();
+}
+
+// The partials form: ONE row per wave (every load of the launch in flight at once: the saved rows are cold by the time the backward
+// reads them), 16 rows per workgroup, the workgroup's dgamma | dbeta sums to row blockIdx.x of `partials` — no atomics, whose
+// same-address chains grow with the number of workgroups.
+extern "C" int gt_layernorm_bwd_partial_rows(int R) { return R > 0 ? (R + 15) / 16 : 0; }
+
+extern "C" int gt_layernorm_bwd_partials(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                                         const float* mean, const float* rstd, int R, int C, float eps,
+                                         float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
+                                         const float* dout_f32, const void* dout_bf16, int lddo,
+                                         float* da, void* dy, int lddy, float* partials, void* stream)
+{
+  LnBwdArgs q;
+  const int rc = fill_ln(q.f, a, y, ldy, gamma, beta, rowmask, nullptr, nullptr, 0, const_cast<float*>(mean), const_cast<float*>(rstd),
+                         R, C, eps, p_in, seed_in, p_out, seed_out, relu, seed_dev);
+  if (rc) return rc;
+  if ((!dout_f32 && !dout_bf16) || !partials) return GT_E_INVAL;
+  q.dout_f32 = dout_f32; q.dout_bf16 = static_cast<const bf16_t*>(dout_bf16); q.lddo = lddo;
+  q.da = da; q.dy = static_cast<bf16_t*>(dy); q.lddy = lddy; q.dgamma = nullptr; q.dbeta = nullptr; q.partials = partials;
+  q.rows_per_block = 16;
+  hipLaunchKernelGGL(gt_layernorm_bwd_kernel<16>, dim3((R + 15) / 16), dim3(1024), 0, GT_ST(stream), q);
+  GT_RET();
+}
+
+extern "C" int gt_layernorm_param_reduce(const gt_ln_reduce_args* args, void* stream)
+{
+  if (!args || args->n_jobs <= 0 || args->n_jobs > GT_LN_REDUCE_MAX) return GT_E_INVAL;
+  int maxc = 0;
+  for (int j = 0; j < args->n_jobs; ++j) {
+    const gt_ln_reduce_job& b = args->job[j];
+    if (!b.partials || !b.dgamma || !b.dbeta || b.n_rows <= 0 || b.C <= 0) return GT_E_INVAL;
+    maxc = b.C > maxc ? b.C : maxc;
+  }
+  hipLaunchKernelGGL(gt_layernorm_param_reduce_kernel, dim3((2 * maxc + 63) / 64, args->n_jobs), dim3(256), 0, GT_ST(stream), *args);
   GT_RET();
 }
 

@@ -47,6 +47,22 @@ def _ln_bwd(rc, ln, saved, dout_f32, dout_bf, want_da, want_dy, grads, relu_in=F
     dy = torch.empty(R, C, dtype=torch.bfloat16, device=dev) if want_dy else None
     dg = grad_accumulator(ln.gamma, (C,))
     db = grad_accumulator(ln.beta, (C,))
+    from . import wgrad
+    q = wgrad.active()
+    if q is not None:
+        # inside a module's backward (an open WgradQueue): per-workgroup partial sums now, ONE reduce launch for all the LayerNorms of
+        # the module when the queue is flushed — instead of 2 C same-address atomics per workgroup in every launch
+        part = torch.empty(L.gt_layernorm_bwd_partial_rows(R), 2 * C, dtype=torch.float32, device=dev)
+        _lib.check(L.gt_layernorm_bwd_partials(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
+                                               _lib.ptr(rc.rowmask), _lib.ptr(mean), _lib.ptr(rstd), R, C, LN_EPS,
+                                               float(p_in), int(seed_in), float(p_out), int(seed_out), int(bool(relu)) | (2 if relu_in else 0),
+                                               _lib.ptr(seed_word(dev)) if (p_in > 0 or p_out > 0) else None,
+                                               _lib.ptr(dout_f32), _lib.ptr(dout_bf), 0 if dout_bf is None else dout_bf.stride(0),
+                                               _lib.ptr(da), _lib.ptr(dy), C, _lib.ptr(part), _st(dev)), "gt_layernorm_bwd_partials")
+        q.add_ln(part, dg, db)
+        grads[ln.gamma] = dg
+        grads[ln.beta] = db
+        return da, dy
     _lib.check(L.gt_layernorm_bwd(_lib.ptr(a), _lib.ptr(y), 0 if y is None else y.stride(0), _lib.ptr(ln.gamma), _lib.ptr(ln.beta),
                                   _lib.ptr(rc.rowmask), _lib.ptr(mean), _lib.ptr(rstd), R, C, LN_EPS,
                                   float(p_in), int(seed_in), float(p_out), int(seed_out), int(bool(relu)) | (2 if relu_in else 0),

@@ -188,6 +188,7 @@ class WgradQueue:
         # even without ASYNC
         self.accumulate, self.force_side = accumulate, side_stream
         self.defer_to = None        # a list: leaving the block parks the queue there instead of flushing (the owner flushes later)
+        self.ln_jobs = []           # (partials, dgamma, dbeta): LayerNorm parameter gradients waiting for their one reduce launch
 
     def __enter__(self):
         _ACTIVE.append(self)
@@ -214,6 +215,25 @@ class WgradQueue:
         if db is not None:
             out[conv.bias] = db
         return out
+
+    def add_ln(self, partials, dgamma, dbeta):
+        """A LayerNorm backward left its per-workgroup dgamma | dbeta sums in `partials` [rows, 2 C] (gt_layernorm_bwd_partials): they
+        are added to dgamma / dbeta by ONE launch for all the LayerNorms of the block (gt_layernorm_param_reduce) when the queue is flushed."""
+        self.ln_jobs.append((partials, dgamma, dbeta))
+        if len(self.ln_jobs) == _lib.LN_REDUCE_MAX:
+            self._flush_ln()
+
+    def _flush_ln(self):
+        if not self.ln_jobs:
+            return
+        import ctypes
+        args = _lib.LnReduceArgs()
+        for i, (part, dg, db) in enumerate(self.ln_jobs):
+            j = args.job[i]
+            j.partials, j.dgamma, j.dbeta, j.n_rows, j.C = part.data_ptr(), dg.data_ptr(), db.data_ptr(), part.shape[0], part.shape[1] // 2
+        args.n_jobs = len(self.ln_jobs)
+        _lib.check(_lib.lib().gt_layernorm_param_reduce(ctypes.byref(args), _lib.current_stream(self.dev)), "gt_layernorm_param_reduce")
+        self.ln_jobs = []
 
     def _plan(self):
         """-> (key, job rows, tile rows, wnb rows, counts, scratch bytes)"""
@@ -255,6 +275,7 @@ class WgradQueue:
         return jobs, tiles, wnbs, row, max_n, off
 
     def flush(self):
+        self._flush_ln()
         if not self.items:
             return
         dev = self.dev

@@ -279,6 +279,19 @@ int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma,
                      float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
                      const float* dout_f32, const void* dout_bf16, int lddo,
                      float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream);
+/* The same backward without atomics: one row per wave, the dgamma | dbeta sums of workgroup w go to row w of partials
+ * [gt_layernorm_bwd_partial_rows(R)][2 C]; gt_layernorm_param_reduce then ADDS the column sums of up to GT_LN_REDUCE_MAX such
+ * buffers to their dgamma / dbeta in one launch (at the end of a module's backward). */
+int gt_layernorm_bwd_partial_rows(int R);
+int gt_layernorm_bwd_partials(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+                              const float* mean, const float* rstd, int R, int C, float eps,
+                              float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
+                              const float* dout_f32, const void* dout_bf16, int lddo,
+                              float* da, void* dy, int lddy, float* partials, void* stream);
+#define GT_LN_REDUCE_MAX 32
+typedef struct gt_ln_reduce_job { const float* partials; float* dgamma; float* dbeta; int32_t n_rows, C; } gt_ln_reduce_job;
+typedef struct gt_ln_reduce_args { gt_ln_reduce_job job[GT_LN_REDUCE_MAX]; int32_t n_jobs; } gt_ln_reduce_args;
+int gt_layernorm_param_reduce(const gt_ln_reduce_args* args, void* stream);
 
 /* Relative-position multi-head self-attention (attentions.py:241-336) in its banded form:
  *   score[i,j] = (q_i.k_j + [|j-i|<=win] q_i.Ek[j-i+win]) / sqrt(D), masked keys/queries -> -1e4,
