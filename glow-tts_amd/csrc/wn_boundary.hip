@@ -36,6 +36,16 @@ constexpr int ZP = C + 4;                     // fp32 tile pitch (floats)
 #define WNB_EXP 0                             // dev experiments (bit mask), 0 in every build that ships
 #endif
 constexpr int RD = 8;                         // weight-fragment ring: k-steps in flight per wave
+#ifndef WNB_LDSBAR
+#define WNB_LDSBAR 0                          // 1: barriers wait for LDS traffic only (common.h lds_barrier) instead of __syncthreads()'s
+                                              // vmcnt(0).  Measured (round 3, back to back): 28.3 vs 28.1 us forward, 28.9 vs 28.7 us backward:
+                                              // the drains are not what the phases wait for
+#endif
+#if WNB_LDSBAR
+#define WNB_BARRIER() lds_barrier()
+#else
+#define WNB_BARRIER() __syncthreads()
+#endif
 #ifndef WNB_PHASES
 #define WNB_PHASES 0                          // dev: per-phase shader-clock stamps of wave 0 (tools/wn_stack_phases.py), 0 in every build that ships
 #endif
@@ -132,7 +142,7 @@ __device__ __forceinline__ void skip_slice(const u32x4_t (&xr)[6], bf16_t* As, c
     const int chunk = threadIdx.x + 256 * i, row = chunk / 24, c8 = chunk - row * 24;
     *reinterpret_cast<u32x4_t*>(As + (L * BM + row) * AP + c8 * 8) = xr[i];
   }
-  __syncthreads();
+  WNB_BARRIER();
   const bf16_t* brow = As + (L * BM + 32 * wm + r) * AP + 8 * h;
   constexpr int CH = 4;
 #pragma unroll
@@ -281,7 +291,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
     skip_slice<1>(xr[1], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<2>(xr[2], As, Wskip, wm, wn, r, h, lane, ring, acc);
     skip_slice<3>(xr[3], As, Wskip, wm, wn, r, h, lane, ring, acc);
-    } else { acc[0][0] = __uint_as_float(xr[0][0].x ^ xr[1][1].x ^ xr[2][2].x ^ xr[3][3].x ^ ring[0][0].x); __syncthreads(); }
+    } else { acc[0][0] = __uint_as_float(xr[0][0].x ^ xr[1][1].x ^ xr[2][2].x ^ xr[3][3].x ^ ring[0][0].x); WNB_BARRIER(); }
     PH(2);
     // the end conv's first weight fragments fly under this epilogue
     WRing<3, H / 16> ring2;
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
                               (acc[bn][4 * g + 2] + b4.z) * rm_l, (acc[bn][4 * g + 3] + b4.w) * rm_l);
         *reinterpret_cast<uint2*>(As + (32 * wm + r) * AP + n) = v;
       }
-    __syncthreads();
+    WNB_BARRIER();
     PH(3);
     if (!(WNB_EXP & 4)) coop_store_rows(wn_out, H, As, m0, R);       // whole rows from the tile (see coop_store_rows)
     // end conv: [m | logs] = wn_out @ Wend^T + b   (N = 160: blocks 0..4, block 5 is the image's zero padding)
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
               make_float4(acc2[bn][4 * g] + b4.x, acc2[bn][4 * g + 1] + b4.y, acc2[bn][4 * g + 2] + b4.z, acc2[bn][4 * g + 3] + b4.w);
         }
       }
-    __syncthreads();
+    WNB_BARRIER();
     PH(5);
     // affine coupling on (row, 4 channels): z = [y0 | (m + exp(logs) y1) mask]
 #pragma unroll
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
         *reinterpret_cast<float4*>(Zt + row * ZP + HALF + c) = z1;
       }
     }
-    __syncthreads();
+    WNB_BARRIER();
     PH(6);
     // (the per-utterance log-det atomics are issued at the very end of the kernel: vector-memory operations retire in order, and a
     // float atomic takes microseconds to come back — issued here, every later wait for a load waited for them too)
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       }
       *reinterpret_cast<float4*>(Zt + row * ZP + c) = v;
     }
-    __syncthreads();
+    WNB_BARRIER();
   }
   if (!HEAD) return;
 
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
       }
     }
   }
-  __syncthreads();
+  WNB_BARRIER();
   PH(8);
   // start conv: h = (y0 @ Wstart^T + b) * mask   (K = 80: 5 k-steps)
   {
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_fwd_kernel(gt_boundary_fwd
             pack4((acc3[bn][4 * g] + b4.x) * rm_l, (acc3[bn][4 * g + 1] + b4.y) * rm_l,
                   (acc3[bn][4 * g + 2] + b4.z) * rm_l, (acc3[bn][4 * g + 3] + b4.w) * rm_l);
       }
-    __syncthreads();
+    WNB_BARRIER();
     PH(10);
     coop_store_rows(h0, H, Hst, m0, R);
   }
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
     }
     WRing<2, H / 16> ring1;
     gemm_prefetch<2, H / 16>(static_cast<const bf16_t*>(a.w_start_d), a.ks_start_d, 2 * wn, lane, ring1);
-    __syncthreads();
+    WNB_BARRIER();
     PH(1);
     f32x16_t acc[2];
     acc_zero<2>(acc);
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
         if (n < HALF)
           *reinterpret_cast<float4*>(Dt + (32 * wm + r) * ZP + n) = make_float4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
       }
-    __syncthreads();
+    WNB_BARRIER();
     PH(2);
     // ActNorm + InvConvNear backward: wave = row phase (rows ph, ph + 4, ..), lane = channel group
     float* sL = reinterpret_cast<float*>(smem + B_RED);
@@ -565,7 +575,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       for (int b = threadIdx.x; b < a.B; b += 256) sv += a.dlogdet[b] * (float)a.len[b];
       sv = wave_sum(sv);
       if (lane == 0) sred[wave] = sv;
-      __syncthreads();
+      WNB_BARRIER();
       sv = sred[0] + sred[1] + sred[2] + sred[3];
       if (a.pg_partial) extra = sv;
       else {
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
 #pragma unroll
       for (int i = 0; i < 16; ++i) sW[ph * 16 + i] = accW[i];
     }
-    __syncthreads();
+    WNB_BARRIER();
     // The workgroup's 336 parameter-gradient atomics (152 workgroups add to the same 336 addresses: they serialise at L2 and take
     // microseconds to retire) are issued at the END of the kernel: vector-memory operations retire in order, so issued here every
     // later wait for a load — the coupling's operands, the next weight fragments — waited for them too (10 k of the launch's 58 k
@@ -670,7 +680,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       }
       *reinterpret_cast<float4*>(Dt + row * ZP + c) = v;
     }
-    __syncthreads();
+    WNB_BARRIER();
   }
 
   // coupling backward on (row, 4 channels): d x = [d z0 | d z1 exp(logs)], d m = d z1, d logs = d z1 exp(logs) y1 + d logdet
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
       *reinterpret_cast<uint2*>(Dout + row * AP + HALF + c) = pl;
     }
   }
-  __syncthreads();
+  WNB_BARRIER();
   PH(5);
   // end conv data gradient: d wn_out = (d out @ Wend) * mask   (K = 160: 10 k-steps)
   bf16_t* At = Dh;                                           // the d h tile is dead
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
         *reinterpret_cast<uint2*>(At + (32 * wm + r) * AP + n) = v;
       }
   }
-  __syncthreads();
+  WNB_BARRIER();
   PH(7);
   coop_store_rows(static_cast<bf16_t*>(a.dwn_out), H, At, m0, R);
   PH(8);
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(256) void gt_wn_boundary_bwd_kernel(gt_boundary_bwd
         const int n = 32 * (3 * wn + bn) + 8 * g + 4 * h;
         *reinterpret_cast<uint2*>(Vst + (32 * wm + r) * AP + n) = pack4(acc[bn][4 * g], acc[bn][4 * g + 1], acc[bn][4 * g + 2], acc[bn][4 * g + 3]);
       }
-    __syncthreads();
+    WNB_BARRIER();
     coop_store_rows(via + l * H, a.ldvs, Vst, m0, R);
     PH(9 + l);
   }

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from glow_tts_amd import _lib, flow_impl, models, modules, ops, wgrad
 
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device("cuda:0")
 L = _lib.lib()
 nb = 12
