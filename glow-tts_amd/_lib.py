@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglowtts_hip.so")
+LIB_PATH = os.environ.get("GT_LIB") or os.path.join(_HERE, "libglowtts_hip.so")     # GT_LIB: dev (an experiment build, tools/exp_variant.py)
 
 c_void_p, c_int, c_i64, c_size_t, c_float, c_u32 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                                     ctypes.c_size_t, ctypes.c_float, ctypes.c_uint32)

@@ -472,7 +472,7 @@ int launch_fwd_long(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, c
 // transposing reads of LDS-staged Q / dO and the B operands straight from the pass-1 buffers.
 constexpr int BTP = 40;            // pitch (halfs) of the transposed band tables [16][32 + pad]
 
-template <int NT, int WV>
+template <int NT, int WV, bool ONE_TILE>
 __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int ld,
     const float* __restrict__ Ek, const float* __restrict__ Ev, const int32_t* __restrict__ lens,
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64 * WV, 1) void gt_attn_bwd_q_mfma_kernel(
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     }
-    if constexpr (NT > 5) {
+    if constexpr (ONE_TILE) {
       // 161 <= T <= 256: holding all NT score tiles of a wave (NT*16 accumulators) next to P and the dropout masks does
       // not fit the register file.  One tile at a time instead: pass A walks the key tiles for Dsum only, pass B
       // RECOMPUTES each tile's dPd^T (6 MFMAs, operands already in LDS / registers), turns it into dS^T, stores it and
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256, 1) void gt_attn_bwd_kv_mfma_kernel(
   }
 }
 
-template <int NT, int WV>
+template <int NT, int WV, bool ONE_TILE = (NT > 5)>
 int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const float* Ek, const float* Ev, const int32_t* lens,
                const bf16_t* dout, int lddo, const float* P, bf16_t* ws, bf16_t* dq, bf16_t* dk, bf16_t* dv, int lddq,
                float* dEk, float* dEv, int B, int T, int Tp, const int32_t* row0, int H, uint32_t th, uint32_t sd, float sc, const uint32_t* seed_dev, hipStream_t st)
@@ -891,12 +891,12 @@ int launch_bwd(const bf16_t* q, const bf16_t* k, const bf16_t* v, int ld, const 
   const size_t lds2 = (size_t)2 * TPAD * VP * 2;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_q_mfma_kernel<NT, WV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_q_mfma_kernel<NT, WV, ONE_TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gt_attn_bwd_kv_mfma_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return GT_E_LAUNCH;
     attr = true;
   }
   if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return 1;
-  hipLaunchKernelGGL((gt_attn_bwd_q_mfma_kernel<NT, WV>), dim3((T + 32 * WV - 1) / (32 * WV), H, B), dim3(64 * WV), lds1, st,
+  hipLaunchKernelGGL((gt_attn_bwd_q_mfma_kernel<NT, WV, ONE_TILE>), dim3((T + 32 * WV - 1) / (32 * WV), H, B), dim3(64 * WV), lds1, st,
                      q, k, v, ld, Ek, Ev, lens, dout, lddo, P, dST, PdT, TI, dq, lddq, dEk, dEv, T, Tp, row0, H, th, sd, sc, seed_dev);
   hipLaunchKernelGGL(gt_attn_bwd_kv_mfma_kernel<NT>, dim3((T + 127) / 128, H, B), dim3(256), lds2, st,
                      q, ld, dout, lddo, dST, PdT, TI, dk, dv, lddq, T, Tp, row0, H);
@@ -924,6 +924,8 @@ int gt_attn_bwd_mfma_impl(const void* q, const void* k, const void* v, int ld, c
   const bf16_t* dd = static_cast<const bf16_t*>(dout);
   bf16_t* w16 = static_cast<bf16_t*>(ws);
   bf16_t* dqq = static_cast<bf16_t*>(dq); bf16_t* dkk = static_cast<bf16_t*>(dk); bf16_t* dvv = static_cast<bf16_t*>(dv);
+  // (T <= 160 through the one-tile-at-a-time form of the longer sequences — <5, 4, true>: 138 registers instead of 362 — measured 66.6 vs
+  //  71.0 us back to back and 13 us of a 4.4 ms step: within the noise, not taken; 5 waves per workgroup, one workgroup per head: 460 us)
   if (T <= 160) return launch_bwd<5, 4>(qq, kk, vv, ld, Ek, Ev, lens, dd, lddo, P, w16, dqq, dkk, dvv, lddq, dEk, dEv, B, T, Tp, row0, H, th, sd, sc, seed_dev, st);
   // 161 <= T <= 256: 8 key tiles, 2 waves per workgroup (153 KB of LDS), one score tile live at a time (recompute form:
   // the first version kept all 8 tiles in registers, needed scratch and faulted — see DESIGN.md §4.5)
