@@ -262,17 +262,40 @@ class FlatAdamW:
         self._host[0], self._host[1] = lr, beta1
         self.hyper[:2].copy_(self._host, non_blocking=True)
 
-    def step(self):
-        from . import _lib, ops
-        L = _lib.lib()
-        dev = self.flat_p.device
+    _early = None            # (lo, hi): floats already updated in this step by step_early()
+
+    def _begin(self):
+        from . import ops
         self.hyper[5:6].add_(1.0)
-        self.gnorm_sq = ops.zeros_small(1, torch.float32, dev)
-        st = _lib.current_stream(dev)
+        self.gnorm_sq = ops.zeros_small(1, torch.float32, self.flat_p.device)
+
+    def _launch(self, s, e):
+        dev = self.flat_p.device
+        _lib.check(_lib.lib().gt_adamw_flat(self.flat_p.data_ptr() + 4 * s, self.gb.flat.data_ptr() + 4 * s, self.m.data_ptr() + 4 * s,
+                                            self.v.data_ptr() + 4 * s, e - s, _lib.ptr(self.hyper), _lib.ptr(self.gnorm_sq),
+                                            _lib.current_stream(dev)), "gt_adamw_flat")
+
+    def step_early(self, lo, hi):
+        """Update floats [lo, hi) NOW, on the current stream, before the rest of the backward has finished: the caller knows that
+        every gradient in the range is final and that every parameter in it has one (train.Trainer: the decoder's conv parameters,
+        90 % of the buffer, right behind the decoder's batched weight gradients — the pass then runs beside the text encoder's last
+        backward launches instead of behind them).  step() later covers what is left."""
+        assert self._early is None and 0 <= lo < hi <= self.gb.total
+        self._begin()
+        self._launch(lo, hi)
+        self._early = (lo, hi)
+
+    def step(self):
+        if self._early is None:
+            self._begin()
+            lo = hi = -1
+        else:
+            lo, hi = self._early
+            self._early = None
         for s, e in self.gb.active_runs():
-            _lib.check(L.gt_adamw_flat(self.flat_p.data_ptr() + 4 * s, self.gb.flat.data_ptr() + 4 * s, self.m.data_ptr() + 4 * s,
-                                       self.v.data_ptr() + 4 * s, e - s, _lib.ptr(self.hyper), _lib.ptr(self.gnorm_sq), st),
-                       "gt_adamw_flat")
+            for a, b in ((s, min(e, lo)), (max(s, hi), e)) if hi > lo else ((s, e),):
+                if b > a:
+                    self._launch(a, b)
         return self.gnorm_sq
 
 
@@ -414,7 +437,7 @@ class Trainer:
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32",
-                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None):
+                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None, early_decoder_adam=True):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
         encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
@@ -423,6 +446,9 @@ class Trainer:
         from collections import OrderedDict
         self.model = model
         self.world = world
+        # early_decoder_adam: without collectives, the optimizer's pass over the decoder's conv parameters starts right behind the
+        # decoder's batched weight gradients (_early_decoder_update) instead of after the whole backward; same numbers either way
+        self.early_decoder_adam = bool(early_decoder_adam)
         self.graph_mode = bool(graph)
         self.split = bool(split_graph)
         accum = []
@@ -517,12 +543,30 @@ class Trainer:
             self.model._prepared_by_trainer = True
         ops.mark("accumulators zeroed")
 
-    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None):
+    def _early_decoder_update(self, params_done):
+        """Called by the decoder's backward right behind its batched weight gradients (wgrad.WgradQueue.flush, site = the decoder): if
+        they covered every parameter of the flat buffer's tail — the decoder's conv weights, gains and biases — the optimizer's pass
+        over that tail starts now, on the decoder's stream, while the text encoder's branch is still in its backward."""
+        done = {id(p) for p in params_done}
+        if all(id(p) in done for p in self.buckets.params[self.dec0:]) and self.dec0_off < self.buckets.total:
+            self.opt.step_early(self.dec0_off, self.buckets.total)
+
+    def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None, early_update=False):
+        """forward + the whole backward; early_update (a full step without collectives, _step_impl): the optimizer's pass over the
+        decoder's parameters is launched from inside the backward (_early_decoder_update) and opt.step() must follow."""
         self._begin(ids.device)
         from . import ops
         loss, l_mle = self._loss(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {})))
         ops.mark("loss")
-        loss.backward()
+        dec = getattr(self.model, "decoder", None)
+        early = early_update and self.early_decoder_adam and dec is not None and not self.buckets.collect and ids.is_cuda
+        if early:                                    # (with collectives the gradients are not final until the all-reduce)
+            object.__setattr__(dec, "_gt_after_flush", self._early_decoder_update)
+        try:
+            loss.backward()
+        finally:
+            if early:
+                object.__setattr__(dec, "_gt_after_flush", None)
         ops.mark("backward joined")
         self.buckets.gather()
         ops.mark("gradients gathered")
@@ -557,7 +601,7 @@ class Trainer:
 
     def _step_impl(self, ids, t_x, y, t_y, lengths_host=None, cond=None, collectives=True):
         if not self.split:
-            out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host, cond)
+            out = self._fwd_bwd(ids, t_x, y, t_y, lengths_host, cond, early_update=True)
             if collectives:
                 self.buckets.allreduce()
         else:

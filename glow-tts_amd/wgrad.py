@@ -189,6 +189,7 @@ class WgradQueue:
         self.accumulate, self.force_side = accumulate, side_stream
         self.defer_to = None        # a list: leaving the block parks the queue there instead of flushing (the owner flushes later)
         self.ln_jobs = []           # (partials, dgamma, dbeta): LayerNorm parameter gradients waiting for their one reduce launch
+        self.params_done = []       # parameters whose gradients this queue's flush completes (handed to the site's _gt_after_flush)
 
     def __enter__(self):
         _ACTIVE.append(self)
@@ -214,6 +215,7 @@ class WgradQueue:
             out[conv.weight_g] = dg
         if db is not None:
             out[conv.bias] = db
+        self.params_done.extend(out.keys())
         return out
 
     def add_ln(self, partials, dgamma, dbeta):
@@ -278,6 +280,13 @@ class WgradQueue:
         self._flush_ln()
         if not self.items:
             return
+        self._flush_convs()
+        cb = getattr(self.site, "_gt_after_flush", None) if self.site is not None else None
+        if cb is not None and not (ASYNC or self.force_side):
+            cb(self.params_done)
+        self.params_done = []
+
+    def _flush_convs(self):
         dev = self.dev
         if (ASYNC or self.force_side) and dev.type == "cuda":
             cur, side = torch.cuda.current_stream(dev), _side_stream(dev)

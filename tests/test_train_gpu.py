@@ -496,3 +496,40 @@ def test_step_inputs_one_launch_matches_copies_and_refreshes(built):
     # a context whose rounded size does not match is refused, as refresh() refuses it
     with pytest.raises(AssertionError):
         train._upload_step_inputs([], [(ctx_g[0], [40] * B)])
+
+
+def test_early_decoder_update_matches_the_single_optimizer_pass(built):
+    """Trainer(early_decoder_adam=True) — the optimizer's pass over the decoder's conv parameters launched right behind the decoder's
+    batched weight gradients, the rest after the backward — ends with the same parameters, moments and gradient norm as the single
+    pass after the backward, eager and graph-replayed; and the early pass really runs (the decoder's flush covers the buffer's tail)."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0)
+    torch.manual_seed(0)
+    m0 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m0.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    outs = {}
+    for early in (False, True):
+        for graph in (False, True):
+            m = train.build_model(cfg, device=dev())
+            m.load_state_dict(m0.state_dict())
+            m.encoder.pre.p_dropout = 0.0
+            tr = train.Trainer(m, graph=graph, capture_after=1, early_decoder_adam=early)
+            calls = []
+            orig = tr.opt.step_early
+            tr.opt.step_early = lambda lo, hi, _o=orig, _c=calls: (_c.append((lo, hi)), _o(lo, hi))[1]
+            for _ in range(3):
+                tr.step(*batch)
+            torch.cuda.synchronize()
+            if not graph:
+                assert calls == ([(tr.dec0_off, tr.buckets.total)] * 3 if early else [])
+            assert tr.adam_steps == 3
+            outs[(early, graph)] = (tr.opt.flat_p.clone(), tr.opt.m.clone(), tr.opt.v.clone(), float(tr.grad_norm))
+    ref = outs[(False, False)]
+    for key, o in outs.items():
+        for a, b in zip(ref[:3], o[:3]):
+            assert (a - b).abs().max().item() < 5e-3, key      # (float atomics order differs from run to run, not the update)
+        assert abs(ref[3] - o[3]) < 2e-2 * abs(ref[3]), key
