@@ -62,7 +62,8 @@ PROTOTYPES = {
     "gt_layernorm_bwd_partials": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                           c_float, c_float, c_u32, c_float, c_u32, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
-    "gt_layernorm_param_reduce": (c_int, [c_void_p, c_void_p]),
+    "gt_param_partials_reduce": (c_int, [c_void_p, c_void_p]),
+    "gt_dds_bwd_partial_rows": (c_int, [c_int]),
     "gt_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_u32, c_void_p, c_void_p]),
     "gt_attn_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -105,10 +106,10 @@ PROTOTYPES = {
     "gt_rows_split3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_dds_sep_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gt_dds_out_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),
-    "gt_dds_out_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),
+    "gt_dds_out_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_u32, c_void_p, c_void_p]),
     "gt_dds_sep_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_int, c_int, c_int, c_float, c_void_p]),
-    "gt_dds_dw_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                               c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "gt_dds_dw_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gt_convflow_pre_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gt_convflow_pre_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_convflow_spline_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
@@ -157,17 +158,18 @@ class StepInputsArgs(ctypes.Structure):
     _fields_ = [("copy", StepCopy * STEP_MAX_COPIES), ("ctx", StepCtx * STEP_MAX_CTX), ("n_copy", ctypes.c_int32), ("n_ctx", ctypes.c_int32)]
 
 
-class LnReduceJob(ctypes.Structure):
-    """struct gt_ln_reduce_job (include/glowtts_hip.h)"""
-    _fields_ = [("partials", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("n_rows", ctypes.c_int32), ("C", ctypes.c_int32)]
+class PartialsJob(ctypes.Structure):
+    """struct gt_partials_job (include/glowtts_hip.h)"""
+    _fields_ = [("partials", c_void_p), ("dst_a", c_void_p), ("dst_b", c_void_p), ("n_rows", ctypes.c_int32), ("Ca", ctypes.c_int32),
+                ("Cb", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
-LN_REDUCE_MAX = 32
+PARTIALS_MAX = 32
 
 
-class LnReduceArgs(ctypes.Structure):
-    """struct gt_ln_reduce_args (include/glowtts_hip.h)"""
-    _fields_ = [("job", LnReduceJob * LN_REDUCE_MAX), ("n_jobs", ctypes.c_int32)]
+class PartialsArgs(ctypes.Structure):
+    """struct gt_partials_args (include/glowtts_hip.h)"""
+    _fields_ = [("job", PartialsJob * PARTIALS_MAX), ("n_jobs", ctypes.c_int32)]
 
 
 class WnStackFwdArgs(ctypes.Structure):

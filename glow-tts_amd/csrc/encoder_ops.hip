@@ -155,19 +155,21 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
   }
 }
 
-// dgamma / dbeta of up to GT_LN_REDUCE_MAX LayerNorms from the partial rows their backward launches left (gt_layernorm_bwd_partials):
-// one launch at the end of a module's backward instead of 2 C same-address atomics per workgroup in every one of them.
-// block (x: 64-column group of the 2 C columns, y: job); thread = (column, row phase)
-__global__ __launch_bounds__(256) void gt_layernorm_param_reduce_kernel(gt_ln_reduce_args a)
+// Parameter gradients from the partial rows backward launches left (gt_layernorm_bwd_partials, gt_dds_*_bwd with `partials`): the
+// column sums of up to GT_PARTIALS_MAX buffers [n_rows][Ca + Cb] are ADDED to dst_a[Ca] | dst_b[Cb] — one launch at the end of a
+// module's backward instead of same-address atomics from every workgroup of every one of them.
+// block (x: 64-column group, y: job); thread = (column, row phase)
+__global__ __launch_bounds__(256) void gt_param_partials_reduce_kernel(gt_partials_args a)
 {
   __shared__ float red[4][64];
-  const gt_ln_reduce_job j = a.job[blockIdx.y];
+  const gt_partials_job j = a.job[blockIdx.y];
+  const int W = j.Ca + j.Cb;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
-  if (blockIdx.x * 64 >= 2 * j.C) return;
+  if (blockIdx.x * 64 >= W) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (c < 2 * j.C) {
+  if (c < W) {
     const float* pp = j.partials + c;
-    const size_t st = (size_t)2 * j.C;
+    const size_t st = (size_t)W;
     int r = ph;
     for (; r + 12 < j.n_rows; r += 16) {
       const float v0 = pp[(size_t)r * st], v1 = pp[(size_t)(r + 4) * st], v2 = pp[(size_t)(r + 8) * st], v3 = pp[(size_t)(r + 12) * st];
@@ -177,9 +179,9 @@ __global__ __launch_bounds__(256) void gt_layernorm_param_reduce_kernel(gt_ln_re
   }
   red[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ph == 0 && c < 2 * j.C) {
+  if (ph == 0 && c < W) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* d = c < j.C ? j.dgamma + c : j.dbeta + (c - j.C);
+    float* d = c < j.Ca ? j.dst_a + c : j.dst_b + (c - j.Ca);
     *d += t;
   }
 }
@@ -884,16 +886,16 @@ extern "C" int gt_layernorm_bwd_partials(const float* a, const void* y, int ldy,
   GT_RET();
 }
 
-extern "C" int gt_layernorm_param_reduce(const gt_ln_reduce_args* args, void* stream)
+extern "C" int gt_param_partials_reduce(const gt_partials_args* args, void* stream)
 {
-  if (!args || args->n_jobs <= 0 || args->n_jobs > GT_LN_REDUCE_MAX) return GT_E_INVAL;
-  int maxc = 0;
+  if (!args || args->n_jobs <= 0 || args->n_jobs > GT_PARTIALS_MAX) return GT_E_INVAL;
+  int maxw = 0;
   for (int j = 0; j < args->n_jobs; ++j) {
-    const gt_ln_reduce_job& b = args->job[j];
-    if (!b.partials || !b.dgamma || !b.dbeta || b.n_rows <= 0 || b.C <= 0) return GT_E_INVAL;
-    maxc = b.C > maxc ? b.C : maxc;
+    const gt_partials_job& b = args->job[j];
+    if (!b.partials || !b.dst_a || b.n_rows <= 0 || b.Ca <= 0 || b.Cb < 0 || (b.Cb > 0 && !b.dst_b)) return GT_E_INVAL;
+    maxw = b.Ca + b.Cb > maxw ? b.Ca + b.Cb : maxw;
   }
-  hipLaunchKernelGGL(gt_layernorm_param_reduce_kernel, dim3((2 * maxc + 63) / 64, args->n_jobs), dim3(256), 0, GT_ST(stream), *args);
+  hipLaunchKernelGGL(gt_param_partials_reduce_kernel, dim3((maxw + 63) / 64, args->n_jobs), dim3(256), 0, GT_ST(stream), *args);
   GT_RET();
 }
 

@@ -36,6 +36,20 @@ __device__ __forceinline__ void wg_fold_add(float* __restrict__ dst, float v, fl
   __syncthreads();
 }
 
+// the same fold; the workgroup's sum goes to its row of a partials buffer (plain store: gt_param_partials_reduce adds the column sums of
+// all rows to the parameter gradients in one launch per module backward) if there is one, else to dst with one atomic
+__device__ __forceinline__ void wg_fold_out(float* __restrict__ dst, float* __restrict__ part, float v, float* sm, int lane, int wave)
+{
+  sm[wave * 64 + lane] = v;
+  __syncthreads();
+  if (wave == 0) {
+    const float s = sm[lane] + sm[64 + lane] + sm[128 + lane] + sm[192 + lane];
+    if (part) *part = s;
+    else if (s != 0.f) atomicAdd(dst, s);
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x)
 {
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256) void gt_dds_out_fwd_kernel(
 __global__ __launch_bounds__(256) void gt_dds_out_bwd_kernel(
     const float* __restrict__ h2, const float* __restrict__ dy, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ rowmask, bf16_t* __restrict__ dh2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    int R, float eps, uint32_t thresh, uint32_t seed, const uint32_t* __restrict__ seed_dev, float scale)
+    float* __restrict__ partials, int R, float eps, uint32_t thresh, uint32_t seed, const uint32_t* __restrict__ seed_dev, float scale)
 {
   if (seed_dev) seed ^= *seed_dev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,7 +214,12 @@ __global__ __launch_bounds__(256) void gt_dds_out_bwd_kernel(
     for (int j = 0; j < NC; ++j) split3_store(dh2 + (size_t)m * 3 * PC, lane + 64 * j, o[j]);
   }
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { wg_fold_add(dgamma + lane + 64 * j, ag[j], fold_sm, lane, wave); wg_fold_add(dbeta + lane + 64 * j, ab[j], fold_sm, lane, wave); }
+  for (int j = 0; j < NC; ++j) {
+    const int c = lane + 64 * j;
+    float* pr = partials ? partials + (size_t)blockIdx.x * 2 * PC : nullptr;            // [gamma | beta]
+    wg_fold_out(dgamma + c, pr ? pr + c : nullptr, ag[j], fold_sm, lane, wave);
+    wg_fold_out(dbeta + c, pr ? pr + PC + c : nullptr, ab[j], fold_sm, lane, wave);
+  }
 }
 
 // backward of the first half, row-local part: d a1 (fp32, from the 1x1 data-gradient GEMM) -> d h1 (gradient at the
@@ -209,7 +228,7 @@ __global__ __launch_bounds__(256) void gt_dds_sep_bwd_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
     const float* __restrict__ gamma, const float* __restrict__ beta, const int32_t* __restrict__ utt,
     const float* __restrict__ rowmask, const float* __restrict__ da1, float* __restrict__ dh1,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int d, float eps)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ partials, int R, int d, float eps)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wk[3][NC], bb[NC], g[NC], be[NC], ag[NC] = {}, ab[NC] = {};
@@ -242,7 +261,12 @@ __global__ __launch_bounds__(256) void gt_dds_sep_bwd_kernel(
     for (int j = 0; j < NC; ++j) dh1[(size_t)m * PC + lane + 64 * j] = o[j];
   }
 #pragma unroll
-  for (int j = 0; j < NC; ++j) { wg_fold_add(dgamma + lane + 64 * j, ag[j], fold_sm, lane, wave); wg_fold_add(dbeta + lane + 64 * j, ab[j], fold_sm, lane, wave); }
+  for (int j = 0; j < NC; ++j) {
+    const int c = lane + 64 * j;
+    float* pr = partials ? partials + (size_t)blockIdx.x * 2 * PC : nullptr;            // [gamma | beta]
+    wg_fold_out(dgamma + c, pr ? pr + c : nullptr, ag[j], fold_sm, lane, wave);
+    wg_fold_out(dbeta + c, pr ? pr + PC + c : nullptr, ab[j], fold_sm, lane, wave);
+  }
 }
 
 // backward of the depthwise conv + the residual: dx = (dy + sum_k w[k] * dh1[m - (k-1)d]) * mask;
@@ -250,7 +274,7 @@ __global__ __launch_bounds__(256) void gt_dds_sep_bwd_kernel(
 __global__ __launch_bounds__(256) void gt_dds_dw_bwd_kernel(
     const float* __restrict__ x, int ldx, const float* __restrict__ dh1, const float* __restrict__ dy,
     const float* __restrict__ w, const int32_t* __restrict__ utt, const float* __restrict__ rowmask,
-    float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int R, int d)
+    float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ partials, int R, int d)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float wk[3][NC], aw[3][NC] = {}, ab[NC] = {};
@@ -291,8 +315,10 @@ __global__ __launch_bounds__(256) void gt_dds_dw_bwd_kernel(
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
     const int c = lane + 64 * j;
-    wg_fold_add(dw + c * 3, aw[0][j], fold_sm, lane, wave); wg_fold_add(dw + c * 3 + 1, aw[1][j], fold_sm, lane, wave);
-    wg_fold_add(dw + c * 3 + 2, aw[2][j], fold_sm, lane, wave); wg_fold_add(db + c, ab[j], fold_sm, lane, wave);
+    float* pr = partials ? partials + (size_t)blockIdx.x * 4 * PC : nullptr;            // [dw[C][3] | db[C]]
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wg_fold_out(dw + c * 3 + k, pr ? pr + c * 3 + k : nullptr, aw[k][j], fold_sm, lane, wave);
+    wg_fold_out(db + c, pr ? pr + 3 * PC + c : nullptr, ab[j], fold_sm, lane, wave);
   }
 }
 
@@ -826,33 +852,34 @@ extern "C" int gt_dds_out_fwd(const float* h2, const float* x, int ldx, const fl
                      static_cast<bf16_t*>(out_bf16), R, eps, th, seed, seed_dev, sc);
   GT_RET();
 }
+extern "C" int gt_dds_bwd_partial_rows(int R) { return R > 0 ? wg_rows_b(R) : 0; }
 extern "C" int gt_dds_out_bwd(const float* h2, const float* dy, const float* gamma, const float* beta, const float* rowmask,
-                              void* dh2_bf16, float* dgamma, float* dbeta, int R, int C, float eps, float drop_p, uint32_t seed,
+                              void* dh2_bf16, float* dgamma, float* dbeta, float* partials, int R, int C, float eps, float drop_p, uint32_t seed,
                               const uint32_t* seed_dev, void* stream)
 {
-  if (!h2 || !dy || !gamma || !beta || !rowmask || !dh2_bf16 || !dgamma || !dbeta || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return GT_E_INVAL;
+  if (!h2 || !dy || !gamma || !beta || !rowmask || !dh2_bf16 || (!partials && (!dgamma || !dbeta)) || R <= 0 || drop_p < 0.f || drop_p >= 1.f) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
   uint32_t th; float sc; fill_drop(drop_p, th, sc);
   hipLaunchKernelGGL(gt_dds_out_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), h2, dy, gamma, beta, rowmask,
-                     static_cast<bf16_t*>(dh2_bf16), dgamma, dbeta, R, eps, th, seed, seed_dev, sc);
+                     static_cast<bf16_t*>(dh2_bf16), dgamma, dbeta, partials, R, eps, th, seed, seed_dev, sc);
   GT_RET();
 }
 extern "C" int gt_dds_sep_bwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
                               const int32_t* utt, const float* rowmask, const float* da1, float* dh1, float* dgamma, float* dbeta,
-                              int R, int C, int dilation, float eps, void* stream)
+                              float* partials, int R, int C, int dilation, float eps, void* stream)
 {
-  if (!x || !w || !b || !gamma || !beta || !utt || !rowmask || !da1 || !dh1 || !dgamma || !dbeta || R <= 0 || dilation <= 0) return GT_E_INVAL;
+  if (!x || !w || !b || !gamma || !beta || !utt || !rowmask || !da1 || !dh1 || (!partials && (!dgamma || !dbeta)) || R <= 0 || dilation <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
   hipLaunchKernelGGL(gt_dds_sep_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), x, ldx, w, b, gamma, beta, utt, rowmask, da1, dh1,
-                     dgamma, dbeta, R, dilation, eps);
+                     dgamma, dbeta, partials, R, dilation, eps);
   GT_RET();
 }
 extern "C" int gt_dds_dw_bwd(const float* x, int ldx, const float* dh1, const float* dy, const float* w, const int32_t* utt,
-                             const float* rowmask, float* dx, float* dw, float* db, int R, int C, int dilation, void* stream)
+                             const float* rowmask, float* dx, float* dw, float* db, float* partials, int R, int C, int dilation, void* stream)
 {
-  if (!x || !dh1 || !dy || !w || !utt || !rowmask || !dx || !dw || !db || R <= 0 || dilation <= 0) return GT_E_INVAL;
+  if (!x || !dh1 || !dy || !w || !utt || !rowmask || !dx || (!partials && (!dw || !db)) || R <= 0 || dilation <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(gt_dds_dw_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), x, ldx, dh1, dy, w, utt, rowmask, dx, dw, db, R, dilation);
+  hipLaunchKernelGGL(gt_dds_dw_bwd_kernel, dim3(wg_rows_b(R)), dim3(256), 0, GT_ST(stream), x, ldx, dh1, dy, w, utt, rowmask, dx, dw, db, partials, R, dilation);
   GT_RET();
 }
 extern "C" int gt_convflow_pre_fwd(const float* z, int ldz, const float* w_pre, const float* b_pre, const float* g1, const float* g2,

@@ -110,14 +110,26 @@ def dds_bwd(rc, dds, saved_all, dy, grads):
     dev = dy.device
     R, C = dy.shape
     utt = rc.row_utt()
+    # inside a module's backward (an open WgradQueue) the three kernels leave their parameter gradients as per-workgroup partial rows
+    # and ONE launch adds them up when the queue is flushed; each of them used to end in 384 - 768 same-address atomics per workgroup
+    # (556 workgroups at cfg 5's 17.8 k frame rows: 32 - 65 us per launch, ~180 of them per step)
+    q = wgrad.active()
+    n_part = L.gt_dds_bwd_partial_rows(R) if q is not None else 0
+
+    def part(width):
+        return torch.empty(n_part, width, dtype=torch.float32, device=dev) if q is not None else None
+
     for i in reversed(range(dds.num_layers)):
         sep, n1, c1, n2 = dds.convs_sep[i], dds.norms_1[i], dds.convs_1x1[i], dds.norms_2[i]
         x, a1, h2 = saved[i]
         dg2, db2 = grad_accumulator(n2.gamma), grad_accumulator(n2.beta)
         dh2 = torch.empty(R, 3 * C, dtype=torch.bfloat16, device=dev)             # bf16x3
+        pt = part(2 * C)
         _lib.check(L.gt_dds_out_bwd(_lib.ptr(h2), _lib.ptr(dy), _lib.ptr(n2.gamma), _lib.ptr(n2.beta), _lib.ptr(rc.rowmask), _lib.ptr(dh2),
-                                    _lib.ptr(dg2), _lib.ptr(db2), R, C, LN_EPS, float(p), int(seed + i),
+                                    _lib.ptr(dg2), _lib.ptr(db2), _lib.ptr(pt), R, C, LN_EPS, float(p), int(seed + i),
                                     _lib.ptr(ops.seed_word(dev)) if p > 0 else None, _st(dev)), "gt_dds_out_bwd")
+        if pt is not None:
+            q.add_ln(pt, dg2, db2)
         grads[n2.gamma], grads[n2.beta] = dg2, db2
         grads.update(conv_param_grads(c1, a1[:, :C], dh2[:, :C], R))               # weight gradient from the hi parts
         da1 = conv_rows(dh2, c1.pc, rc, dgrad=True, out_f32=True)
@@ -125,13 +137,17 @@ def dds_bwd(rc, dds, saved_all, dy, grads):
         dh1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         _lib.check(L.gt_dds_sep_bwd(_lib.ptr(x), x.stride(0), _lib.ptr(sep.weight), _lib.ptr(sep.bias), _lib.ptr(n1.gamma), _lib.ptr(n1.beta),
                                     _lib.ptr(utt), _lib.ptr(rc.rowmask), _lib.ptr(da1), _lib.ptr(dh1), _lib.ptr(dg1), _lib.ptr(db1),
-                                    R, C, dds.kernel_size ** i, LN_EPS, _st(dev)), "gt_dds_sep_bwd")
+                                    _lib.ptr(pt1 := part(2 * C)), R, C, dds.kernel_size ** i, LN_EPS, _st(dev)), "gt_dds_sep_bwd")
+        if pt1 is not None:
+            q.add_ln(pt1, dg1, db1)
         grads[n1.gamma], grads[n1.beta] = dg1, db1
         dw, db = grad_accumulator(sep.weight), grad_accumulator(sep.bias)
         dx = torch.empty(R, C, dtype=torch.float32, device=dev)
         _lib.check(L.gt_dds_dw_bwd(_lib.ptr(x), x.stride(0), _lib.ptr(dh1), _lib.ptr(dy), _lib.ptr(sep.weight), _lib.ptr(utt),
-                                   _lib.ptr(rc.rowmask), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), R, C, dds.kernel_size ** i, _st(dev)),
-                   "gt_dds_dw_bwd")
+                                   _lib.ptr(rc.rowmask), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(pt2 := part(4 * C)), R, C,
+                                   dds.kernel_size ** i, _st(dev)), "gt_dds_dw_bwd")
+        if pt2 is not None:
+            q.add_ln(pt2, dw, db)
         grads[sep.weight], grads[sep.bias] = dw, db
         dy = dx
     return dy

@@ -188,7 +188,7 @@ class WgradQueue:
         # even without ASYNC
         self.accumulate, self.force_side = accumulate, side_stream
         self.defer_to = None        # a list: leaving the block parks the queue there instead of flushing (the owner flushes later)
-        self.ln_jobs = []           # (partials, dgamma, dbeta): LayerNorm parameter gradients waiting for their one reduce launch
+        self.ln_jobs = []           # (partials, dst_a, dst_b): parameter gradients left as per-workgroup partial rows, waiting for their one reduce launch
         self.params_done = []       # parameters whose gradients this queue's flush completes (handed to the site's _gt_after_flush)
 
     def __enter__(self):
@@ -218,23 +218,25 @@ class WgradQueue:
         self.params_done.extend(out.keys())
         return out
 
-    def add_ln(self, partials, dgamma, dbeta):
-        """A LayerNorm backward left its per-workgroup dgamma | dbeta sums in `partials` [rows, 2 C] (gt_layernorm_bwd_partials): they
-        are added to dgamma / dbeta by ONE launch for all the LayerNorms of the block (gt_layernorm_param_reduce) when the queue is flushed."""
-        self.ln_jobs.append((partials, dgamma, dbeta))
-        if len(self.ln_jobs) == _lib.LN_REDUCE_MAX:
+    def add_ln(self, partials, dst_a, dst_b):
+        """A backward kernel left its per-workgroup parameter-gradient sums in `partials` [rows, dst_a.numel() + dst_b.numel()]
+        (gt_layernorm_bwd_partials: dgamma | dbeta; the DDSConv backward kernels: the same, and dw | db): they are added to dst_a / dst_b
+        by ONE launch for all such buffers of the block (gt_param_partials_reduce) when the queue is flushed."""
+        assert partials.shape[1] == dst_a.numel() + dst_b.numel()
+        self.ln_jobs.append((partials, dst_a, dst_b))
+        if len(self.ln_jobs) == _lib.PARTIALS_MAX:
             self._flush_ln()
 
     def _flush_ln(self):
         if not self.ln_jobs:
             return
         import ctypes
-        args = _lib.LnReduceArgs()
-        for i, (part, dg, db) in enumerate(self.ln_jobs):
+        args = _lib.PartialsArgs()
+        for i, (part, da, db) in enumerate(self.ln_jobs):
             j = args.job[i]
-            j.partials, j.dgamma, j.dbeta, j.n_rows, j.C = part.data_ptr(), dg.data_ptr(), db.data_ptr(), part.shape[0], part.shape[1] // 2
+            j.partials, j.dst_a, j.dst_b, j.n_rows, j.Ca, j.Cb = part.data_ptr(), da.data_ptr(), db.data_ptr(), part.shape[0], da.numel(), db.numel()
         args.n_jobs = len(self.ln_jobs)
-        _lib.check(_lib.lib().gt_layernorm_param_reduce(ctypes.byref(args), _lib.current_stream(self.dev)), "gt_layernorm_param_reduce")
+        _lib.check(_lib.lib().gt_param_partials_reduce(ctypes.byref(args), _lib.current_stream(self.dev)), "gt_param_partials_reduce")
         self.ln_jobs = []
 
     def _plan(self):

@@ -280,18 +280,18 @@ int gt_layernorm_bwd(const float* a, const void* y, int ldy, const float* gamma,
                      const float* dout_f32, const void* dout_bf16, int lddo,
                      float* da, void* dy, int lddy, float* dgamma, float* dbeta, void* stream);
 /* The same backward without atomics: one row per wave, the dgamma | dbeta sums of workgroup w go to row w of partials
- * [gt_layernorm_bwd_partial_rows(R)][2 C]; gt_layernorm_param_reduce then ADDS the column sums of up to GT_LN_REDUCE_MAX such
- * buffers to their dgamma / dbeta in one launch (at the end of a module's backward). */
+ * [gt_layernorm_bwd_partial_rows(R)][2 C]; gt_param_partials_reduce then ADDS the column sums of up to GT_PARTIALS_MAX such
+ * buffers [n_rows][Ca + Cb] to their destinations dst_a[Ca] / dst_b[Cb] in one launch (at the end of a module's backward). */
 int gt_layernorm_bwd_partial_rows(int R);
 int gt_layernorm_bwd_partials(const float* a, const void* y, int ldy, const float* gamma, const float* beta, const float* rowmask,
                               const float* mean, const float* rstd, int R, int C, float eps,
                               float p_in, uint32_t seed_in, float p_out, uint32_t seed_out, int relu, const uint32_t* seed_dev,
                               const float* dout_f32, const void* dout_bf16, int lddo,
                               float* da, void* dy, int lddy, float* partials, void* stream);
-#define GT_LN_REDUCE_MAX 32
-typedef struct gt_ln_reduce_job { const float* partials; float* dgamma; float* dbeta; int32_t n_rows, C; } gt_ln_reduce_job;
-typedef struct gt_ln_reduce_args { gt_ln_reduce_job job[GT_LN_REDUCE_MAX]; int32_t n_jobs; } gt_ln_reduce_args;
-int gt_layernorm_param_reduce(const gt_ln_reduce_args* args, void* stream);
+#define GT_PARTIALS_MAX 32
+typedef struct gt_partials_job { const float* partials; float* dst_a; float* dst_b; int32_t n_rows, Ca, Cb, pad_; } gt_partials_job;
+typedef struct gt_partials_args { gt_partials_job job[GT_PARTIALS_MAX]; int32_t n_jobs; } gt_partials_args;
+int gt_param_partials_reduce(const gt_partials_args* args, void* stream);
 
 /* Relative-position multi-head self-attention (attentions.py:241-336) in its banded form:
  *   score[i,j] = (q_i.k_j + [|j-i|<=win] q_i.Ek[j-i+win]) / sqrt(D), masked keys/queries -> -1e4,
@@ -589,14 +589,18 @@ int gt_dds_sep_fwd(const float* x, int ldx, const float* w, const float* b, cons
                    const int32_t* utt, const float* rowmask, void* a1_bf16, int lda, int R, int C, int dilation, float eps, void* stream);
 int gt_dds_out_fwd(const float* h2, const float* x, int ldx, const float* gamma, const float* beta, const float* rowmask,
                    float* out, void* out_bf16, int R, int C, float eps, float drop_p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+/* The three backward kernels accumulate their parameter gradients with one atomic per address and workgroup — or, with `partials`
+ * (then the gradient pointers may be NULL), store the workgroup's sums to row w of partials [gt_dds_bwd_partial_rows(R)][W], W = 2 C
+ * (gamma | beta) for out / sep, 4 C (dw[C][3] | db[C]) for dw; gt_param_partials_reduce adds the column sums later. */
+int gt_dds_bwd_partial_rows(int R);
 int gt_dds_out_bwd(const float* h2, const float* dy, const float* gamma, const float* beta, const float* rowmask,
-                   void* dh2_bf16, float* dgamma, float* dbeta, int R, int C, float eps, float drop_p, uint32_t seed,
+                   void* dh2_bf16, float* dgamma, float* dbeta, float* partials, int R, int C, float eps, float drop_p, uint32_t seed,
                    const uint32_t* seed_dev, void* stream);
 int gt_dds_sep_bwd(const float* x, int ldx, const float* w, const float* b, const float* gamma, const float* beta,
                    const int32_t* utt, const float* rowmask, const float* da1, float* dh1, float* dgamma, float* dbeta,
-                   int R, int C, int dilation, float eps, void* stream);
+                   float* partials, int R, int C, int dilation, float eps, void* stream);
 int gt_dds_dw_bwd(const float* x, int ldx, const float* dh1, const float* dy, const float* w, const int32_t* utt,
-                  const float* rowmask, float* dx, float* dw, float* db, int R, int C, int dilation, void* stream);
+                  const float* rowmask, float* dx, float* dw, float* db, float* partials, int R, int C, int dilation, void* stream);
 
 /* ConvFlow (modules.py:792-819), in_channels = 2, on z rows [R, 2]:
  *   gt_convflow_pre_fwd:    x0 = (w_pre * z[:,0] + b_pre + g1 (+ g2)) * mask          (pre + DDSConv's `x = x + g`)

@@ -112,10 +112,22 @@ def test_dds_dropout_replays_in_backward(built):
     dh = torch.empty(R_, 3 * C, dtype=torch.bfloat16, device=dev())
     dg, db = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
     _lib.check(L.gt_dds_out_bwd(_lib.ptr(h2), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mask), _lib.ptr(dh), _lib.ptr(dg), _lib.ptr(db),
-                                R_, C, 1e-5, p, seed, None, st), "gt_dds_out_bwd")
+                                None, R_, C, 1e-5, p, seed, None, st), "gt_dds_out_bwd")
     got = dh[:, :C].float() + dh[:, 2 * C:].float()                   # bf16x3 layout: hi + lo
     assert torch.equal(dh[:, :C], dh[:, C:2 * C])
     assert relerr(got, hh.grad) < 1e-4, relerr(got, hh.grad)
+    # the partials form (per-workgroup rows, summed by gt_param_partials_reduce) gives the same parameter gradients as the atomics
+    import ctypes
+    part = torch.empty(L.gt_dds_bwd_partial_rows(R_), 2 * C, device=dev())
+    _lib.check(L.gt_dds_out_bwd(_lib.ptr(h2), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mask), _lib.ptr(dh), None, None,
+                                _lib.ptr(part), R_, C, 1e-5, p, seed, None, st), "gt_dds_out_bwd")
+    dg2, db2 = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    args = _lib.PartialsArgs()
+    j = args.job[0]
+    j.partials, j.dst_a, j.dst_b, j.n_rows, j.Ca, j.Cb = part.data_ptr(), dg2.data_ptr(), db2.data_ptr(), part.shape[0], C, C
+    args.n_jobs = 1
+    _lib.check(L.gt_param_partials_reduce(ctypes.byref(args), st), "gt_param_partials_reduce")
+    assert relerr(dg2, dg) < 1e-5 and relerr(db2, db) < 1e-5
 
 
 @pytest.mark.parametrize("which", ["sdp", "spp", "sep"])
