@@ -21,7 +21,10 @@ namespace {
 constexpr int PC = 192;                       // channels of every predictor network (filter_channels = in_channels, models.py:223)
 constexpr int NC = PC / 64;                   // channels per lane
 constexpr int RPW = 8;                        // rows per wave per workgroup (forward kernels)
-constexpr int RPB = 8;                        // ... of the backward kernels that also accumulate parameter gradients
+#ifndef DDS_RPB
+#define DDS_RPB 4                             // (cfg 5 step: 18.05 ms at 8 rows per wave, 17.51 at 4, 17.54 at 2)
+#endif
+constexpr int RPB = DDS_RPB;                  // ... of the backward kernels that also accumulate parameter gradients
 
 // parameter-gradient partial of this lane -> ONE atomic per address per workgroup: the four waves' values are folded in LDS
 // first (same-address float atomics serialise at L2, ~25-50 ns each; with one per wave they were most of these kernels)
