@@ -394,7 +394,7 @@ def main():
                          "how": "device-side begin / end stamps (wall_clock64, 100 MHz) written by every launch of the kernel inside the "
                                 "replayed HIP graphs of the timed steps: max(end) - min(start) per launch, mean over "
                                 f"{n_l} launches; FLOPs count the VALID squeezed frames only (the recomputed halo rows are not counted)",
-                         "profile": "profiles/r03_trainstep_*_summary.txt (rocprofv3 --kernel-trace --stats of the same command)"})
+                         "profile": "profiles/r03_v3_trainstep_summary.txt (rocprofv3 --kernel-trace --stats of the same command)"})
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc):
                 with open(pmc) as f:
