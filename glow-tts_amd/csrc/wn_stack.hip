@@ -47,6 +47,12 @@ constexpr int XR = BM + TAPS - 1;             // 68 input rows
 #define WNS_FIXA 1                            // loads ahead of stores (see the forward kernel)
 #endif
 constexpr int RING = WNS_RING;
+#ifndef WNS_RING1
+#define WNS_RING1 WNS_RING                    // weight ring depths of the 32-row form (NBM = 1).  Its spare accumulator registers could pay for
+#endif                                        // deeper rings; measured at 5 120 rows (round 3): forward 56.6 / 58.4 / 58.4 us at depth 4 / 5 / 3,
+#ifndef WNS_RB1                               // backward 73.7 / 68.2 us at depth 9 / 5 — what the 256 workgroups wait for is the L2 itself
+#define WNS_RB1 (2 * WNS_RING - 1)            // (each streams all 3.2 MB of weights: 0.8 GB per launch), not a ring step's round trip
+#endif
 #ifndef WNS_PHASES
 #define WNS_PHASES 0                          // dev: per-phase shader-clock stamps of wave 0 (tools/wn_stack_phases.py), 0 in every build that ships
 #endif
@@ -109,9 +115,15 @@ __device__ __forceinline__ T pick(T const (&arr)[NLMAX], int i)        // scalar
 // w[c] * contour[t] + b[c] — squeezed in time (modules.py:353-362): squeezed row m, column parity * O + c (O = H n) holds
 // w[c] * contour[2 m + parity] + b[c], and layer i reads columns [2H i, 2H (i+1)).  Materialised, that is 6 KB of fp32 per row written
 // by a host-side op and read back here; formed from the row's two contour values and the 2 x O parameters it is 8 bytes per row.
-template <int COND, bool DROP>
+// NBM: 32-row blocks computed per layer — 2 (64-row tiles, 52 owned with 4 layers) or 1 (32-row tiles, 20 owned) for launches whose
+// 64-row tiles would leave most of the chip idle (cfg 4 / cfg 5's 4-5 k rows: 90 workgroups on 256 CUs): 2.6 x the workgroups, each
+// with half the MFMA rows but the same weight stream.  The LDS layout is the 64-row one either way; every row's arithmetic (K order,
+// dropout hash, epilogue) is the same, so the results are bit-identical between the two forms.
+template <int COND, bool DROP, int NBM>
 __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_args a, uint32_t drop_thresh, float drop_scale)
 {
+  constexpr int BMv = 32 * NBM, XRv = BMv + TAPS - 1;
+  constexpr int RINGv = NBM == 1 ? WNS_RING1 : RING;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // bench.py's live timing: workgroup 0's start (the first dispatched) is kept in a register and stored at the end, every workgroup's
   // end goes into one atomicMax AFTER its last wait — an atomicMin here, 188 workgroups on one address, sat in front of every
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
   const int r = lane & 31, h = lane >> 5;
   const int n_layers = a.n_layers, R = a.R;
   const int halo = 2 * (n_layers - 1);                               // rows lost per side: 6 for 4 layers
-  const int own = BM - 2 * halo;                                     // rows this workgroup owns: 52
+  const int own = BMv - 2 * halo;                                    // rows this workgroup owns: 52 (NBM = 2) or 20
   const int s0 = blockIdx.x * own - halo;                            // global row of tile row 0
   bf16_t* Xc = reinterpret_cast<bf16_t*>(smem);
   bf16_t* Xn = Xc + XR * AP;
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
   // Vector-memory operations retire IN ORDER on one counter (vmcnt): a wait for a weight fragment also waits for every store issued
   // before that load.  So the loads a layer needs first are issued BEFORE the stores that precede their use: the next layer's first
   // ring steps ahead of the T / S / acts / x_next stores, and layer 0's here, ahead of (and overlapping) the input tile's loads.
-  uint4 ring[RING][4][3];
+  uint4 ring[RINGv][4][3];
   float rm2;
   // Fragment addresses are left to the compiler: it forms the layer's per-lane offsets once, outside the layer loop, and every load
   // is then ONE instruction with an immediate offset.  Measured against scalar bases formed next to each load (`pinned`, as the
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     return ldfrag(W, (tap * NBT + 3 * wave + bn) * KS + kg * 4 + ks, lane);
   };
   auto w_load_l = [&](const bf16_t* W, int it, uint4 (&dst)[4][3]) {
-    if ((WNS_EXP & 2) && it > RING) return;
+    if ((WNS_EXP & 2) && it > RINGv) return;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     for (int i = 0; i < NX; ++i) {
       const int chunk = threadIdx.x + 256 * i, u = chunk / CPR, c8 = chunk - u * CPR, gm = s0 - 2 + u;
       xin[i] = make_uint4(0, 0, 0, 0);
-      if (u < XR && gm >= 0 && gm < R) xin[i] = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
+      if (u < XRv && gm >= 0 && gm < R) xin[i] = *reinterpret_cast<const uint4*>(x0 + (size_t)gm * H + c8 * 8);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -204,13 +216,13 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     {
       const bf16_t* W10 = static_cast<const bf16_t*>(a.w_in[0]);
 #pragma unroll
-      for (int p = 0; p < RING - 1; ++p) w_load_l(W10, p, ring[p]);
+      for (int p = 0; p < RINGv - 1; ++p) w_load_l(W10, p, ring[p]);
     }
 #endif
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int chunk = threadIdx.x + 256 * i, u = chunk / CPR, c8 = chunk - u * CPR;
-      if (u < XR) *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = xin[i];
+      if (u < XRv) *reinterpret_cast<uint4*>(Xc + u * AP + c8 * 8) = xin[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       }
     }
     if (threadIdx.x < 4 * 24) {                                       // the next tile's rows 0, 1, 66, 67 are never produced
-      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
+      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XRv - 4 + q;
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
     }
   }
@@ -233,18 +245,18 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
   PH(1);
 
   // per-utterance conditioning: the utterance of this lane's two rows (one binary search each, once per launch)
-  int cb[2] = {0, 0};
-  float sg[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                          // COND == 2: the two contour values (even / odd frame) of this lane's two rows
+  int cb[NBM] = {};
+  float sg[NBM][2] = {};                          // COND == 2: the two contour values (even / odd frame) of this lane's two rows
   if (COND == 1) {
 #pragma unroll
-    for (int bm = 0; bm < 2; ++bm) {
+    for (int bm = 0; bm < NBM; ++bm) {
       const int m = s0 + 32 * bm + r, mc = m < 0 ? 0 : (m >= R ? R - 1 : m);
       cb[bm] = a.B > 0 ? gt_row_batch(a.row0, a.B, mc, a.Tp) : mc;
     }
   }
   if (COND == 2) {
 #pragma unroll
-    for (int bm = 0; bm < 2; ++bm) {
+    for (int bm = 0; bm < NBM; ++bm) {
       const int m = s0 + 32 * bm + r;
       if (m >= 0 && m < R) { const float2 v = *reinterpret_cast<const float2*>(a.aff_sig + 2 * (size_t)m); sg[bm][0] = v.x; sg[bm][1] = v.y; }
     }
@@ -261,34 +273,35 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     bf16_t* xo = static_cast<bf16_t*>(pick(a.x_out, layer));
     const uint32_t seed = (a.drop_seed + (uint32_t)layer) ^ seed_x;
 
-    f32x16_t acc[3][2];
+    f32x16_t acc[3][NBM];
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-      for (int bm = 0; bm < 2; ++bm)
+      for (int bm = 0; bm < NBM; ++bm)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
 
     auto w_load = [&](int it, uint4 (&dst)[4][3]) { w_load_l(W1, it, dst); };
 #if !WNS_FIXA
 #pragma unroll
-    for (int p = 0; p < RING - 1; ++p) w_load(p, ring[p]);
+    for (int p = 0; p < RINGv - 1; ++p) w_load(p, ring[p]);
 #endif
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int kg = it / TAPS, tap = it - kg * TAPS;
-      w_load(it + RING - 1 < NIT ? it + RING - 1 : NIT - 1, ring[(it + RING - 1) % RING]);
-      __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RING - 1 steps ahead
+      w_load(it + RINGv - 1 < NIT ? it + RINGv - 1 : NIT - 1, ring[(it + RINGv - 1) % RINGv]);
+      __builtin_amdgcn_sched_barrier(0);       // keep the prefetch RINGv - 1 steps ahead
       const bf16_t* xsb = Xc + (r + tap) * AP + 8 * h + kg * 64;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + ks * 16);
-        const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * AP + ks * 16);
+        bf16x8_t bx[NBM];
 #pragma unroll
-        for (int bn = 0; bn < 3; ++bn) {
-          acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b0, acc[bn][0], 0, 0, 0);
-          acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RING][ks][bn]), b1, acc[bn][1], 0, 0, 0);
-        }
+        for (int bm = 0; bm < NBM; ++bm) bx[bm] = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * bm * AP + ks * 16);
+#pragma unroll
+        for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+          for (int bm = 0; bm < NBM; ++bm)
+            acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RINGv][ks][bn]), bx[bm], acc[bn][bm], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -301,9 +314,10 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     const int r_e = tid_e & 31, h_e = (tid_e >> 5) & 1, wave_e = tid_e >> 6;
     // second-stage weights start flying now, under the gate epilogue
     const int wn2 = wave & 1, wm2 = wave >> 1;
+    const bool st2 = wm2 < NBM;                // the residual stage's 2 x 2 waves are (row block, column half): NBM = 1 leaves two of them out
     constexpr int R2 = KK2 / 2;
     uint4 ring2[R2][3];
-    if (!last) {
+    if (!last && st2) {
 #pragma unroll
       for (int kk = 0; kk < R2; ++kk)
 #pragma unroll
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
         const float4 bt = *reinterpret_cast<const float4*>(bias1 + c), bs = *reinterpret_cast<const float4*>(bias1 + H + c);
         const float btv[4] = {bt.x, bt.y, bt.z, bt.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
-        for (int bm = 0; bm < 2; ++bm) {
+        for (int bm = 0; bm < NBM; ++bm) {
           const int t = 32 * bm + r_e, m = s0 + t;
           float ctv[4] = {}, csv[4] = {};
           if (COND == 1) {
@@ -402,7 +416,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
-    {
+    if (st2) {
       const bf16_t* ab = At + (32 * wm2 + r) * AP + 8 * h;
 #pragma unroll
       for (int kk = 0; kk < KK2; ++kk) {
@@ -419,11 +433,11 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
     {                                          // the next layer's first ring steps, ahead of the x_next stores
       const bf16_t* W1n = static_cast<const bf16_t*>(pick(a.w_in, layer + 1));
 #pragma unroll
-      for (int p = 0; p < RING - 1; ++p) w_load_l(W1n, p, ring[p]);
+      for (int p = 0; p < RINGv - 1; ++p) w_load_l(W1n, p, ring[p]);
     }
     store_gate_tiles();                        // T, S, acts: the tiles are untouched until the next layer's epilogue
 #endif
-    {
+    if (st2) {
       const int t = 32 * wm2 + r;
       const float rm = rm2;
 #pragma unroll
@@ -461,7 +475,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_fwd_kernel(gt_wn_stack_fwd_ar
       }
     }
     if (threadIdx.x < 4 * 24) {                                        // rows 0, 1, 66, 67 of the tile after next
-      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XR - 4 + q;
+      const int q = threadIdx.x / 24, c8 = threadIdx.x - q * 24, u = q < 2 ? q : XRv - 4 + q;
       *reinterpret_cast<uint4*>(Xn + u * AP + c8 * 8) = make_uint4(0, 0, 0, 0);
     }
     PH(7 + 6 * layer);
@@ -522,49 +536,55 @@ __device__ __forceinline__ void bwd_w_load(const bf16_t* W1, int it, int wn, int
 }
 // the first RB - 1 steps: issued by the PREVIOUS step (or the kernel's head) ahead of its stores — vmcnt retires in order, so a
 // wait for these fragments would otherwise also wait for every store issued before them (see the forward kernel)
-__device__ __forceinline__ void bwd_ring_prologue(const void* w, int lane, uint4 (&ring)[RB][2][3])
+template <int RBv>
+__device__ __forceinline__ void bwd_ring_prologue(const void* w, int lane, uint4 (&ring)[RBv][2][3])
 {
   const int wave = wave_scalar(), wn = wave & 1, wk = wave >> 1;
   const bf16_t* W1 = pinned(static_cast<const bf16_t*>(w));
 #pragma unroll
-  for (int p = 0; p < RB - 1; ++p) bwd_w_load(W1, p, wn, wk, lane, ring[p]);
+  for (int p = 0; p < RBv - 1; ++p) bwd_w_load(W1, p, wn, wk, lane, ring[p]);
 }
 
 // one step j of the chain (compile-time j: every pointer is a kernel argument, every fragment address is formed where it is used)
-template <int J, bool COND, bool DROP>
+template <int J, bool COND, bool DROP, int NBM>
 __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t drop_thresh, float drop_scale, uint32_t seed_x,
-                                         bf16_t* Dt, float* Ex, bf16_t* At, int s0, int halo, int lane, int wave, uint4 (&ring)[RB][2][3], float rm)
+                                         bf16_t* Dt, float* Ex, bf16_t* At, int s0, int halo, int lane, int wave,
+                                         uint4 (&ring)[NBM == 1 ? WNS_RB1 : RB][2][3], float rm)
 {
   const int r = lane & 31, h = lane >> 5;
   wave = wave_scalar();
   const int wn = wave & 1, wk = wave >> 1;     // stage 1: column half, K half;  afterwards wk doubles as the row half
+  constexpr int BMv = 32 * NBM;                // rows of the tile (NBM: see the forward kernel)
+  constexpr int RBv = NBM == 1 ? WNS_RB1 : RB;
+  const bool act = wk < NBM;                   // NBM = 1: one row block — the waves of K half 1 hand their sums over and sit the rest out
   const int n_layers = a.n_layers, R = a.R;
   const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
   constexpr int NIT = B_NIT;
   const bf16_t* W1 = pinned(static_cast<const bf16_t*>(a.w_in_d[J]));
-  f32x16_t acc[3][2];
+  f32x16_t acc[3][NBM];
 #pragma unroll
   for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-    for (int bm = 0; bm < 2; ++bm)
+    for (int bm = 0; bm < NBM; ++bm)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[bn][bm][e] = 0.0f;
   auto w_load = [&](int it, uint4 (&dst)[2][3]) { bwd_w_load(W1, it, wn, wk, lane, dst); };
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int slice = it / TAPS, tap = it - slice * TAPS;
-    w_load(it + RB - 1 < NIT ? it + RB - 1 : NIT - 1, ring[(it + RB - 1) % RB]);
+    w_load(it + RBv - 1 < NIT ? it + RBv - 1 : NIT - 1, ring[(it + RBv - 1) % RBv]);
     __builtin_amdgcn_sched_barrier(0);
     const bf16_t* xsb = Dt + (r + tap) * DP + 8 * h + slice * 64 + 32 * wk;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-      const bf16x8_t b0 = *reinterpret_cast<const bf16x8_t*>(xsb + k2 * 16);
-      const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * DP + k2 * 16);
+      bf16x8_t bx[NBM];
 #pragma unroll
-      for (int bn = 0; bn < 3; ++bn) {
-        acc[bn][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b0, acc[bn][0], 0, 0, 0);
-        acc[bn][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RB][k2][bn]), b1, acc[bn][1], 0, 0, 0);
-      }
+      for (int bm = 0; bm < NBM; ++bm) bx[bm] = *reinterpret_cast<const bf16x8_t*>(xsb + 32 * bm * DP + k2 * 16);
+#pragma unroll
+      for (int bn = 0; bn < 3; ++bn)
+#pragma unroll
+        for (int bm = 0; bm < NBM; ++bm)
+          acc[bn][bm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(asfrag(ring[it % RBv][k2][bn]), bx[bm], acc[bn][bm], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -573,7 +593,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   constexpr int JL = J > 0 ? J - 1 : 0;
   const bf16_t* W2 = pinned(static_cast<const bf16_t*>(a.w_res_d[JL]));
   uint4 ring2[KK2][3];                         // all of them now: reloaded inside the 36-MFMA loop they arrived after it needed them
-  if (J > 0) {
+  if (J > 0 && act) {
 #pragma unroll
     for (int kk = 0; kk < KK2; ++kk)
 #pragma unroll
@@ -592,7 +612,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
     for (int i = 0; i < NPRE; ++i) {
       const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR, mm = s0 + row;
       pre[0][i] = pre[1][i] = pre[2][i] = make_uint4(0, 0, 0, 0);
-      if (mm >= 0 && mm < R) {
+      if (row < BMv && mm >= 0 && mm < R) {
         pre[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)mm * a.ldvs + JLp * H + c8 * 8);
         pre[1][i] = *reinterpret_cast<const uint4*>(Tg + (size_t)mm * H + c8 * 8);
         pre[2][i] = *reinterpret_cast<const uint4*>(Sg + (size_t)mm * H + c8 * 8);
@@ -602,27 +622,27 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   WNS_BARRIER();                            // every wave is done with the d pre tile: the exchange buffer may overwrite it
 
   // K halves meet: a wave keeps row block bm == wk and hands the other one to its partner (same columns, other K half)
-  {
+  if (NBM == 2 || wk) {
     float* mine = Ex + wave * (3 * 16 * 64);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mine[(bn * 16 + e) * 64 + lane] = wk ? acc[bn][0][e] : acc[bn][1][e];
+      for (int e = 0; e < 16; ++e) mine[(bn * 16 + e) * 64 + lane] = (NBM == 2 && !wk) ? acc[bn][NBM - 1][e] : acc[bn][0][e];
   }
   WNS_BARRIER();
   f32x16_t sum[3];
-  {
+  if (act) {
     const float* theirs = Ex + (wave ^ 2) * (3 * 16 * 64);
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) sum[bn][e] = (wk ? acc[bn][1][e] : acc[bn][0][e]) + theirs[(bn * 16 + e) * 64 + lane];
+      for (int e = 0; e < 16; ++e) sum[bn][e] = ((NBM == 2 && wk) ? acc[bn][NBM - 1][e] : acc[bn][0][e]) + theirs[(bn * 16 + e) * 64 + lane];
   }
   PH(3 + 8 * (3 - J));
   // dX_j = (conv^T(d pre_j) + dX_{j+1}) * mask -> HBM (owned rows) and the stage-2 tile (which still holds dX_{j+1})
   const int t = 32 * wk + r, m = s0 + t;
-  const bool mine_row = t >= halo && t < BM - halo && m < R;
-  {
+  const bool mine_row = act && t >= halo && t < BMv - halo && m < R;
+  if (act) {
 #pragma unroll
     for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
@@ -640,7 +660,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   auto store_dx = [&]() {
     // dX_j of the owned rows leaves as whole rows from the finished tile (the MFMA layout gives a store 16 bytes in each of 32 rows)
     bf16_t* dx = static_cast<bf16_t*>(a.dx[J]);
-    const int own = BM - 2 * halo;
+    const int own = BMv - 2 * halo;
     constexpr int NC = (BM * CPR + 255) / 256;
     uint4 vx[NC];
 #pragma unroll
@@ -664,7 +684,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   for (int bn = 0; bn < 3; ++bn)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[bn][e] = 0.0f;
-  {
+  if (act) {
     const bf16_t* ab = At + (32 * wk + r) * AP + 8 * h;
 #pragma unroll
     for (int kk = 0; kk < KK2; ++kk) {
@@ -681,13 +701,14 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
 #pragma unroll
   for (int i = 0; i < NPRE; ++i) {
     const int idx = threadIdx.x + 256 * i, row = idx / CPR, c8 = idx - row * CPR;
+    if (row >= BMv) continue;
     *reinterpret_cast<uint4*>(Vl + row * AP + c8 * 8) = pre[0][i];
     *reinterpret_cast<uint4*>(Tl + row * AP + c8 * 8) = pre[1][i];
     *reinterpret_cast<uint4*>(Sl + row * AP + c8 * 8) = pre[2][i];
   }
   WNS_BARRIER();
   PH(6 + 8 * (3 - J));
-  {
+  if (act) {
     bf16_t* dpre_c = static_cast<bf16_t*>(a.dpre_c[JL]);
     const uint32_t seed = (a.drop_seed + (uint32_t)JL) ^ seed_x;
     const bool in = m >= 0 && m < R;
@@ -720,7 +741,7 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   {
     // d pre_{j-1} of the owned rows: whole 768-byte rows from the tile (read-only until the next step's exchange, which follows a barrier)
     bf16_t* dpre = static_cast<bf16_t*>(a.dpre[JL]);
-    const int own = BM - 2 * halo;
+    const int own = BMv - 2 * halo;
     constexpr int CPR2 = 2 * H / 8, NC = (BM * CPR2 + 255) / 256, NP = 4;      // 12 chunks per thread, in passes of NP
 #pragma unroll
     for (int i0 = 0; i0 < NC; i0 += NP) {
@@ -741,21 +762,23 @@ __device__ __forceinline__ void bwd_step(const gt_wn_stack_bwd_args& a, uint32_t
   PH(9 + 8 * (3 - J));
 }
 
-template <bool COND, bool DROP>
+template <bool COND, bool DROP, int NBM>
 __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_args a, uint32_t drop_thresh, float drop_scale)
 {
+  constexpr int BMv = 32 * NBM, XRv = BMv + TAPS - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   PH(0);
   const uint32_t seed_x = a.seed_dev ? *a.seed_dev : 0u;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_layers = a.n_layers, R = a.R;
-  const int halo = 2 * (n_layers - 1), own = BM - 2 * halo;
+  const int halo = 2 * (n_layers - 1), own = BMv - 2 * halo;
   const int s0 = blockIdx.x * own - halo;
   bf16_t* Dt = reinterpret_cast<bf16_t*>(smem);
   float* Ex = reinterpret_cast<float*>(smem);
   bf16_t* At = reinterpret_cast<bf16_t*>(smem + BWD_DT);
   const bf16_t* via = static_cast<const bf16_t*>(a.via_skip);
-  uint4 ring[RB][2][3];
+  constexpr int RBv = NBM == 1 ? WNS_RB1 : RB;
+  uint4 ring[RBv][2][3];
   bwd_ring_prologue(pick(a.w_in_d, n_layers - 1), lane, ring);      // ahead of the head's d pre stores
   float rm;                                                         // the row mask of the row this lane finishes in every dX epilogue
   {
@@ -779,7 +802,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
     for (int i = 0; i < NH; ++i) {
       const int idx = threadIdx.x + 256 * i, u = idx / CPR, c8 = idx - u * CPR, m = s0 - 2 + u;
       hv[0][i] = hv[1][i] = hv[2][i] = make_uint4(0, 0, 0, 0);
-      if (u < XR && m >= 0 && m < R) {
+      if (u < XRv && m >= 0 && m < R) {
         hv[0][i] = *reinterpret_cast<const uint4*>(via + (size_t)m * a.ldvs + L * H + c8 * 8);
         hv[1][i] = *reinterpret_cast<const uint4*>(Tt + (size_t)m * H + c8 * 8);
         hv[2][i] = *reinterpret_cast<const uint4*>(Ss + (size_t)m * H + c8 * 8);
@@ -788,7 +811,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int idx = threadIdx.x + 256 * i, u = idx / CPR, c8 = idx - u * CPR, m = s0 - 2 + u, n = c8 * 8;
-      if (u >= XR) continue;
+      if (u >= XRv) continue;
       uint2 pt[2], ps[2], ct[2], cs[2];
       pt[0] = pt[1] = ps[0] = ps[1] = ct[0] = ct[1] = cs[0] = cs[1] = make_uint2(0, 0);
       if (m >= 0 && m < R) {
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
           unpack4(q ? make_uint2(hv[2][i].z, hv[2][i].w) : make_uint2(hv[2][i].x, hv[2][i].y), sg);
           gate_bwd4<DROP>(dd, t, sg, seed, m, n + 4 * q, drop_thresh, drop_scale, pt[q], ps[q], ct[q], cs[q]);
         }
-        if (u - 2 >= halo && u - 2 < BM - halo) {
+        if (u - 2 >= halo && u - 2 < BMv - halo) {
           *reinterpret_cast<uint4*>(dpre + (size_t)m * 2 * H + n) = make_uint4(pt[0].x, pt[0].y, pt[1].x, pt[1].y);
           *reinterpret_cast<uint4*>(dpre + (size_t)m * 2 * H + H + n) = make_uint4(ps[0].x, ps[0].y, ps[1].x, ps[1].y);
           if (COND) {
@@ -816,10 +839,10 @@ __global__ __launch_bounds__(256) void gt_wn_stack_bwd_kernel(gt_wn_stack_bwd_ar
   WNS_BARRIER();
   PH(1);
   // the chain, top to bottom (workgroup-uniform branches; each step is its own straight-line code)
-  if (n_layers > 3) bwd_step<3, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
-  if (n_layers > 2) bwd_step<2, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
-  if (n_layers > 1) bwd_step<1, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
-  bwd_step<0, COND, DROP>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  if (n_layers > 3) bwd_step<3, COND, DROP, NBM>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  if (n_layers > 2) bwd_step<2, COND, DROP, NBM>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  if (n_layers > 1) bwd_step<1, COND, DROP, NBM>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
+  bwd_step<0, COND, DROP, NBM>(a, drop_thresh, drop_scale, seed_x, Dt, Ex, At, s0, halo, lane, wave, ring, rm);
   PH(40);
 }
 
@@ -834,6 +857,18 @@ extern "C" int gt_dev_wns_phases(void* dst, size_t bytes)
 }
 #endif
 
+#ifndef WNS_SMALL_TILE_MAX_WGS
+#define WNS_SMALL_TILE_MAX_WGS 80             // 64-row tiles give at most this many workgroups -> 32-row tiles (needs n_layers <= 4: 20 owned rows)
+#endif
+// 32-row blocks per tile for a launch over R rows: 2, or 1 when the 64-row tiling would leave two thirds of the 256 CUs idle.  Measured
+// back to back (tools/wn_layer_bench.py stack, WN_BENCH_TY=..., round 3; forward / backward us per launch, 64-row -> 32-row tiles):
+// 3 072 rows 61.7 / 71.4 -> 51.2 / 59.3;  3 584 rows 62.0 / 72.9 -> 51.7 / 61.0;  5 120 rows 63.2 / 75.6 -> 57.1 / 68.2 (and nothing left
+// of it inside the cfg 4 / cfg 5 steps, whose other branch then finds no free CU: the threshold stays below that);  9 728 rows: 2 rounds.
+static int stack_row_blocks(int R, int n_layers)
+{
+  const int own2 = BM - 4 * (n_layers - 1), own1 = 32 - 4 * (n_layers - 1);
+  return (own1 >= 8 && (R + own2 - 1) / own2 <= WNS_SMALL_TILE_MAX_WGS) ? 1 : 2;
+}
 extern "C" int gt_wn_stack_rows_per_workgroup(int n_layers) { return BM - 4 * (n_layers - 1); }
 
 extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
@@ -863,20 +898,23 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
     thresh = (uint32_t)((double)a.drop_p * 4294967296.0); scale = 1.0f / (1.0f - a.drop_p);
   }
   typedef void (*kern_t)(gt_wn_stack_fwd_args, uint32_t, float);
-  static const kern_t kerns[6] = {gt_wn_stack_fwd_kernel<0, false>, gt_wn_stack_fwd_kernel<0, true>, gt_wn_stack_fwd_kernel<1, false>,
-                                  gt_wn_stack_fwd_kernel<1, true>, gt_wn_stack_fwd_kernel<2, false>, gt_wn_stack_fwd_kernel<2, true>};
+  static const kern_t kerns[12] = {gt_wn_stack_fwd_kernel<0, false, 2>, gt_wn_stack_fwd_kernel<0, true, 2>, gt_wn_stack_fwd_kernel<1, false, 2>,
+                                   gt_wn_stack_fwd_kernel<1, true, 2>, gt_wn_stack_fwd_kernel<2, false, 2>, gt_wn_stack_fwd_kernel<2, true, 2>,
+                                   gt_wn_stack_fwd_kernel<0, false, 1>, gt_wn_stack_fwd_kernel<0, true, 1>, gt_wn_stack_fwd_kernel<1, false, 1>,
+                                   gt_wn_stack_fwd_kernel<1, true, 1>, gt_wn_stack_fwd_kernel<2, false, 1>, gt_wn_stack_fwd_kernel<2, true, 1>};
   static bool attr = false;                    // > 64 KB of LDS: opt in once per process
   if (!attr) {
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 12; ++i)
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              i >= 4 ? STACK_FWD_LDS_AFF : STACK_FWD_LDS) != hipSuccess)
+                              (i % 6) >= 4 ? STACK_FWD_LDS_AFF : STACK_FWD_LDS) != hipSuccess)
         return GT_E_LAUNCH;
     attr = true;
   }
-  const int own = BM - 4 * (a.n_layers - 1);
+  const int nbm = stack_row_blocks(a.R, a.n_layers);
+  const int own = 32 * nbm - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
   const int mode = affine ? 2 : (a.cond ? 1 : 0);
-  hipLaunchKernelGGL(kerns[2 * mode + (thresh ? 1 : 0)], grid, block, affine ? STACK_FWD_LDS_AFF : STACK_FWD_LDS,
+  hipLaunchKernelGGL(kerns[(nbm == 1 ? 6 : 0) + 2 * mode + (thresh ? 1 : 0)], grid, block, affine ? STACK_FWD_LDS_AFF : STACK_FWD_LDS,
                      static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }
@@ -905,8 +943,10 @@ extern "C" int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream)
   for (int i = 0; i < a.n_layers; ++i) cond = cond || a.dpre_c[i];
   for (int i = 0; i < a.n_layers; ++i) if (cond && !a.dpre_c[i]) return GT_E_INVAL;
   typedef void (*kern_t)(gt_wn_stack_bwd_args, uint32_t, float);
-  static const kern_t kerns[4] = {gt_wn_stack_bwd_kernel<false, false>, gt_wn_stack_bwd_kernel<false, true>,
-                                  gt_wn_stack_bwd_kernel<true, false>, gt_wn_stack_bwd_kernel<true, true>};
+  static const kern_t kerns[8] = {gt_wn_stack_bwd_kernel<false, false, 2>, gt_wn_stack_bwd_kernel<false, true, 2>,
+                                  gt_wn_stack_bwd_kernel<true, false, 2>, gt_wn_stack_bwd_kernel<true, true, 2>,
+                                  gt_wn_stack_bwd_kernel<false, false, 1>, gt_wn_stack_bwd_kernel<false, true, 1>,
+                                  gt_wn_stack_bwd_kernel<true, false, 1>, gt_wn_stack_bwd_kernel<true, true, 1>};
   static bool attr = false;
   if (!attr) {
     for (kern_t k : kerns)
@@ -914,8 +954,9 @@ extern "C" int gt_wn_stack_bwd(const gt_wn_stack_bwd_args* args, void* stream)
         return GT_E_LAUNCH;
     attr = true;
   }
-  const int own = BM - 4 * (a.n_layers - 1);
+  const int nbm = stack_row_blocks(a.R, a.n_layers);
+  const int own = 32 * nbm - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
-  hipLaunchKernelGGL(kerns[(cond ? 2 : 0) + (thresh ? 1 : 0)], grid, block, SBWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
+  hipLaunchKernelGGL(kerns[(nbm == 1 ? 4 : 0) + (cond ? 2 : 0) + (thresh ? 1 : 0)], grid, block, SBWD_LDS, static_cast<hipStream_t>(stream), a, thresh, scale);
   return gt_launch_status(__func__);
 }

@@ -15,9 +15,10 @@ wns = [modules.WN(160, H, 5, 1, n, 0, 0.05).to(dev) for _ in range(12)]
 for w in wns:
     modules.prepare_all(w)
 g = torch.Generator().manual_seed(1234)
-t_y = (torch.randint(150, 401, (32,), generator=g) * 2); t_y[0] = 800
+TY = int(os.environ.get("WN_BENCH_TY", "800"))      # longest utterance in mel frames (800: cfg 2; 400: cfg 5's row count)
+t_y = (torch.randint(TY * 3 // 16, TY // 2 + 1, (32,), generator=g) * 2); t_y[0] = TY
 lens = [int(v) // 2 for v in t_y]
-rc = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev), 400, lengths_host=lens, round_to=512)
+rc = ops.RowsCtx(torch.tensor(lens, dtype=torch.int32, device=dev), TY // 2, lengths_host=lens, round_to=512)
 R = rc.R
 x = (torch.randn(R, H, device=dev) * rc.rowmask[:, None]).to(torch.bfloat16)
 acts = torch.empty(R, n * H, dtype=torch.bfloat16, device=dev)
