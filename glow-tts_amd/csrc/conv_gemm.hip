@@ -365,6 +365,9 @@ __device__ __forceinline__ size_t pk_index(bool frag, int t, int nrow, int k, in
 #define PK_THREADS 256
 #endif
 constexpr int PK_RPW = 8 / (PK_THREADS / 64);       // rows per wave
+constexpr int PK8_SMALLN = 1024;                    // the row length the small form holds: 16 KB of LDS and 32 row registers instead of
+                                                    // 36 KB and 72, twice the resident workgroups (the decoder's convs: 960; 90 % of the step's weights)
+template <int MAXN>
 __device__ __forceinline__ void pack_rows8(
     const float* __restrict__ v, const float* __restrict__ g, bf16_t* __restrict__ Pf, bf16_t* __restrict__ Pd,
     float* __restrict__ inv_norm, int co0, int Cout, int Cin, int taps, int Npf, int Kpf, int Npd, int Kpd, int gate,
@@ -375,13 +378,13 @@ __device__ __forceinline__ void pack_rows8(
   // wave w: rows 2w, 2w+1, each held in registers (<= 9 float4 per lane) from ONE batch of loads that are all in flight
   // together — a load / accumulate loop per row left the launch bound by ~30 dependent HBM latencies per workgroup
   // (171 us for the 28 M weights of the step; the bytes alone are ~40 us)
-  float4 x[PK_RPW][PK8_MAXN / 256];
+  float4 x[PK_RPW][MAXN / 256];
   const bool al = ((reinterpret_cast<uintptr_t>(v) | ((size_t)n * 4)) & 15) == 0;
 #pragma unroll
   for (int k = 0; k < PK_RPW; ++k) {
     const float* vr = v + (size_t)(co0 + PK_RPW * w + k) * n;
 #pragma unroll
-    for (int j = 0; j < PK8_MAXN / 256; ++j) {
+    for (int j = 0; j < MAXN / 256; ++j) {
       const int i = lane + 64 * j;
       x[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifdef PK_EXP
@@ -400,14 +403,14 @@ __device__ __forceinline__ void pack_rows8(
     if (g) {
       float ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < PK8_MAXN / 256; ++j) ss += x[k][j].x * x[k][j].x + x[k][j].y * x[k][j].y + x[k][j].z * x[k][j].z + x[k][j].w * x[k][j].w;
+      for (int j = 0; j < MAXN / 256; ++j) ss += x[k][j].x * x[k][j].x + x[k][j].y * x[k][j].y + x[k][j].z * x[k][j].z + x[k][j].w * x[k][j].w;
       ss = wave_sum(ss);
       const float inv = 1.0f / sqrtf(ss);
       if (lane == 0 && inv_norm) inv_norm[co] = inv;
       sc = g[co] * inv;
     }
 #pragma unroll
-    for (int j = 0; j < PK8_MAXN / 256; ++j) {
+    for (int j = 0; j < MAXN / 256; ++j) {
       const int i = lane + 64 * j;
       if (i < n4)
         *reinterpret_cast<uint2*>(tile + rr * n + 4 * i) =
@@ -450,9 +453,10 @@ __device__ __forceinline__ void pack_rows8(
   }
 }
 
+template <int MAXN>
 __global__ __launch_bounds__(PK_THREADS) void gt_pack_conv_weights_multi8_kernel(const gt_pack_desc* __restrict__ descs, int n)
 {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[8 * PK8_MAXN];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[8 * MAXN];
   __shared__ float scl[8];
   __shared__ int sel;
   const int row = blockIdx.x * 8;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(PK_THREADS) void gt_pack_conv_weights_multi8_kernel
   for (int i = threadIdx.x; i < n; i += PK_THREADS) if (descs[i].row_start <= row) atomicMax(&sel, i);
   __syncthreads();
   const gt_pack_desc d = descs[sel];
-  pack_rows8(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, row - d.row_start,
+  pack_rows8<MAXN>(d.v, d.g, static_cast<bf16_t*>(d.pack_fwd), static_cast<bf16_t*>(d.pack_dgrad), d.inv_norm, row - d.row_start,
              d.Cout, d.Cin, d.taps, d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, tile, scl);
 }
 
@@ -604,10 +608,14 @@ extern "C" int gt_pack_conv_weights(const float* v, const float* g, void* pack_f
 extern "C" int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, int group8, void* stream)
 {
   if (!descs_device || n_convs <= 0 || total_rows <= 0) return GT_E_INVAL;
-  if (group8) {
+  if (group8) {                                 // 1: rows of <= 2304 elements; 2: the caller vouches for <= 1024 (GT_PACK_SMALL_ROW)
     if (total_rows & 7) return GT_E_INVAL;
-    hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel, dim3(total_rows / 8), dim3(PK_THREADS), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const gt_pack_desc*>(descs_device), n_convs);
+    if (group8 == 2)
+      hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel<PK8_SMALLN>, dim3(total_rows / 8), dim3(PK_THREADS), 0, static_cast<hipStream_t>(stream),
+                         static_cast<const gt_pack_desc*>(descs_device), n_convs);
+    else
+      hipLaunchKernelGGL(gt_pack_conv_weights_multi8_kernel<PK8_MAXN>, dim3(total_rows / 8), dim3(PK_THREADS), 0, static_cast<hipStream_t>(stream),
+                         static_cast<const gt_pack_desc*>(descs_device), n_convs);
     return gt_launch_status(__func__);
   }
   hipLaunchKernelGGL(gt_pack_conv_weights_multi_kernel, dim3(total_rows), dim3(256), 0, static_cast<hipStream_t>(stream),

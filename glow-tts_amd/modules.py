@@ -161,7 +161,15 @@ class _PackPlan:
             return
         dev = entries[0][0].device
         # the bf16x3 (split) images are written by the one-row-per-workgroup kernel: a table of their own
-        for part in ([e for e in entries if not getattr(e[2], "split3", False)], [e for e in entries if getattr(e[2], "split3", False)]):
+        def g8(pc, maxn):
+            return pc.Cout % 8 == 0 and pc.Cin % 8 == 0 and pc.Cin * pc.taps <= maxn and not getattr(pc, "split3", False)
+
+        plain = [e for e in entries if not getattr(e[2], "split3", False)]
+        # rows of <= 1024 elements (the decoder's 192 x 5 convs: 90 % of the weights) go through the small form of the packing kernel
+        # (16 KB of LDS per workgroup instead of 36: twice the resident workgroups), the rest through the 2304-element form
+        small = [e for e in plain if g8(e[2], 1024)] if all(g8(e[2], 2304) for e in plain) else []
+        large = [e for e in plain if not any(e is x for x in small)]
+        for part in (small, large, [e for e in entries if getattr(e[2], "split3", False)]):
             if not part:
                 continue
             arr = (_lib.PackDesc * len(part))()
@@ -175,8 +183,7 @@ class _PackPlan:
                 d.Np_fwd, d.Kp_fwd, d.Np_dgrad, d.Kp_dgrad, d.gate, d.row_start = pc.Np_f, pc.Kp_f, pc.Np_d, pc.Kp_d, pc.flags, row
                 row += pc.Cout
             # 8 output channels per workgroup (coalesced 16-byte stores of both images) when every conv allows it
-            group8 = int(all(pc.Cout % 8 == 0 and pc.Cin % 8 == 0 and pc.Cin * pc.taps <= 2304 and not getattr(pc, "split3", False)
-                             for _, _, pc in part))
+            group8 = 2 if part is small else int(all(g8(pc, 2304) for _, _, pc in part))
             raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.tables.append((raw.to(dev), len(part), row, group8))
 

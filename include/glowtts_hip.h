@@ -167,6 +167,8 @@ typedef struct gt_pack_desc {
   const float* v; const float* g; void* pack_fwd; void* pack_dgrad; float* inv_norm;
   int32_t Cout, Cin, taps, Np_fwd, Kp_fwd, Np_dgrad, Kp_dgrad, gate, row_start, pad_;
 } gt_pack_desc;
+/* group8: 0 one workgroup per output channel; 1 eight output channels per workgroup (every conv: Cout % 8 == 0, Cin % 8 == 0,
+ * Cin * taps <= 2304); 2 the same for tables whose every conv has Cin * taps <= 1024 (less LDS and fewer registers per workgroup). */
 int gt_pack_conv_weights_multi(const void* descs_device, int n_convs, int total_rows, int group8, void* stream);
 
 /* Weight gradient of the rows-layout convolution: partial sums over S row slabs into
