@@ -84,6 +84,7 @@ def load_checkpoint(checkpoint_path, model, trainer=None):
                       f"in this model (ignored: {ignored[:4]}{' ...' if len(ignored) > 4 else ''})")
     model.load_state_dict({k: saved.get(k, v) for k, v in cur.items()})
     if trainer is not None:
+        trainer.invalidate_packed()                  # (load_state_dict bumps the parameters' version counters anyway)
         if "optimizer" in ck:
             load_optimizer_state_dict(trainer, ck["optimizer"])
         if "scheduler" in ck and "last_epoch" in ck["scheduler"]:

@@ -581,11 +581,20 @@ class FlowGenerator(nn.Module):
         if pend:
             torch.autograd.backward([s for s, _ in pend], [g for _, g in pend])
 
-    def prepare(self, side=None):
-        """Re-pack every conv weight for the MFMA kernels (once per optimizer step).  side: see modules.prepare_all."""
-        prepare_all(self, side)
-        if not self.use_sdp:
-            self.encoder.proj_w.prepare_extra()
+    def prepare(self, side=None, part="all"):
+        """Re-pack every conv weight for the MFMA kernels (once per optimizer step).  side: see modules.prepare_all.
+        part: "all", or one of the two halves it consists of — "decoder" (the flow decoder's convs: 90 % of the weights; train.Trainer
+        packs them at the END of a step, right behind the optimizer's pass over them, beside the text encoder's last backward launches)
+        and "rest" (every other child; the head of the next step).  The halves keep their own descriptor tables and derived-bias
+        buffers, so a captured step that packs by halves and an eager call that packs everything write the same memory."""
+        if part in ("all", "rest"):
+            for child in self.children():
+                if child is not self.decoder:
+                    prepare_all(child, side)
+            if not self.use_sdp:
+                self.encoder.proj_w.prepare_extra()
+        if part in ("all", "decoder"):
+            prepare_all(self.decoder, side if part == "all" else None)
 
     @staticmethod
     def _contour(c, y_max_length):

@@ -449,6 +449,8 @@ class Trainer:
         # early_decoder_adam: without collectives, the optimizer's pass over the decoder's conv parameters starts right behind the
         # decoder's batched weight gradients (_early_decoder_update) instead of after the whole backward; same numbers either way
         self.early_decoder_adam = bool(early_decoder_adam)
+        self._dec_fresh_version = None        # flat_p._version at which the decoder's packed weight images were last made at a step's end
+        self._head_rest = self._tail_packed = False
         self.graph_mode = bool(graph)
         self.split = bool(split_graph)
         accum = []
@@ -538,10 +540,28 @@ class Trainer:
             self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
         for p in self.buckets.params:
             p.grad = None
+        self._head_rest = False
+        if side is None:
+            self._dec_fresh_version = None
         if side is not None:
-            self.model.prepare(side=side)            # joins `side` at its end
+            # the decoder's weights were packed at the end of the previous step (_early_decoder_update) unless anything touched the
+            # parameters since (torch bumps the flat buffer's version counter on every in-place op on a view of it; the
+            # optimizer and packing kernels go through raw pointers and do not)
+            self._head_rest = self._dec_fresh_version == self._param_version()
+            self.model.prepare(side=side, part="rest" if self._head_rest else "all")            # joins `side` at its end
             self.model._prepared_by_trainer = True
+            self._dec_fresh_version = None
         ops.mark("accumulators zeroed")
+
+    def _param_version(self):
+        """Changes whenever torch wrote into the decoder's parameters (load_state_dict, the capture pass's restore, an in-place op on a
+        parameter): in-place ops bump a tensor's version counter, the optimizer and packing kernels go through raw pointers and do
+        not.  (A write through `p.data` is invisible to it: call invalidate_packed() after one.)"""
+        return self.opt.flat_p._version + sum(p._version for p in self.buckets.params[self.dec0:])
+
+    def invalidate_packed(self):
+        """The decoder's packed weight images no longer match its parameters: the next step packs everything at its head."""
+        self._dec_fresh_version = None
 
     def _early_decoder_update(self, params_done):
         """Called by the decoder's backward right behind its batched weight gradients (wgrad.WgradQueue.flush, site = the decoder): if
@@ -550,6 +570,13 @@ class Trainer:
         done = {id(p) for p in params_done}
         if all(id(p) in done for p in self.buckets.params[self.dec0:]) and self.dec0_off < self.buckets.total:
             self.opt.step_early(self.dec0_off, self.buckets.total)
+            if self.cfg.encoder_stream and hasattr(self.model, "prepare"):
+                # ... and the NEXT step's packing of these weights (90 % of that launch) follows at once, still beside the encoder's
+                # branch: the next step's head then packs the rest only.  (The decoder's other parameters — ActNorm, InvConvNear —
+                # are not part of any packed image.)
+                self.model.prepare(part="decoder")
+                self._tail_packed = True
+                self._dec_fresh_version = self._param_version()
 
     def _fwd_bwd(self, ids, t_x, y, t_y, lengths_host=None, cond=None, early_update=False):
         """forward + the whole backward; early_update (a full step without collectives, _step_impl): the optimizer's pass over the
@@ -660,8 +687,14 @@ class Trainer:
                     self._step_impl(*static, lengths_host=lh, cond=cond, collectives=False)
             finally:
                 self._restore(snap)
+            if self._tail_packed and hasattr(self.model, "prepare"):
+                # the warm-up steps packed the decoder's weights at their ends — from parameters the restore has just undone: pack them
+                # again from the restored ones, so that the captured step (whose head then packs the rest only) finds them fresh
+                self.model.prepare(part="decoder")
+                self._dec_fresh_version = self._param_version()
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        self._tail_packed = False
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and work they launched on another stream would stay outside the captured graph
         from . import wgrad
@@ -692,6 +725,9 @@ class Trainer:
         wgrad.sync_uploads(ids.device)               # fill the tables the captured kernels read (once, not per replay)
         wgrad.table_arena_end(ids.device)
         ctxs = dict(ctxs or {}, _keep=tables)        # wgrad.CaptureKeep: lives (and is released) with this key's graphs
+        # how the captured step packs the decoder's weights: its head packs everything (False) or relies on the previous step's
+        # end having packed the decoder's (True); its own end packs them for the next step or not
+        ctxs["_head_rest"], ctxs["_tail_packed"] = self._head_rest, self._tail_packed
         return graphs, static + [cond], out, ctxs
 
     def _rows_key(self, Tx, Ty, lh):
@@ -820,6 +856,8 @@ class Trainer:
             if "f" in ctxs:
                 ctx_lens.append((ctxs["f"], [int(v) // 2 * 2 for v in lh[1]]))
         _upload_step_inputs(pairs, ctx_lens)
+        if ctxs.get("_head_rest") and self._dec_fresh_version != self._param_version():
+            self.model.prepare(part="decoder")       # something touched the parameters since the last step's end (or that step did not pack)
         graphs[0].replay()                           # collectives sit BETWEEN the graphs, never inside one
         if len(graphs) == 2:
             self.buckets.allreduce()
@@ -829,4 +867,5 @@ class Trainer:
             graphs[1].replay()
             self.buckets.allreduce(0, self.dec0_off, wait=True)
             graphs[2].replay()
+        self._dec_fresh_version = self._param_version() if ctxs.get("_tail_packed") else None
         return out

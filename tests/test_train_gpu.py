@@ -527,6 +527,15 @@ def test_early_decoder_update_matches_the_single_optimizer_pass(built):
             if not graph:
                 assert calls == ([(tr.dec0_off, tr.buckets.total)] * 3 if early else [])
             assert tr.adam_steps == 3
+            # the early pass is followed by the NEXT step's packing of the decoder's weights; a write into the parameters between two
+            # steps (here: torch in-place ops, as load_state_dict does them) must not leave the stale images in use
+            with torch.no_grad():
+                for n, p in m.named_parameters():
+                    if n.startswith("decoder.") and n.endswith("in_layers.0.weight_v"):
+                        p.mul_(0.5)
+            for _ in range(2):
+                tr.step(*batch)
+            torch.cuda.synchronize()
             outs[(early, graph)] = (tr.opt.flat_p.clone(), tr.opt.m.clone(), tr.opt.v.clone(), float(tr.grad_norm))
     ref = outs[(False, False)]
     for key, o in outs.items():
