@@ -234,6 +234,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--late-adam", action="store_true", help="dev: the optimizer's pass over the decoder's parameters after the whole backward "
+                    "(Trainer(early_decoder_adam=False)) instead of right behind the decoder's weight gradients")
+    ap.add_argument("--head-pack", action="store_true", help="dev: pack all weights at the head of the step (Trainer(pack_in_tail=False)) "
+                    "instead of the decoder's at the end of the previous one")
     ap.add_argument("--split-graph", type=int, default=None, choices=[0, 1],
                     help="dev: force (1) / forbid (0) the phased, three-graph step (Trainer(split_graph=)); at N = 1 it shows what "
                          "that schedule costs without any collective (6.0 vs 4.84 ms: why one backward is the default at every N)")
@@ -271,7 +275,8 @@ def main():
             torch.distributed.broadcast(p.data, 0)
     use_graph = not args.no_graph
     tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True, grad_wire=args.grad_wire,
-                       split_graph=None if args.split_graph is None else bool(args.split_graph))
+                       split_graph=None if args.split_graph is None else bool(args.split_graph),
+                       early_decoder_adam=not args.late_adam, pack_in_tail=not args.head_pack)
     nb = 1 if args.one_batch else N_BATCHES
     batches = [make_batch(wl, rank, dev, i) for i in range(nb)]
     call = lambda b: tr.step(b["ids"], b["t_x"], b["y"], b["t_y"], lengths_host=b["lh"], **b["cond"])      # noqa: E731

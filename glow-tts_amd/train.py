@@ -437,7 +437,7 @@ class Trainer:
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32",
-                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None, early_decoder_adam=True):
+                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None, early_decoder_adam=True, pack_in_tail=True):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
         encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
@@ -449,6 +449,7 @@ class Trainer:
         # early_decoder_adam: without collectives, the optimizer's pass over the decoder's conv parameters starts right behind the
         # decoder's batched weight gradients (_early_decoder_update) instead of after the whole backward; same numbers either way
         self.early_decoder_adam = bool(early_decoder_adam)
+        self.pack_in_tail = bool(pack_in_tail)   # ... followed by the next step's packing of the decoder's weights (see _early_decoder_update)
         self._dec_fresh_version = None        # flat_p._version at which the decoder's packed weight images were last made at a step's end
         self._head_rest = self._tail_packed = False
         self.graph_mode = bool(graph)
@@ -570,7 +571,7 @@ class Trainer:
         done = {id(p) for p in params_done}
         if all(id(p) in done for p in self.buckets.params[self.dec0:]) and self.dec0_off < self.buckets.total:
             self.opt.step_early(self.dec0_off, self.buckets.total)
-            if self.cfg.encoder_stream and hasattr(self.model, "prepare"):
+            if self.pack_in_tail and self.cfg.encoder_stream and hasattr(self.model, "prepare"):
                 # ... and the NEXT step's packing of these weights (90 % of that launch) follows at once, still beside the encoder's
                 # branch: the next step's head then packs the rest only.  (The decoder's other parameters — ActNorm, InvConvNear —
                 # are not part of any packed image.)
