@@ -76,6 +76,7 @@ PROTOTYPES = {
                                  c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_rows_ctx_fill": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gt_step_inputs": (c_int, [c_void_p, c_void_p]),
+    "gt_step_zero": (c_int, [c_void_p, c_void_p]),
     "gt_rows_utt_sum": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gt_logp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gt_prior_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -170,6 +171,15 @@ PARTIALS_MAX = 32
 class PartialsArgs(ctypes.Structure):
     """struct gt_partials_args (include/glowtts_hip.h)"""
     _fields_ = [("job", PartialsJob * PARTIALS_MAX), ("n_jobs", ctypes.c_int32)]
+
+
+ZERO_MAX = 4
+
+
+class StepZeroArgs(ctypes.Structure):
+    """struct gt_step_zero_args (include/glowtts_hip.h)"""
+    _fields_ = [("ptr", c_void_p * ZERO_MAX), ("bytes", ctypes.c_uint64 * ZERO_MAX), ("seed_word", c_void_p), ("seed_inc", ctypes.c_uint32),
+                ("n", ctypes.c_int32)]
 
 
 class WnStackFwdArgs(ctypes.Structure):

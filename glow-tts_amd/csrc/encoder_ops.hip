@@ -578,6 +578,20 @@ __global__ __launch_bounds__(256) void gt_step_inputs_kernel(gt_step_inputs_args
   }
 }
 
+// The fills at the head of a training step in one launch: up to GT_ZERO_MAX regions cleared (16-byte aligned, sizes multiples of 16) and
+// the dropout seed word advanced (the step's accumulator arena, its pre-zeroed buffer region, the accumulated-gradient slice of the flat
+// buffer: three fills and an add before — serial launches in front of both branches of the step).
+__global__ __launch_bounds__(256) void gt_step_zero_kernel(gt_step_zero_args a)
+{
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.seed_word) *a.seed_word += a.seed_inc;
+  size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;               // 16-byte word of the concatenated regions
+  for (int j = 0; j < a.n; ++j) {
+    const size_t nw = a.bytes[j] >> 4;
+    if (w < nw) { reinterpret_cast<uint4*>(a.ptr[j])[w] = make_uint4(0, 0, 0, 0); return; }
+    w -= nw;
+  }
+}
+
 // ------------------------------------------------------------------ logp lattice (models.py:1076-1082)
 // logp[b,i,j] = sum_d(-0.5 log 2pi - s_id) + sum_d e^{-2 s_id} (-0.5 z_jd^2) + sum_d m_id e^{-2 s_id} z_jd
 //               + sum_d -0.5 m_id^2 e^{-2 s_id}
@@ -1009,6 +1023,19 @@ extern "C" int gt_rows_ctx_fill(const int32_t* row0, const int32_t* lens, int64_
 {
   if (!row0 || !lens || !rowbatch || !rowframe || !rowmask || B <= 0 || R <= 0) return GT_E_INVAL;
   hipLaunchKernelGGL(gt_rows_ctx_fill_kernel, dim3((R + 255) / 256), dim3(256), 0, GT_ST(stream), row0, lens, rowbatch, rowframe, rowmask, rowutt, B, R);
+  GT_RET();
+}
+extern "C" int gt_step_zero(const gt_step_zero_args* args, void* stream)
+{
+  if (!args || args->n < 0 || args->n > GT_ZERO_MAX) return GT_E_INVAL;
+  size_t words = 0;
+  for (int j = 0; j < args->n; ++j) {
+    if (!args->ptr[j] || (args->bytes[j] & 15) || ((uintptr_t)args->ptr[j] & 15)) return GT_E_ALIGN;
+    words += args->bytes[j] >> 4;
+  }
+  if (!words && !args->seed_word) return GT_OK;
+  if (words > ((size_t)1 << 31)) return GT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(gt_step_zero_kernel, dim3((unsigned)((words + 255) / 256) + (words ? 0 : 1)), dim3(256), 0, GT_ST(stream), *args);
   GT_RET();
 }
 extern "C" int gt_step_inputs(const gt_step_inputs_args* args, void* stream)

@@ -160,6 +160,47 @@ def arena_begin(device):
     a["off"], a["on"] = 0, True
 
 
+def step_head(device, extra=None, bump=True):
+    """arena_begin + big_begin (+ one more region to clear: `extra` = a contiguous tensor whose byte size is a multiple of 16) and
+    bump_seed in ONE launch (gt_step_zero) — the serial head of a training step; falls back to the separate calls off the GPU."""
+    if device.type != "cuda":
+        if bump:
+            bump_seed(device)
+        arena_begin(device); big_begin(device)
+        if extra is not None:
+            extra.zero_()
+        return
+    import ctypes
+    key = str(device)
+    regions = []
+    a = _ARENA.get(key)
+    if a is None:
+        arena_begin(device)                            # first use: allocates (zeroed)
+    else:
+        regions.append((a["buf"].data_ptr(), ARENA_BYTES))
+        a["off"], a["on"] = 0, True
+    b = _BIG.get(key)
+    if b is None:
+        big_begin(device)
+    else:
+        n = min(BIG_BYTES, (b["used"] + 4095) & ~4095) if b["used"] else BIG_BYTES
+        regions.append((b["buf"].data_ptr(), n))       # only what the previous step dirtied
+        b["off"], b["on"] = 0, True
+    if extra is not None and extra.numel():
+        nb = extra.numel() * extra.element_size()
+        if nb % 16 or extra.data_ptr() % 16 or not extra.is_contiguous():
+            extra.zero_()
+        else:
+            regions.append((extra.data_ptr(), nb))
+    args = _lib.StepZeroArgs()
+    for i, (p, n) in enumerate(regions):
+        args.ptr[i], args.bytes[i] = p, n
+    args.n = len(regions)
+    if bump:
+        args.seed_word, args.seed_inc = seed_word(device).data_ptr(), 0x632BE5AB
+    _lib.check(_lib.lib().gt_step_zero(ctypes.byref(args), _lib.current_stream(device)), "gt_step_zero")
+
+
 def arena_end(device):
     a = _ARENA.get(str(device))
     if a is not None:

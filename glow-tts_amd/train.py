@@ -122,6 +122,14 @@ class GradBuckets:
             self.flat[:self.accum_end].zero_()
             self.accum_live = True
 
+    def accum_region(self):
+        """zero_accum() for a caller that clears the region itself (ops.step_head: one launch for all of a step's fills): -> the slice
+        to clear (None if there is none); ops.grad_accumulator hands out its slices from now on."""
+        if not self.n_accum:
+            return None
+        self.accum_live = True
+        return self.flat[:self.accum_end]
+
     def view(self, i):
         p, o = self.params[i], self.offsets[i]
         return self.flat[o:o + p.numel()].view_as(p)
@@ -527,7 +535,6 @@ class Trainer:
         if ops.MARKS is not None:
             ops.MARKS.names = []
             ops.mark("step begin")
-        ops.bump_seed(device)
         # The step's head: three accumulator fills, the gathers of the derived biases and the weight-packing launch, all before
         # either branch can start.  Only the packing is long (~100 us): the rest runs beside it on the encoder's stream.
         from . import text_models
@@ -536,9 +543,9 @@ class Trainer:
             side = text_models._encoder_stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            ops.arena_begin(device)                  # one fill for all the small zeroed accumulators of this step
-            ops.big_begin(device)                    # ... and one for the partly written per-layer buffers (attention)
-            self.buckets.zero_accum()                # ... and one for the atomically accumulated parameter gradients
+            # ONE launch (gt_step_zero): the arena of the step's small zeroed accumulators, the region of the partly written per-layer
+            # buffers (attention), the atomically accumulated parameter gradients' slice of the flat buffer, and the dropout seed's bump
+            ops.step_head(device, extra=self.buckets.accum_region())
         for p in self.buckets.params:
             p.grad = None
         self._head_rest = False

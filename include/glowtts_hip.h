@@ -343,6 +343,11 @@ typedef struct gt_step_inputs_args {
   gt_step_copy copy[GT_STEP_MAX_COPIES]; gt_step_ctx ctx[GT_STEP_MAX_CTX]; int32_t n_copy, n_ctx;
 } gt_step_inputs_args;
 int gt_step_inputs(const gt_step_inputs_args* args, void* stream);
+/* The head of a training step: up to GT_ZERO_MAX regions zeroed (16-byte aligned, sizes multiples of 16) and *seed_word += seed_inc
+ * (optional), one launch. */
+#define GT_ZERO_MAX 4
+typedef struct gt_step_zero_args { void* ptr[GT_ZERO_MAX]; uint64_t bytes[GT_ZERO_MAX]; uint32_t* seed_word; uint32_t seed_inc; int32_t n; } gt_step_zero_args;
+int gt_step_zero(const gt_step_zero_args* args, void* stream);
 
 /* out[m,:] = (x[m,:] + cond[utterance(m),:]) * rowmask[m]: a per-utterance vector added to every valid row — the
  * speaker conditioning the reference broadcasts over time in attentions.py:66-67 (Encoder.cond_g, before layer index 2)

@@ -542,3 +542,25 @@ def test_early_decoder_update_matches_the_single_optimizer_pass(built):
         for a, b in zip(ref[:3], o[:3]):
             assert (a - b).abs().max().item() < 5e-3, key      # (float atomics order differs from run to run, not the update)
         assert abs(ref[3] - o[3]) < 2e-2 * abs(ref[3]), key
+
+
+def test_step_head_one_launch_clears_the_regions_and_bumps_the_seed(built):
+    """ops.step_head (gt_step_zero): the step's accumulator arena, its pre-zeroed buffer region and one more region cleared, the dropout
+    seed word advanced by bump_seed's constant — one launch; what lies behind a region is untouched."""
+    from glow_tts_amd import ops
+    d = dev()
+    ops.arena_begin(d); ops.big_begin(d)                             # allocate
+    a, b = ops._ARENA[str(d)], ops._BIG[str(d)]
+    a["buf"].fill_(3); b["buf"][:8192].fill_(5); b["used"] = 5000
+    extra = torch.full((1000 + 4,), 2.0, device=d)[:1000]            # 4000 bytes: a multiple of 16, with a guard behind it
+    guard = extra.storage_offset()
+    seed0 = int(ops.seed_word(d).item())
+    ops.step_head(d, extra=extra)
+    torch.cuda.synchronize()
+    assert int(a["buf"].count_nonzero()) == 0 and int(b["buf"][:8192].count_nonzero()) == 0 and int(extra.count_nonzero()) == 0
+    assert (int(ops.seed_word(d).item()) - seed0) & 0xffffffff == 0x632BE5AB
+    odd = torch.full((1001,), 2.0, device=d)                         # 4004 bytes: not a multiple of 16 -> the plain fill
+    ops.step_head(d, extra=odd, bump=False)
+    torch.cuda.synchronize()
+    assert int(odd.count_nonzero()) == 0 and (int(ops.seed_word(d).item()) - seed0) & 0xffffffff == 0x632BE5AB
+    ops.arena_end(d)
