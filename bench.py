@@ -238,6 +238,8 @@ def main():
                     "(Trainer(early_decoder_adam=False)) instead of right behind the decoder's weight gradients")
     ap.add_argument("--head-pack", action="store_true", help="dev: pack all weights at the head of the step (Trainer(pack_in_tail=False)) "
                     "instead of the decoder's at the end of the previous one")
+    ap.add_argument("--join-roots", action="store_true", help="dev (cfg 5): join the predictors' branch at the end of the forward and run "
+                    "ONE backward root (Trainer(split_roots=False)) instead of one root per stream")
     ap.add_argument("--split-graph", type=int, default=None, choices=[0, 1],
                     help="dev: force (1) / forbid (0) the phased, three-graph step (Trainer(split_graph=)); at N = 1 it shows what "
                          "that schedule costs without any collective (6.0 vs 4.84 ms: why one backward is the default at every N)")
@@ -276,7 +278,7 @@ def main():
     use_graph = not args.no_graph
     tr = train.Trainer(model, world=world, graph=use_graph, kernel_stamps=True, grad_wire=args.grad_wire,
                        split_graph=None if args.split_graph is None else bool(args.split_graph),
-                       early_decoder_adam=not args.late_adam, pack_in_tail=not args.head_pack)
+                       early_decoder_adam=not args.late_adam, pack_in_tail=not args.head_pack, split_roots=not args.join_roots)
     nb = 1 if args.one_batch else N_BATCHES
     batches = [make_batch(wl, rank, dev, i) for i in range(nb)]
     call = lambda b: tr.step(b["ids"], b["t_x"], b["y"], b["t_y"], lengths_host=b["lh"], **b["cond"])      # noqa: E731

@@ -273,6 +273,10 @@ class RowsConfig:
         self.encoder_stream = os.environ.get("GT_ENC_STREAM", "1") != "0"      # text encoder + duration predictor as a parallel branch
         self.predictor_branch = os.environ.get("GT_PRED_BRANCH", "1") != "0"   # cfg 5: stochastic predictors on the encoder's stream
         self.energy_on_main = os.environ.get("GT_ENERGY_MAIN", "1") != "0"     # ... except the energy predictor (main stream)
+        # the caller's stream waits for the predictors' branch at the end of forward() (so that the losses can be read there).
+        # train.Trainer's single-backward step turns it off and seeds the backward with one root per stream instead: the decoder's
+        # backward then starts behind the likelihood terms, beside the predictors' forward, instead of behind it
+        self.join_predictors = True
 
 
 DEFAULT_ROWS = RowsConfig()

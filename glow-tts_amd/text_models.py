@@ -722,11 +722,17 @@ class FlowGenerator(nn.Module):
             l_length, l_pitch, l_energy, logw = self._predictor_losses(rcx, xb, w, x_mask, x_lengths, z_mask, g, l, logw, noise, mas, y_lengths,
                                                                        y_max_length, pitch_norm, energy_norm,
                                                                        energy_stream=main if (pfork and self.rows_cfg.energy_on_main) else None)
-        if pfork:
+        # which stream each loss term was produced on; None = the caller's (joined below, or never forked)
+        self._loss_streams = None
+        if pfork and self.rows_cfg.join_predictors:
             main.wait_stream(enc_stream)
             for t_ in (l_length, l_pitch, l_energy):
                 if t_ is not None:
                     t_.record_stream(main)
+        elif pfork:
+            # no join: l_length / l_pitch (and l_energy unless its chain ran on the caller's stream) stay on the encoder's stream;
+            # the caller seeds the backward per stream (train.Trainer._loss_roots) and joins the streams after it
+            self._loss_streams = {"stream": enc_stream, "energy_on_caller": bool(self.rows_cfg.energy_on_main and self.use_spp and self.use_sep)}
         z_m = _PriorExpandFn.apply(x_m, mas.frame2token, mas.workspace)
         z_logs = torch.zeros_like(z_m) if self.mean_only else _PriorExpandFn.apply(x_logs, mas.frame2token, mas.workspace)
         self.last_logp = logp
@@ -737,6 +743,18 @@ class FlowGenerator(nn.Module):
         """l_length, l_pitch, l_energy of models.py:1086-1115 (+ logw of the deterministic duration predictor).
         energy_stream: the energy predictor's chain goes there (the caller's main stream, idle between MAS and the loss) instead of
         queueing behind the duration and pitch predictors on the current (encoder) stream."""
+        # The frame-rate features both prosody predictors read come FIRST and the event behind them is what the energy chain on the
+        # caller's stream waits for: recorded behind the duration predictor (as until round 3) that chain — and with it the caller's
+        # likelihood terms and the decoder's backward — queued behind a predictor it does not depend on.
+        l_pitch = l_energy = None
+        rcf = xf = zsum = ready = None
+        if self.use_spp or self.use_sep:                                       # models.py:1094-1115
+            rcf = ops.make_ctx(y_lengths.to(torch.int32), y_max_length, "f", cfg=self.rows_cfg)
+            xf = self._gather_features(rcx, xb, rcf, mas.frame2token)
+            zsum = torch.sum(z_mask)
+            if energy_stream is not None and xf.is_cuda and self.use_spp and self.use_sep:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(xf.device))           # xf, zsum, the frame-row context: what both chains read
         if self.use_sdp:                                                       # models.py:1086-1088
             pw = self.encoder.proj_w
             w_rows = rcx.to_rows(w.float())[:, 0].contiguous()
@@ -746,15 +764,7 @@ class FlowGenerator(nn.Module):
             if logw is None:
                 logw = self._predict_logw(g, l)
             l_length = _DurationLossFn.apply(logw, w, x_lengths)
-        l_pitch = l_energy = None
-        if self.use_spp or self.use_sep:                                       # models.py:1094-1115
-            rcf = ops.make_ctx(y_lengths.to(torch.int32), y_max_length, "f", cfg=self.rows_cfg)
-            xf = self._gather_features(rcx, xb, rcf, mas.frame2token)
-            zsum = torch.sum(z_mask)
-            ready = None
-            if energy_stream is not None and xf.is_cuda and self.use_spp and self.use_sep:
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(xf.device))           # xf, zsum, the frame-row context: what both chains read
+        if self.use_spp or self.use_sep:
             if self.use_spp:
                 pp = self.proj_pitch
                 npz = None if noise is None else rcf.to_rows(noise[1].float())[:, 0].contiguous()

@@ -445,7 +445,7 @@ class Trainer:
 
     def __init__(self, model, lr=2e-4, betas=(0.9, 0.98), eps=1e-9, world=1, graph=False, total_steps=None,
                  split_graph=None, ragged=None, max_graphs=8, pad_tx=16, pad_ty=32, kernel_stamps=False, grad_wire="fp32",
-                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None, early_decoder_adam=True, pack_in_tail=True):
+                 force_collectives=False, capture_after=2, ty_boundaries=None, row_round=None, early_decoder_adam=True, pack_in_tail=True, split_roots=True):
         """total_steps: length of the OneCycleLR schedule the reference runs (train_ms_emo_lang_pitch.py:161);
         None keeps lr / betas constant.  split_graph=True selects the phased form (the decoder's gradient slice on the wire while the
         encoder's backward runs: three graphs); the default at any world size is ONE backward — the encoder's backward beside the
@@ -457,7 +457,10 @@ class Trainer:
         # early_decoder_adam: without collectives, the optimizer's pass over the decoder's conv parameters starts right behind the
         # decoder's batched weight gradients (_early_decoder_update) instead of after the whole backward; same numbers either way
         self.early_decoder_adam = bool(early_decoder_adam)
-        self.pack_in_tail = bool(pack_in_tail)   # ... followed by the next step's packing of the decoder's weights (see _early_decoder_update)
+        self.pack_in_tail = bool(pack_in_tail)
+        # cfg-5-like models (stochastic predictors on the encoder's stream): the single-backward step does not join that branch at the
+        # end of the forward; the backward gets one root per stream (_loss_roots)
+        self.split_roots = bool(split_roots)   # ... followed by the next step's packing of the decoder's weights (see _early_decoder_update)
         self._dec_fresh_version = None        # flat_p._version at which the decoder's packed weight images were last made at a step's end
         self._head_rest = self._tail_packed = False
         self.graph_mode = bool(graph)
@@ -528,6 +531,29 @@ class Trainer:
             loss = loss + 0.5 * l_energy
         return loss, l_mle
 
+    def _loss_roots(self, outs):
+        """_loss() for a forward that did not join the predictors' branch (ops.RowsConfig.join_predictors = False): one backward root
+        per stream — the likelihood term (+ the energy term when its chain ran on this stream) here, the duration and pitch terms on
+        the encoder's stream, where they were produced — so that nothing on this stream waits for the predictors' forward before the
+        decoder's backward starts.  -> ([roots], l_mle); their sum is _loss()'s loss."""
+        m = self.model
+        ls = getattr(m, "_loss_streams", None)
+        if ls is None:
+            loss, l_mle = self._loss(outs)
+            return [loss], l_mle
+        (z, z_m, z_logs, logdet, z_mask), _, (attn, l_length, l_pitch, l_energy), _, _ = outs
+        l_mle = models.mle_loss(z, z_m, None if m.mean_only else z_logs, logdet, z_mask)
+        here = l_mle
+        with torch.cuda.stream(ls["stream"]):
+            there = torch.sum(l_length)
+            if l_pitch is not None:
+                there = there + 0.5 * l_pitch
+            if l_energy is not None and not ls["energy_on_caller"]:
+                there = there + 0.5 * l_energy
+        if l_energy is not None and ls["energy_on_caller"]:
+            here = here + 0.5 * l_energy
+        return [here, there], l_mle
+
     def _begin(self, device):
         from . import ops
         if self.stamps is not None:
@@ -591,17 +617,32 @@ class Trainer:
         decoder's parameters is launched from inside the backward (_early_decoder_update) and opt.step() must follow."""
         self._begin(ids.device)
         from . import ops
-        loss, l_mle = self._loss(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {})))
+        rows_cfg = getattr(self.model, "rows_cfg", None)
+        if rows_cfg is not None:
+            rows_cfg.join_predictors = not self.split_roots
+        try:
+            roots, l_mle = self._loss_roots(self.model(ids, t_x, y, t_y, lengths_host=lengths_host, **(cond or {})))
+        finally:
+            if rows_cfg is not None:
+                rows_cfg.join_predictors = True
         ops.mark("loss")
         dec = getattr(self.model, "decoder", None)
         early = early_update and self.early_decoder_adam and dec is not None and not self.buckets.collect and ids.is_cuda
         if early:                                    # (with collectives the gradients are not final until the all-reduce)
             object.__setattr__(dec, "_gt_after_flush", self._early_decoder_update)
         try:
-            loss.backward()
+            if len(roots) == 1:
+                roots[0].backward()
+            else:
+                torch.autograd.backward(roots)
         finally:
             if early:
                 object.__setattr__(dec, "_gt_after_flush", None)
+        if len(roots) > 1:                           # (the engine has joined the streams its leaves were accumulated on; make it explicit)
+            torch.cuda.current_stream().wait_stream(self.model._loss_streams["stream"])
+            loss = roots[0].detach() + roots[1].detach()
+        else:
+            loss = roots[0]
         ops.mark("backward joined")
         self.buckets.gather()
         ops.mark("gradients gathered")
