@@ -470,25 +470,36 @@ __global__ __launch_bounds__(256) void gt_bct_from_rows_kernel(const void* __res
 // Gradient of modules.WNP's affine per-frame conditioning (cond_layer1 has ONE input channel: cond = b + contour * w, squeezed in time,
 // see gt_wn_stack_fwd): from the gate backward's d pre rows of the WaveNet's layers (before the dropout mask where dropout is on),
 //   d w[off_i + c] += sum_m dpre_i[m, c] * sig[m, par_i],   d b[off_i + c] += sum_m dpre_i[m, c],   c < 2H, layer i.
-// grid (row slab, layer); 192 threads, 2 consecutive channels each (one 4-byte load per row), fp32 sums, one atomic pair per thread.
-__global__ __launch_bounds__(192) void gt_cond_affine_grads_kernel(const bf16_t* __restrict__ d0, const bf16_t* __restrict__ d1, const bf16_t* __restrict__ d2,
+// grid (row slab, layer); 768 threads = 4 row phases x 192 threads of 2 consecutive channels each (one 4-byte load per row), fp32 sums
+// folded over the phases in LDS, one atomic pair per channel pair and workgroup.  (Round 3 first ran 192 threads down 256 rows each:
+// 64 dependent load batches, 24 us per launch, 24 launches on the decoder's backward chain of cfg 5.)
+constexpr int CAG_PH = 4;
+__global__ __launch_bounds__(192 * CAG_PH) void gt_cond_affine_grads_kernel(const bf16_t* __restrict__ d0, const bf16_t* __restrict__ d1, const bf16_t* __restrict__ d2,
                                                                    const bf16_t* __restrict__ d3, int lddp, const float* __restrict__ sig,
                                                                    float* __restrict__ dw, float* __restrict__ db, int R, int H, int n_layers,
                                                                    int rows_per_block)
 {
+  __shared__ float red[CAG_PH][192][4];
   const int layer = blockIdx.y, O = H * n_layers;
   const bf16_t* d = layer == 0 ? d0 : (layer == 1 ? d1 : (layer == 2 ? d2 : d3));
   const int par = (2 * H * layer) / O, off = 2 * H * layer - par * O;
-  const int c = 2 * threadIdx.x;
+  const int tc = threadIdx.x % 192, ph = threadIdx.x / 192;
+  const int c = 2 * tc;
   const int m0 = blockIdx.x * rows_per_block, m1 = min(R, m0 + rows_per_block);
   float w0 = 0.f, w1 = 0.f, b0 = 0.f, b1 = 0.f;
   if (c < 2 * H) {
-#pragma unroll 4
-    for (int m = m0; m < m1; ++m) {
+#pragma unroll 8
+    for (int m = m0 + ph; m < m1; m += CAG_PH) {
       const uint32_t v = *reinterpret_cast<const uint32_t*>(d + (size_t)m * lddp + c);
       const float x0 = bf2f(v & 0xffff), x1 = bf2f(v >> 16), p = sig[2 * (size_t)m + par];
       b0 += x0; b1 += x1; w0 += x0 * p; w1 += x1 * p;
     }
+  }
+  red[ph][tc][0] = w0; red[ph][tc][1] = w1; red[ph][tc][2] = b0; red[ph][tc][3] = b1;
+  __syncthreads();
+  if (ph == 0 && c < 2 * H) {
+#pragma unroll
+    for (int q = 1; q < CAG_PH; ++q) { w0 += red[q][tc][0]; w1 += red[q][tc][1]; b0 += red[q][tc][2]; b1 += red[q][tc][3]; }
     atomicAdd(dw + off + c, w0); atomicAdd(dw + off + c + 1, w1);
     atomicAdd(db + off + c, b0); atomicAdd(db + off + c + 1, b1);
   }
@@ -652,8 +663,8 @@ extern "C" int gt_cond_affine_grads(const void* dpre0, const void* dpre1, const 
   if (!dpre0 || !sig || !dw || !db || R < 0 || H != 192 || n_layers < 1 || n_layers > 4 || ((H * n_layers) % (2 * H)) || (lddp & 1)) return GT_E_INVAL;
   if ((n_layers > 1 && !dpre1) || (n_layers > 2 && !dpre2) || (n_layers > 3 && !dpre3)) return GT_E_INVAL;
   if (R == 0) return GT_OK;
-  const int rows_per_block = 256;
-  hipLaunchKernelGGL(gt_cond_affine_grads_kernel, dim3((R + rows_per_block - 1) / rows_per_block, n_layers), dim3(192), 0, GT_ST(stream),
+  const int rows_per_block = 128;
+  hipLaunchKernelGGL(gt_cond_affine_grads_kernel, dim3((R + rows_per_block - 1) / rows_per_block, n_layers), dim3(192 * CAG_PH), 0, GT_ST(stream),
                      static_cast<const bf16_t*>(dpre0), static_cast<const bf16_t*>(dpre1), static_cast<const bf16_t*>(dpre2),
                      static_cast<const bf16_t*>(dpre3), lddp, sig, dw, db, R, H, n_layers, rows_per_block);
   GT_RET();
