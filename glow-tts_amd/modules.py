@@ -199,7 +199,7 @@ class _PackPlan:
 _RETIRED_PLANS = []
 
 
-def prepare_all(module, side=None):
+def prepare_all(module, side=None, join=True):
     """(Re)pack every conv weight under `module` for the MFMA kernels — once per optimizer step.
     side: a stream that already follows the current one (train.Trainer: the encoder's branch, with the step's accumulator fills
     on it): the small gathers of the derived biases go there, beside the packing launch, and the current stream joins it at the end."""
@@ -257,7 +257,7 @@ def prepare_all(module, side=None):
         plan = _PackPlan(module)
         object.__setattr__(module, "_pack_plan", plan)
     plan.run()
-    if side is not None:
+    if side is not None and join:                 # join=False: the caller makes the current stream wait for `side` itself, later
         torch.cuda.current_stream().wait_stream(side)
 
 

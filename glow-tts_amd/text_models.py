@@ -581,7 +581,7 @@ class FlowGenerator(nn.Module):
         if pend:
             torch.autograd.backward([s for s, _ in pend], [g for _, g in pend])
 
-    def prepare(self, side=None, part="all"):
+    def prepare(self, side=None, part="all", join=True):
         """Re-pack every conv weight for the MFMA kernels (once per optimizer step).  side: see modules.prepare_all.
         part: "all", or one of the two halves it consists of — "decoder" (the flow decoder's convs: 90 % of the weights; train.Trainer
         packs them at the END of a step, right behind the optimizer's pass over them, beside the text encoder's last backward launches)
@@ -590,11 +590,11 @@ class FlowGenerator(nn.Module):
         if part in ("all", "rest"):
             for child in self.children():
                 if child is not self.decoder:
-                    prepare_all(child, side)
+                    prepare_all(child, side, join)
             if not self.use_sdp:
                 self.encoder.proj_w.prepare_extra()
         if part in ("all", "decoder"):
-            prepare_all(self.decoder, side if part == "all" else None)
+            prepare_all(self.decoder, side if part == "all" else None, join)
 
     @staticmethod
     def _contour(c, y_max_length):
@@ -647,6 +647,9 @@ class FlowGenerator(nn.Module):
         g = self.condition(g, emo, emo_cartesian)
         if l is not None:
             l = self.emb_l(l).unsqueeze(-1)                          # language ids [b] -> [b, lin_channels, 1] (models.py:1012-1013)
+        pending = self.__dict__.pop("_prepare_side", None)           # train.Trainer packed on this stream and left the join to us:
+        if pending is not None:                                      # the front end above ran beside the packing launches
+            torch.cuda.current_stream(x.device).wait_stream(pending)
         assert (g is None) == (self.gin_channels == 0), "a speaker / conditioning vector is required exactly when gin_channels != 0"
         if (self.use_spp and pitch is None) or (self.use_sep and energy is None):
             raise ValueError("use_spp / use_sep: forward needs the pitch / energy contours (models.py:1057-1115)")

@@ -582,8 +582,11 @@ class Trainer:
             # parameters since (torch bumps the flat buffer's version counter on every in-place op on a view of it; the
             # optimizer and packing kernels go through raw pointers and do not)
             self._head_rest = self._dec_fresh_version == self._param_version()
-            self.model.prepare(side=side, part="rest" if self._head_rest else "all")            # joins `side` at its end
+            # (no join here: FlowGenerator.forward makes its stream wait for `side` behind its conditioning front end — cfg 5's
+            #  speaker / emotion / language embeddings are ~40 small launches that need no packed weight)
+            self.model.prepare(side=side, part="rest" if self._head_rest else "all", join=False)
             self.model._prepared_by_trainer = True
+            self.model._prepare_side = side
             self._dec_fresh_version = None
         ops.mark("accumulators zeroed")
 

@@ -1,12 +1,14 @@
 """Dev tool: idle time inside one replayed step, from a rocprofv3 --kernel-trace database.
-usage: timeline.py <dir> — takes the last full step (between two gt_pack_conv_weights_multi launches) and reports the span,
+usage: timeline.py <dir> — takes a step in the middle of the run (between two gt_step_zero launches) and reports the span,
 the time during which NO kernel was running, and the largest idle gaps with the kernels around them."""
 import glob, sqlite3, sys
 
 db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end, queue_id, stream_id from kernels order by start").fetchall()
-packs = [i for i, r in enumerate(rows) if "gt_pack_conv_weights_multi" in r[0]]
+packs = [i for i, r in enumerate(rows) if "gt_step_zero" in r[0]]         # one per step, at its head (round 3; before: the packing launch)
+if len(packs) < 3:
+    packs = [i for i, r in enumerate(rows) if "gt_pack_conv_weights_multi" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else len(packs) // 2
 i0, i1 = packs[k], packs[k + 1]                     # default: a step in the middle of the run (the replayed ones)
 step = rows[i0:i1]
