@@ -475,7 +475,12 @@ class Trainer:
         # flat-buffer order: everything but the decoder first, the decoder's parameters last (whatever the registration order
         # of the model's sub-modules; checkpoint.py maps the flat layout back to model.parameters() order by identity)
         named = list(model.named_parameters())
-        plist = [p for n, p in named if not n.startswith("decoder.")] + [p for n, p in named if n.startswith("decoder.")]
+        # ... and inside the decoder the parameters its batched weight-gradient flush does NOT write (the conditioning layers, whose
+        # effective weights are formed by host-side torch ops: their gradients arrive through autograd at the end of the backward)
+        # before the ones it does: the tail of the buffer is then final the moment that flush is (_early_decoder_update)
+        late = lambda n: ".cond_layer." in n or "cond_layer1" in n                 # noqa: E731
+        plist = [p for n, p in named if not n.startswith("decoder.")] + [p for n, p in named if n.startswith("decoder.") and late(n)] + \
+                [p for n, p in named if n.startswith("decoder.") and not late(n)]
         self.buckets = GradBuckets(plist, world, accum=accum, wire=grad_wire,      # grad_wire="bf16": GradBuckets.__init__
                                    force_collectives=force_collectives)
         # phased backward: the decoder's parameters (the tail of the flat buffer, ~90 % of the bytes) are final after the
@@ -485,6 +490,9 @@ class Trainer:
         self.dec0 = next((i for i, n in enumerate(names) if i >= self.buckets.n_accum and n.startswith("decoder.")), len(names))
         assert all(n.startswith("decoder.") for n in names[self.dec0:]), "decoder parameters must be the tail of the model"
         self.dec0_off = self.buckets.offsets[self.dec0] if self.dec0 < len(names) else self.buckets.total
+        # the part of that tail the decoder's weight-gradient flush completes (early optimizer pass, packing at the step's end)
+        self.dec_cov = next((i for i, n in enumerate(names) if i >= self.dec0 and not late(n)), len(names))
+        self.dec_cov_off = self.buckets.offsets[self.dec_cov] if self.dec_cov < len(names) else self.buckets.total
         self.opt = FlatAdamW(self.buckets, lr, betas, eps)
         self.max_lr, self.total_steps, self.n_steps = lr, total_steps, 0
         self.grad_norm = None
@@ -594,7 +602,7 @@ class Trainer:
         """Changes whenever torch wrote into the decoder's parameters (load_state_dict, the capture pass's restore, an in-place op on a
         parameter): in-place ops bump a tensor's version counter, the optimizer and packing kernels go through raw pointers and do
         not.  (A write through `p.data` is invisible to it: call invalidate_packed() after one.)"""
-        return self.opt.flat_p._version + sum(p._version for p in self.buckets.params[self.dec0:])
+        return self.opt.flat_p._version + sum(p._version for p in self.buckets.params[self.dec_cov:])
 
     def invalidate_packed(self):
         """The decoder's packed weight images no longer match its parameters: the next step packs everything at its head."""
@@ -605,8 +613,8 @@ class Trainer:
         they covered every parameter of the flat buffer's tail — the decoder's conv weights, gains and biases — the optimizer's pass
         over that tail starts now, on the decoder's stream, while the text encoder's branch is still in its backward."""
         done = {id(p) for p in params_done}
-        if all(id(p) in done for p in self.buckets.params[self.dec0:]) and self.dec0_off < self.buckets.total:
-            self.opt.step_early(self.dec0_off, self.buckets.total)
+        if all(id(p) in done for p in self.buckets.params[self.dec_cov:]) and self.dec_cov_off < self.buckets.total:
+            self.opt.step_early(self.dec_cov_off, self.buckets.total)
             if self.pack_in_tail and self.cfg.encoder_stream and hasattr(self.model, "prepare"):
                 # ... and the NEXT step's packing of these weights (90 % of that launch) follows at once, still beside the encoder's
                 # branch: the next step's head then packs the rest only.  (The decoder's other parameters — ActNorm, InvConvNear —

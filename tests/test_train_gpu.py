@@ -525,7 +525,7 @@ def test_early_decoder_update_matches_the_single_optimizer_pass(built):
                 tr.step(*batch)
             torch.cuda.synchronize()
             if not graph:
-                assert calls == ([(tr.dec0_off, tr.buckets.total)] * 3 if early else [])
+                assert calls == ([(tr.dec_cov_off, tr.buckets.total)] * 3 if early else [])
             assert tr.adam_steps == 3
             # the early pass is followed by the NEXT step's packing of the decoder's weights; a write into the parameters between two
             # steps (here: torch in-place ops, as load_state_dict does them) must not leave the stale images in use
@@ -564,3 +564,40 @@ def test_step_head_one_launch_clears_the_regions_and_bumps_the_seed(built):
     torch.cuda.synchronize()
     assert int(odd.count_nonzero()) == 0 and (int(ops.seed_word(d).item()) - seed0) & 0xffffffff == 0x632BE5AB
     ops.arena_end(d)
+
+
+def test_early_decoder_update_with_conditioning_layers(built):
+    """A speaker-conditioned decoder (cfg 4): the WaveNets' cond_layer parameters get their gradients through autograd at the end of
+    the backward, not from the decoder's weight-gradient flush — they sit in FRONT of the flush's parameters in the flat buffer, the
+    early optimizer pass covers the tail behind them, and the result equals the single late pass."""
+    from glow_tts_amd import train
+    cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, p_dropout=0.0, p_dropout_dec=0.0, gin_channels=32)
+    torch.manual_seed(0)
+    m0 = train.build_model(cfg, device=dev())
+    with torch.no_grad():
+        for n, p in m0.named_parameters():
+            if n.endswith("end.weight") or n.endswith("pre.proj.weight"):
+                p.normal_(0, 0.02)
+    batch = train.synth_batch(4, 40, 120, 0, dev())
+    g = torch.randn(4, 32, 1, generator=torch.Generator().manual_seed(1)).to(dev())
+    outs = {}
+    for early in (False, True):
+        m = train.build_model(cfg, device=dev())
+        m.load_state_dict(m0.state_dict())
+        m.encoder.pre.p_dropout = 0.0
+        tr = train.Trainer(m, graph=True, capture_after=1, early_decoder_adam=early)
+        names = {id(p): n for n, p in m.named_parameters()}
+        tail = [names[id(p)] for p in tr.buckets.params[tr.dec_cov:]]
+        assert tr.dec0 < tr.dec_cov < len(tr.buckets.params) and all(n.startswith("decoder.") and ".cond_layer." not in n for n in tail)
+        assert all(".cond_layer." in names[id(p)] for p in tr.buckets.params[tr.dec0:tr.dec_cov])
+        calls = []
+        orig = tr.opt.step_early
+        tr.opt.step_early = lambda lo, hi, _o=orig, _c=calls: (_c.append((lo, hi)), _o(lo, hi))[1]
+        for _ in range(3):
+            tr.step(*batch, g=g)
+        torch.cuda.synchronize()
+        assert bool(calls) == early and all(c == (tr.dec_cov_off, tr.buckets.total) for c in calls)
+        outs[early] = ({n: p.detach().clone() for n, p in m.named_parameters()}, float(tr.grad_norm))
+    for n, a in outs[False][0].items():
+        assert (a - outs[True][0][n]).abs().max().item() < 5e-3, n
+    assert abs(outs[False][1] - outs[True][1]) < 2e-2 * abs(outs[False][1])
