@@ -199,7 +199,10 @@ __device__ __forceinline__ void coop_store_rows(bf16_t* __restrict__ dst, int ld
 // on a forward launch, + 9 us on a backward one, all of it gone once the images are back in the cache (tools/wn_layer_bench.py,
 // WN_BENCH_COLD).  A boundary launch runs 152 workgroups on 256 CUs: PF_WGS extra workgroups (blockIdx >= the row tiles) read
 // those images once, on CUs that were idle, and retire within a few microseconds.
-constexpr int PF_WGS = 64;
+#ifndef WNB_PF_WGS
+#define WNB_PF_WGS 64
+#endif
+constexpr int PF_WGS = WNB_PF_WGS;
 __device__ __forceinline__ void prefetch_images(const void* const (&ptr)[16], const uint32_t (&bytes)[16], int wg, uint32_t* sink)
 {
   uint32_t acc = 0;
