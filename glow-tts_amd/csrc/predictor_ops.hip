@@ -20,9 +20,12 @@ namespace {
 
 constexpr int PC = 192;                       // channels of every predictor network (filter_channels = in_channels, models.py:223)
 constexpr int NC = PC / 64;                   // channels per lane
-constexpr int RPW = 8;                        // rows per wave per workgroup (forward kernels)
+#ifndef DDS_RPW
+#define DDS_RPW 2                             // (cfg 5 step: 16.2 ms at 8 rows per wave, 15.5 at 4, 15.0-15.2 at 2, 15.1 at 1)
+#endif
+constexpr int RPW = DDS_RPW;                  // rows per wave per workgroup (forward kernels)
 #ifndef DDS_RPB
-#define DDS_RPB 4                             // (cfg 5 step: 18.05 ms at 8 rows per wave, 17.51 at 4, 17.54 at 2)
+#define DDS_RPB 2                             // (cfg 5 step, with the partial-row reduce: 18.05 ms at 8 rows per wave, 17.5 at 4; 14.9 at 2 with DDS_RPW 2)
 #endif
 constexpr int RPB = DDS_RPB;                  // ... of the backward kernels that also accumulate parameter gradients
 
