@@ -512,7 +512,7 @@ extern "C" int gt_colsum(const void* Y, int ldy, int is_f32, float* out, int R, 
 {
   if (!Y || !out || R < 0 || N <= 0) return GT_E_INVAL;
   if (R == 0) return GT_OK;
-  const int rows_per_block = 512;
+  const int rows_per_block = 128;             // (512: 128 dependent loads per thread — 31 us for 17.8 k x 192 fp32 rows)
   const dim3 grid((N + 63) / 64, (R + rows_per_block - 1) / rows_per_block);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (is_f32) hipLaunchKernelGGL(gt_colsum_kernel<true>,  grid, dim3(256), 0, st, Y, ldy, out, R, N, rows_per_block);
