@@ -115,7 +115,9 @@ PROTOTYPES = {
     "gt_convflow_pre_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gt_convflow_spline_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "gt_convflow_spline_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+                                       c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "gt_convflow_spline_partial_rows": (c_int, [c_int]),
+    "gt_convflow_spline_partial_width": (c_int, []),
     "gt_convflow_spline_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gt_ea_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
     "gt_ea_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p]),

@@ -516,6 +516,7 @@ __device__ __forceinline__ void spline_grad(const Spline& s, float gy, float gl,
 
 constexpr int SPR = 32;                       // rows per workgroup of the spline kernels
 constexpr int HP = PC + 1;                    // LDS pitch of the h tile (conflict-free column walks)
+constexpr int SPL_PW = NPAR * PC + NPAR;      // floats per partial row of the spline backward: d Wp [NPAR][PC] | d bp [NPAR]
 
 // add `v` (per lane of wave 0, lanes < SPR) to acc[utt] with one atomic when the rows share an utterance
 __device__ __forceinline__ void utt_accumulate(float* acc, int u, bool on, float v)
@@ -583,8 +584,11 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_bwd_kernel(
     const float* __restrict__ h, const float* __restrict__ Wp, const float* __restrict__ par, const float* __restrict__ zin,
     const float* __restrict__ dzout, const float* __restrict__ gacc, const float* __restrict__ rowmask,
     const int32_t* __restrict__ utt, float* __restrict__ dh, float* __restrict__ dWp, float* __restrict__ dbp,
-    float* __restrict__ dzin, float sign, int flip, int R)
+    float* __restrict__ partials, float* __restrict__ dzin, float sign, int flip, int R)
 {
+  // partials: row blockIdx.x of [gridDim.x][SPL_PW] receives this workgroup's d Wp | d bp sums (plain stores; gt_param_partials_reduce adds
+  // them up) instead of NPAR * PC + NPAR atomics per workgroup — 556 workgroups on 5 597 addresses at cfg 5's frame rows: 46 us per launch
+  float* prow = partials ? partials + (size_t)blockIdx.x * SPL_PW : nullptr;
   __shared__ float Ws[32][HP];                // [o][k], rows >= NPAR zero
   __shared__ float Hs[SPR][HP];
   __shared__ float Gs[SPR][32];               // d params per row (masked)
@@ -634,12 +638,14 @@ __global__ __launch_bounds__(256) void gt_convflow_spline_bwd_kernel(
     float a = 0.f;
 #pragma unroll 8
     for (int r = 0; r < SPR; ++r) a += Gs[r][o] * Hs[r][k];
-    if (a != 0.f) atomicAdd(dWp + q, a);
+    if (prow) prow[q] = a;
+    else if (a != 0.f) atomicAdd(dWp + q, a);
   }
   if (tid < NPAR) {
     float a = 0.f;
     for (int r = 0; r < SPR; ++r) a += Gs[r][tid];
-    if (a != 0.f) atomicAdd(dbp + tid, a);
+    if (prow) prow[NPAR * PC + tid] = a;
+    else if (a != 0.f) atomicAdd(dbp + tid, a);
   }
 }
 
@@ -914,14 +920,16 @@ extern "C" int gt_convflow_spline_fwd(const float* h, const float* Wp, const flo
                      z_out, params, acc, sign, flip, R);
   GT_RET();
 }
+extern "C" int gt_convflow_spline_partial_rows(int R) { return R > 0 ? (R + SPR - 1) / SPR : 0; }
+extern "C" int gt_convflow_spline_partial_width(void) { return SPL_PW; }
 extern "C" int gt_convflow_spline_bwd(const float* h, const float* Wp, const float* params, const float* z_in, const float* dz_out,
                                       const float* gacc, const float* rowmask, const int32_t* utt, float* dh, float* dWp, float* dbp,
-                                      float* dz_in, float sign, int flip, int R, int C, void* stream)
+                                      float* partials, float* dz_in, float sign, int flip, int R, int C, void* stream)
 {
-  if (!h || !Wp || !params || !z_in || !dz_out || !gacc || !rowmask || !utt || !dh || !dWp || !dbp || !dz_in || R <= 0) return GT_E_INVAL;
+  if (!h || !Wp || !params || !z_in || !dz_out || !gacc || !rowmask || !utt || !dh || (!partials && (!dWp || !dbp)) || !dz_in || R <= 0) return GT_E_INVAL;
   if (C != PC) return GT_E_UNSUPPORTED;
   hipLaunchKernelGGL(gt_convflow_spline_bwd_kernel, dim3((R + SPR - 1) / SPR), dim3(256), 0, GT_ST(stream), h, Wp, params, z_in, dz_out, gacc,
-                     rowmask, utt, dh, dWp, dbp, dz_in, sign, flip, R);
+                     rowmask, utt, dh, dWp, dbp, partials, dz_in, sign, flip, R);
   GT_RET();
 }
 extern "C" int gt_convflow_spline_inv(const float* h, const float* Wp, const float* bp, const float* z_in, const float* rowmask,

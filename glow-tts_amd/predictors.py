@@ -238,9 +238,14 @@ def _cf_bwd(rc, cf, saved, dzo, gacc, dg, grads, sign=-1.0):
     dh = torch.empty(R, C, dtype=torch.float32, device=dev)
     dz = torch.empty_like(z)
     dWp, dbp = grad_accumulator(cf.proj.weight), grad_accumulator(cf.proj.bias)
+    q = wgrad.active()                               # inside a module's backward: partial rows + the queue's one reduce launch
+    pt = torch.empty(L.gt_convflow_spline_partial_rows(R), L.gt_convflow_spline_partial_width(), dtype=torch.float32, device=dev) \
+        if (q is not None and dWp.numel() + dbp.numel() == L.gt_convflow_spline_partial_width()) else None
     _lib.check(L.gt_convflow_spline_bwd(_lib.ptr(h), _lib.ptr(cf.proj.weight), _lib.ptr(par), _lib.ptr(z), _lib.ptr(dzo), _lib.ptr(gacc),
-                                        _lib.ptr(rc.rowmask), _lib.ptr(rc.row_utt()), _lib.ptr(dh), _lib.ptr(dWp), _lib.ptr(dbp),
+                                        _lib.ptr(rc.rowmask), _lib.ptr(rc.row_utt()), _lib.ptr(dh), _lib.ptr(dWp), _lib.ptr(dbp), _lib.ptr(pt),
                                         _lib.ptr(dz), float(sign), 1, R, C, _st(dev)), "gt_convflow_spline_bwd")
+    if pt is not None:
+        q.add_ln(pt, dWp, dbp)
     grads[cf.proj.weight], grads[cf.proj.bias] = dWp, dbp
     dx0 = dds_bwd(rc, cf.convs, sv, dh, grads)
     dwp, dbpre = grad_accumulator(cf.pre.weight), grad_accumulator(cf.pre.bias)

@@ -623,9 +623,13 @@ int gt_convflow_pre_bwd(const float* dx0, const float* z, int ldz, const float* 
                         float* dw_pre, float* db_pre, float* dz, int lddz, float* dg, int R, int C, void* stream);
 int gt_convflow_spline_fwd(const float* h, const float* Wp, const float* bp, const float* z_in, const float* rowmask,
                            const int32_t* utt, float* z_out, float* params, float* acc, float sign, int flip, int R, int C, void* stream);
+/* partials (optional; then dWp / dbp may be NULL): row w of [gt_convflow_spline_partial_rows(R)][gt_convflow_spline_partial_width()]
+ * receives workgroup w's d Wp [29][C] | d bp [29] sums instead of atomics (gt_param_partials_reduce adds them up). */
+int gt_convflow_spline_partial_rows(int R);
+int gt_convflow_spline_partial_width(void);
 int gt_convflow_spline_bwd(const float* h, const float* Wp, const float* params, const float* z_in, const float* dz_out,
                            const float* gacc, const float* rowmask, const int32_t* utt, float* dh, float* dWp, float* dbp,
-                           float* dz_in, float sign, int flip, int R, int C, void* stream);
+                           float* partials, float* dz_in, float sign, int flip, int R, int C, void* stream);
 int gt_convflow_spline_inv(const float* h, const float* Wp, const float* bp, const float* z_in, const float* rowmask,
                            float* z_out, int R, int C, void* stream);
 
