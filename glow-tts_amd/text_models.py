@@ -310,7 +310,7 @@ class _MleLossFn(torch.autograd.Function):
         dev = z.device
         zc, mc = z.detach().float().contiguous(), m.detach().float().contiguous()
         lc = None if logs is None else logs.detach().float().contiguous()
-        acc = ops.zeros_small(2, torch.float32, dev)
+        acc = torch.empty(2 * 2048, dtype=torch.float32, device=dev)       # GT_MLE_PARTS partial pairs, all written by the kernel
         _lib.check(L.gt_mle_sums(_lib.ptr(zc), _lib.ptr(mc), _lib.ptr(lc), _lib.ptr(acc), zc.numel(), _lib.current_stream(dev)), "gt_mle_sums")
         # the scalar tail in one launch: loss = (acc[0] + 0.5 acc[1] - sum logdet) / denom + 0.5 log 2pi, denom = C * sum(mask)
         ld = logdet.detach().float().contiguous()

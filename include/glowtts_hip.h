@@ -373,9 +373,11 @@ int gt_logp_f32(const float* x_m, const float* x_logs, const float* z, float* lo
 int gt_prior_expand(const float* x_m, const int32_t* frame2token, float* z_m, int B, int C, int Tx, int Ty, void* stream);
 int gt_prior_expand_bwd(const float* dz_m, const int32_t* frame2token, float* dx_m, int B, int C, int Tx, int Ty, void* stream);
 
-/* mle_loss pieces (commons.py:28-33): acc2[0] += sum(logs), acc2[1] += sum(exp(-2 logs)(z-m)^2);
+/* mle_loss pieces (commons.py:28-33): gt_mle_sums leaves GT_MLE_PARTS partial pairs (sum(logs), sum(exp(-2 logs)(z-m)^2)) in acc2 — one per
+ * workgroup, plain stores, summed by gt_mle_finish;
  * backward: dz = g e^{-2 logs}(z-m), dm = -dz, dlogs = g (1 - e^{-2 logs}(z-m)^2), g = *gscale (/ *gdenom when gdenom != NULL:
  * the loss's denominator stays on the device); dlogdet (optional, [B]) receives -g. */
+#define GT_MLE_PARTS 2048      /* acc2 holds this many (sum logs, sum exp(-2 logs)(z-m)^2) partial pairs: 2 * GT_MLE_PARTS floats, all written */
 int gt_mle_sums(const float* z, const float* m, const float* logs, float* acc2, size_t n, void* stream);
 int gt_mle_bwd(const float* z, const float* m, const float* logs, const float* gscale, float* dz, float* dm, float* dlogs,
                size_t n, const float* gdenom, float* dlogdet, int B, void* stream);
