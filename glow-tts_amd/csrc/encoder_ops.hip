@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void gt_layernorm_bwd_kernel(LnBwdA
 // Parameter gradients from the partial rows backward launches left (gt_layernorm_bwd_partials, gt_dds_*_bwd with `partials`): the
 // column sums of up to GT_PARTIALS_MAX buffers [n_rows][Ca + Cb] are ADDED to dst_a[Ca] | dst_b[Cb] — one launch at the end of a
 // module's backward instead of same-address atomics from every workgroup of every one of them.
-// block (x: 64-column group, y: job); thread = (column, row phase)
+// block (x: 64-column group, y: job, z: slice of the rows — PARTIALS_ZS adders per address); thread = (column, row phase)
+constexpr int PARTIALS_ZS = 4;
 __global__ __launch_bounds__(256) void gt_param_partials_reduce_kernel(gt_partials_args a)
 {
   __shared__ float red[4][64];
@@ -166,23 +167,24 @@ __global__ __launch_bounds__(256) void gt_param_partials_reduce_kernel(gt_partia
   const int W = j.Ca + j.Cb;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   if (blockIdx.x * 64 >= W) return;
+  const int per = ((j.n_rows + PARTIALS_ZS - 1) / PARTIALS_ZS + 3) & ~3, r0 = blockIdx.z * per, r1 = min(j.n_rows, r0 + per);
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < W) {
     const float* pp = j.partials + c;
     const size_t st = (size_t)W;
-    int r = ph;
-    for (; r + 12 < j.n_rows; r += 16) {
+    int r = r0 + ph;
+    for (; r + 12 < r1; r += 16) {
       const float v0 = pp[(size_t)r * st], v1 = pp[(size_t)(r + 4) * st], v2 = pp[(size_t)(r + 8) * st], v3 = pp[(size_t)(r + 12) * st];
       s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    for (; r < j.n_rows; r += 4) s0 += pp[(size_t)r * st];
+    for (; r < r1; r += 4) s0 += pp[(size_t)r * st];
   }
   red[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ph == 0 && c < W) {
     const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     float* d = c < j.Ca ? j.dst_a + c : j.dst_b + (c - j.Ca);
-    *d += t;
+    atomicAdd(d, t);
   }
 }
 
@@ -924,7 +926,7 @@ extern "C" int gt_param_partials_reduce(const gt_partials_args* args, void* stre
     if (!b.partials || !b.dst_a || b.n_rows <= 0 || b.Ca <= 0 || b.Cb < 0 || (b.Cb > 0 && !b.dst_b)) return GT_E_INVAL;
     maxw = b.Ca + b.Cb > maxw ? b.Ca + b.Cb : maxw;
   }
-  hipLaunchKernelGGL(gt_param_partials_reduce_kernel, dim3((maxw + 63) / 64, args->n_jobs), dim3(256), 0, GT_ST(stream), *args);
+  hipLaunchKernelGGL(gt_param_partials_reduce_kernel, dim3((maxw + 63) / 64, args->n_jobs, PARTIALS_ZS), dim3(256), 0, GT_ST(stream), *args);
   GT_RET();
 }
 
