@@ -277,6 +277,7 @@ class RowsConfig:
         # train.Trainer's single-backward step turns it off and seeds the backward with one root per stream instead: the decoder's
         # backward then starts behind the likelihood terms, beside the predictors' forward, instead of behind it
         self.join_predictors = True
+        self.front_stream = os.environ.get("GT_FRONT_STREAM", "1") != "0"    # the conditioning front end (and its backward) on a stream of its own
 
 
 DEFAULT_ROWS = RowsConfig()

@@ -378,6 +378,16 @@ def mle_loss(z, m, logs, logdet, mask):
 _ENC_STREAMS = {}            # device -> the branch's stream (one per device and process: streams are a device resource, not model state)
 
 
+_FRONT_STREAMS = {}
+
+
+def _front_stream(dev):
+    key = str(dev)
+    if key not in _FRONT_STREAMS:
+        _FRONT_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _FRONT_STREAMS[key]
+
+
 def _encoder_stream(dev):
     key = str(dev)
     if key not in _ENC_STREAMS:
@@ -644,9 +654,28 @@ class FlowGenerator(nn.Module):
         trainer all-reduces the decoder's 90 % of the gradient bytes while the encoder's backward runs.
         noise = (e_w [b,2,t_x], e_p [b,1,t_y], e_e [b,1,t_y]): the predictors' torch.randn draws (models.py:288,383,457),
         injected by the parity tests."""
-        g = self.condition(g, emo, emo_cartesian)
-        if l is not None:
-            l = self.emb_l(l).unsqueeze(-1)                          # language ids [b] -> [b, lin_channels, 1] (models.py:1012-1013)
+        # The conditioning front end (speaker / emotion / language embeddings: ~40 small launches on [B, <= 512] tensors) runs on a
+        # stream of its own when the step forks anyway: autograd then replays its BACKWARD there too — it needs the conditioning
+        # vector's gradient from every consumer, so on the caller's stream it queued behind the decoder's weight gradients, optimizer
+        # pass and packing and ended the step with 0.65 ms of small launches on an idle machine (cfg 5).
+        front = self.rows_cfg.front_stream and self.rows_cfg.encoder_stream and x.is_cuda and torch.is_grad_enabled() and \
+            (self.use_spk_embeds or self.use_emo_embeds or l is not None)
+        if front:
+            caller = torch.cuda.current_stream(x.device)
+            fs = _front_stream(x.device)
+            fs.wait_stream(caller)
+            with torch.cuda.stream(fs):
+                g = self.condition(g, emo, emo_cartesian)
+                if l is not None:
+                    l = self.emb_l(l).unsqueeze(-1)
+            caller.wait_stream(fs)
+            for t_ in (g, l):
+                if t_ is not None:
+                    t_.record_stream(caller)
+        else:
+            g = self.condition(g, emo, emo_cartesian)
+            if l is not None:
+                l = self.emb_l(l).unsqueeze(-1)                      # language ids [b] -> [b, lin_channels, 1] (models.py:1012-1013)
         pending = self.__dict__.pop("_prepare_side", None)           # train.Trainer packed on this stream and left the join to us:
         if pending is not None:                                      # the front end above ran beside the packing launches
             torch.cuda.current_stream(x.device).wait_stream(pending)
