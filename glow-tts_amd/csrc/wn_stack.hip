@@ -864,10 +864,14 @@ extern "C" int gt_dev_wns_phases(void* dst, size_t bytes)
 // back to back (tools/wn_layer_bench.py stack, WN_BENCH_TY=..., round 3; forward / backward us per launch, 64-row -> 32-row tiles):
 // 3 072 rows 61.7 / 71.4 -> 51.2 / 59.3;  3 584 rows 62.0 / 72.9 -> 51.7 / 61.0;  5 120 rows 63.2 / 75.6 -> 57.1 / 68.2 (and nothing left
 // of it inside the cfg 4 / cfg 5 steps, whose other branch then finds no free CU: the threshold stays below that);  9 728 rows: 2 rounds.
-static int stack_row_blocks(int R, int n_layers)
+#ifndef WNS_SMALL_TILE_MAX_WGS_FWD
+#define WNS_SMALL_TILE_MAX_WGS_FWD 128        // the FORWARD takes the 32-row form up to here: with cfg 5's final schedule its decoder forward runs
+#endif                                        // alone on the machine for 2.6 ms (14.55-14.64 -> 14.24 ms per step); the backward, which always
+                                              // shares it with the predictors' backward, at the same threshold: 15.75 ms
+static int stack_row_blocks(int R, int n_layers, bool fwd = false)
 {
   const int own2 = BM - 4 * (n_layers - 1), own1 = 32 - 4 * (n_layers - 1);
-  return (own1 >= 8 && (R + own2 - 1) / own2 <= WNS_SMALL_TILE_MAX_WGS) ? 1 : 2;
+  return (own1 >= 8 && (R + own2 - 1) / own2 <= (fwd ? WNS_SMALL_TILE_MAX_WGS_FWD : WNS_SMALL_TILE_MAX_WGS)) ? 1 : 2;
 }
 extern "C" int gt_wn_stack_rows_per_workgroup(int n_layers) { return BM - 4 * (n_layers - 1); }
 
@@ -910,7 +914,7 @@ extern "C" int gt_wn_stack_fwd(const gt_wn_stack_fwd_args* args, void* stream)
         return GT_E_LAUNCH;
     attr = true;
   }
-  const int nbm = stack_row_blocks(a.R, a.n_layers);
+  const int nbm = stack_row_blocks(a.R, a.n_layers, true);
   const int own = 32 * nbm - 4 * (a.n_layers - 1);
   const dim3 grid((a.R + own - 1) / own), block(256);
   const int mode = affine ? 2 : (a.cond ? 1 : 0);
