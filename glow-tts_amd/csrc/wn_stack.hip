@@ -865,7 +865,8 @@ extern "C" int gt_dev_wns_phases(void* dst, size_t bytes)
 // 3 072 rows 61.7 / 71.4 -> 51.2 / 59.3;  3 584 rows 62.0 / 72.9 -> 51.7 / 61.0;  5 120 rows 63.2 / 75.6 -> 57.1 / 68.2 (and nothing left
 // of it inside the cfg 4 / cfg 5 steps, whose other branch then finds no free CU: the threshold stays below that);  9 728 rows: 2 rounds.
 #ifndef WNS_SMALL_TILE_MAX_WGS_FWD
-#define WNS_SMALL_TILE_MAX_WGS_FWD 128        // the FORWARD takes the 32-row form up to here: with cfg 5's final schedule its decoder forward runs
+#define WNS_SMALL_TILE_MAX_WGS_FWD 98         // the FORWARD takes the 32-row form up to here (2.6 x 98 = 255 workgroups: one round of the
+                                              // chip; measured at 128, which cfg 4 / cfg 5's 85 / 89 tiles are below either way): with cfg 5's final schedule its decoder forward runs
 #endif                                        // alone on the machine for 2.6 ms (14.55-14.64 -> 14.24 ms per step); the backward, which always
                                               // shares it with the predictors' backward, at the same threshold: 15.75 ms
 static int stack_row_blocks(int R, int n_layers, bool fwd = false)
