@@ -276,6 +276,7 @@ class RowsConfig:
         # the caller's stream waits for the predictors' branch at the end of forward() (so that the losses can be read there).
         # train.Trainer's single-backward step turns it off and seeds the backward with one root per stream instead: the decoder's
         # backward then starts behind the likelihood terms, beside the predictors' forward, instead of behind it
+        self.dp_balance = os.environ.get("GT_DP_BALANCE", "1") != "0"        # long texts: the duration predictor on the caller's stream (text_models)
         self.join_predictors = True
         self.front_stream = os.environ.get("GT_FRONT_STREAM", "1") != "0"    # the conditioning front end (and its backward) on a stream of its own
 

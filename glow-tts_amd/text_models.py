@@ -701,6 +701,11 @@ class FlowGenerator(nn.Module):
         # the decoder's too.  Both are chains of latency-bound kernels on a fraction of the CUs.
         fork = self.rows_cfg.encoder_stream and x.is_cuda
         logw = None
+        # Long texts (cfg 3: T_x = 375 against 436 squeezed mel frames) make the encoder's branch the longer one — its backward ends
+        # 0.9 ms after the decoder's —, so the deterministic duration predictor (0.08 ms forward, 0.33 ms backward, needs the encoder's
+        # output only and hands nothing back to it: models.py:586 detaches) then runs on the caller's stream instead of the encoder's.
+        # Decided on the PADDED shapes, so that it is the same for every batch of a captured graph's key.
+        dp_here = fork and not self.use_sdp and self.rows_cfg.dp_balance and x.shape[1] * self.n_sqz >= 0.6 * y.size(2)
         if fork:
             main = torch.cuda.current_stream(x.device)
             enc_stream = _encoder_stream(x.device)
@@ -709,7 +714,7 @@ class FlowGenerator(nn.Module):
                 ops.mark("enc fwd begin")
                 xo, x_m, x_logs, x_mask = self.encoder(x, x_lengths, l=l, g=g, prepared=True)
                 ops.mark("enc fwd end")
-                if not self.use_sdp:
+                if not self.use_sdp and not dp_here:
                     logw = self._predict_logw(g, l)   # needs the encoder's output only (x is detached, models.py:586): same branch
                     ops.mark("dp fwd end")
         else:
@@ -732,6 +737,9 @@ class FlowGenerator(nn.Module):
             ops.mark("fwd joined")
             for t_ in (xo, x_m, x_logs, x_mask, self.encoder._last_rows[1]) + ((logw,) if logw is not None else ()):
                 t_.record_stream(main)
+            if dp_here:
+                logw = self._predict_logw(g, l)
+                ops.mark("dp fwd end")
         with torch.no_grad():
             logp, mas = _LogpMasFn.run(x_m, x_logs, z, x_lengths, y_lengths, self.mean_only)
             self._last_mas_path = mas.path                                    # (the searched alignment, whatever `path` says)
