@@ -65,3 +65,35 @@ def test_capture_policy_admits_on_the_nth_sight_and_forgets():
     for k in "bcdefg":
         pol.admit(k)
     assert len(pol.seen) <= 4
+
+
+def test_flat_buffer_order_decoder_conditioning_layers_before_the_flush_parameters():
+    """train.Trainer's flat buffer (host logic, no GPU): everything but the decoder first, then the decoder's conditioning layers
+    (their gradients arrive through autograd at the end of the backward), then the parameters the decoder's batched weight-gradient
+    flush completes — the tail [dec_cov, end) that the early optimizer pass and the end-of-step packing cover; dec0 still marks the
+    start of the decoder's slice for the phased all-reduce."""
+    import torch
+    from glow_tts_amd import train
+    for gin in (0, 32):
+        cfg = dict(train.BASE_MODEL, n_blocks_dec=2, n_layers_enc=1, gin_channels=gin)
+        m = train.build_model(cfg, device="cpu")
+        tr = train.Trainer(m, graph=False)
+        names = {id(p): n for n, p in m.named_parameters()}
+        ns = [names[id(p)] for p in tr.buckets.params]
+        assert sorted(ns) == sorted(names.values())                         # every parameter exactly once
+        assert tr.buckets.n_accum <= tr.dec0 <= tr.dec_cov <= len(ns)
+        assert not any(n.startswith("decoder.") for n in ns[tr.buckets.n_accum:tr.dec0])
+        assert all(n.startswith("decoder.") and ".cond_layer." in n for n in ns[tr.dec0:tr.dec_cov])
+        assert all(n.startswith("decoder.") and ".cond_layer." not in n and "cond_layer1" not in n for n in ns[tr.dec_cov:])
+        assert (tr.dec_cov > tr.dec0) == (gin > 0)
+        assert tr.dec0_off == tr.buckets.offsets[tr.dec0] and tr.dec_cov_off == tr.buckets.offsets[tr.dec_cov]
+        # the parameters are views of the flat buffer in that order, and a torch in-place write into the covered tail is seen by the
+        # version check that guards the end-of-step packing (a write through .data is not: Trainer.invalidate_packed)
+        v0 = tr._param_version()
+        with torch.no_grad():
+            tr.buckets.params[tr.dec_cov].mul_(1.0)
+        assert tr._param_version() != v0
+        v1 = tr._param_version()
+        with torch.no_grad():
+            tr.buckets.params[0].mul_(1.0)                                    # not a parameter of the covered tail
+        assert tr._param_version() == v1
