@@ -97,3 +97,19 @@ def test_flat_buffer_order_decoder_conditioning_layers_before_the_flush_paramete
         with torch.no_grad():
             tr.buckets.params[0].mul_(1.0)                                    # not a parameter of the covered tail
         assert tr._param_version() == v1
+
+
+def test_step_head_cpu_fallback_matches_the_separate_calls():
+    """ops.step_head off the GPU: the separate fills + the seed bump it replaces (one launch, gt_step_zero, on the GPU — tested there)."""
+    import torch
+    from glow_tts_amd import ops
+    d = torch.device("cpu")
+    s0 = int(ops.seed_word(d).item())
+    x = torch.ones(12)
+    ops.step_head(d, extra=x)
+    assert int(x.count_nonzero()) == 0 and (int(ops.seed_word(d).item()) - s0) & 0xffffffff == 0x632BE5AB
+    a = ops.zeros_small((5,), torch.float32, d)                            # the arena is open: slices of it are handed out
+    assert a.shape == (5,) and int(a.count_nonzero()) == 0
+    ops.step_head(d, extra=None, bump=False)
+    assert int(ops.seed_word(d).item()) & 0xffffffff == (s0 + 0x632BE5AB) & 0xffffffff
+    ops.arena_end(d)
