@@ -113,3 +113,28 @@ def test_step_head_cpu_fallback_matches_the_separate_calls():
     ops.step_head(d, extra=None, bump=False)
     assert int(ops.seed_word(d).item()) & 0xffffffff == (s0 + 0x632BE5AB) & 0xffffffff
     ops.arena_end(d)
+
+
+def test_flat_adamw_early_range_and_the_rest_cover_the_active_runs_once():
+    """FlatAdamW.step_early + step() (host logic; the kernel launch is replaced by a recorder): the early range and what step() launches
+    afterwards partition exactly the runs of parameters that have a gradient — nothing twice, nothing of a gradient-less parameter."""
+    import torch
+    from glow_tts_amd import train
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (70, 130, 64, 200, 90, 300)]
+    gb = train.GradBuckets(ps, world=1)
+    opt = train.FlatAdamW(gb, 1e-3, (0.9, 0.98), 1e-9)
+    launched = []
+    opt._launch = lambda s, e: launched.append((s, e))
+    opt._begin = lambda: None
+    gb.active = [True, False, True, True, True, True]                      # parameter 1 never gets a gradient
+    lo, hi = gb.offsets[4], gb.total                                        # the tail: parameters 4 and 5
+    opt.step_early(lo, hi)
+    assert launched == [(lo, hi)]
+    opt.step()
+    covered = sorted(launched)
+    want = [(gb.offsets[0], gb.offsets[1]), (gb.offsets[2], lo), (lo, hi)]
+    assert covered == sorted(want), (covered, want)
+    assert opt._early is None
+    launched.clear()
+    opt.step()                                                              # no early pass this time: the plain runs
+    assert sorted(launched) == [(gb.offsets[0], gb.offsets[1]), (gb.offsets[2], gb.total)]
